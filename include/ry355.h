@@ -1,0 +1,113 @@
+/* ry355.h -- C ABI of libry355.so: the MI355X-native convert hot path of realtime-yukarin.
+ *
+ * The reference has no FFI for this path: its boundary is the Python surface of two un-vendored
+ * packages.  Each entry point below names the reference call it stands in for; the ctypes binding a
+ * maintainer adds is realtime_yukarin_amd/_lib.py.
+ *
+ * Conventions: plain pointers and sizes, no torch types.  Every function returning int returns 0 on
+ * success and a negative RY_E* code on failure (never aborts); ry_last_error() gives the message for
+ * the calling thread.  All tensors are float32, channels-last:
+ *   stage-1  [batch][frames][channels]      (= the (N, C) feature matrix of encode_feature, untransposed)
+ *   stage-2  [batch][frames][bins]
+ * `on_device` = 0: x / y are host pointers, the call returns after the result is in y.
+ * `on_device` = 1: x / y are device pointers on the context's GPU; the call only enqueues work on the
+ *                  context stream (ry_stream); use ry_sync or your own event to wait.
+ */
+#ifndef RY355_H
+#define RY355_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RY_OK 0
+#define RY_EINVAL (-1)   /* bad argument / shape the predictor cannot take */
+#define RY_EHIP (-2)     /* HIP runtime error (message carries hipGetErrorString) */
+#define RY_ENOMEM (-3)
+#define RY_ESTATE (-4)   /* wrong context / destroyed handle */
+
+#define RY_ACT_NONE 0
+#define RY_ACT_LRELU 1
+#define RY_ACT_RELU 2
+#define RY_ACT_GLU 3
+
+typedef struct ry_ctx ry_ctx;
+typedef struct ry_net ry_net;
+
+/* `create_predictor(config.model)` / `create_predictor_sr(config.model)` arguments ([MEM], built inside
+ * yukarin.AcousticConverter.__init__ / become_yukarin.SuperResolution.__init__; reference call sites
+ * realtime_voice_conversion/converter/yukarin_converter.py:40-55, check.py:54-63). */
+typedef struct ry_net_desc {
+    int ndim;               /* 1 = stage-1 Predictor (Convolution1D), 2 = stage-2 SRPredictor (Convolution2D) */
+    int in_ch, out_ch;      /* stage-2: 1, 1 */
+    int base;               /* generator_base_channels */
+    int extensive_layers;   /* generator_extensive_layers */
+    int width;              /* stage-2: bins fed to the predictor (fft_size/2 = 512); stage-1: 1 */
+    float bn_eps;           /* Chainer BatchNormalization eps = 2e-5 */
+    float lrelu_slope;      /* F.leaky_relu slope = 0.2 */
+} ry_net_desc;
+
+/* One context per (process, GPU).  Create it in the process that converts (after fork), cf. the
+ * convert worker process of run.py:69-79.  `chainer.cuda.get_device(gpu).use()` equivalent. */
+int ry_init(int device_ordinal, ry_ctx** out);
+void ry_shutdown(ry_ctx* ctx);
+int ry_sync(ry_ctx* ctx);
+void* ry_stream(ry_ctx* ctx);                 /* hipStream_t the context enqueues on */
+int ry_device_count(void);
+const char* ry_last_error(void);
+
+/* Number of floats of the flat weight blob = K-list order of the Chainer save_npz keys:
+ * encoder/c0/{W,b}, encoder/c{1..7}/{c/W,c/b,batchnorm/gamma,beta,avg_mean,avg_var}, decoder/c{0..6}/..., decoder/c7/{W,b}. */
+size_t ry_net_param_count(const ry_net_desc* desc);
+
+/* `chainer.serializers.load_npz(model_path, model)` + `model.to_gpu(gpu)` ([MEM]): takes the flat blob
+ * (host, or device when weights_on_device -- e.g. the buffer an RCCL broadcast just filled), folds
+ * BatchNormalization into per-channel scale/shift and re-lays the filters out for the kernels. */
+int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, size_t n_floats,
+                  int weights_on_device, ry_net** out);
+void ry_net_destroy(ry_net* net);
+
+/* `Predictor.__call__` / `SRPredictor.__call__` on an already padded block (frames % 128 == 0 when
+ * extensive_layers == 8).  stage-1: x [batch][frames][in_ch] -> y [batch][frames][out_ch];
+ * stage-2: x [batch][frames][width] -> y [batch][frames][width]. */
+int ry_net_forward(ry_net* net, const float* x, float* y, int batch, int frames, int on_device);
+
+/* Array part of `AcousticConverter.convert` (voice_changer.py:33): x [batch][n_frames][in_ch] ->
+ * pad time to n + (128 - n % 128) with the per-channel minimum -> Predictor -> crop -> y [batch][n_frames][out_ch]. */
+int ry_ac_convert(ry_net* stage1, const float* x, float* y, int batch, int n_frames, int on_device);
+
+/* `SuperResolution.convert` (voice_changer.py:41): sp [batch][n_frames][width+1] -> pad 'minimum' -> log ->
+ * drop last bin -> SRPredictor -> edge-pad one bin -> exp -> crop -> out [batch][n_frames][width+1]. */
+int ry_sr_convert(ry_net* stage2, const float* sp, float* out, int batch, int n_frames, int on_device);
+
+/* ---- single operators (the Chainer links of SURVEY.md section 2.1), host pointers, Chainer weight layouts ---- */
+/* L.ConvolutionND(1) / L.DeconvolutionND(1) [+ L.BatchNormalization] [+ activation].  x [B][L][Cin] ->
+ * y [B][Lout][Cout] (GLU: Cout/2 channels).  W: (Cout,Cin,k) or, transposed, (Cin,Cout,k); bn = gamma|beta|avg_mean|avg_var
+ * (4*Cout floats) or NULL.  k <= 4; transposed requires k4 s2 p1.  splits = 0 lets the library choose. */
+int ry_conv1d(ry_ctx* ctx, const float* x, int B, int L, int Cin, const float* W, const float* bias, const float* bn,
+              int Cout, int k, int stride, int pad, int dilate, int transposed, int act, int splits, float* y);
+/* L.Convolution2D / L.Deconvolution2D.  x [B][H][W][Cin] -> y [B][Ho][Wo][Cout].  path: 0 auto, 1 implicit-GEMM (MFMA),
+ * 2 direct (VALU); tile: 0 auto, 1 = 128x128, 2 = 256x64, 3 = 64x128, 4 = 32x128. */
+int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int W, int Cin, const float* Wt, const float* bias, const float* bn,
+              int Cout, int k, int stride, int pad, int transposed, int act, int path, int tile, int splits, float* y);
+
+/* ---- measurement ---- */
+int ry_timer_start(ry_ctx* ctx);              /* hipEventRecord on the context stream */
+int ry_timer_stop(ry_ctx* ctx, float* ms);    /* record + synchronize + elapsed */
+
+typedef struct ry_kernel_stat {
+    char name[48];          /* kernel family, e.g. "ry_igemm_f32<128,128>" */
+    char layer[24];         /* e.g. "encoder/c3" */
+    float ms;               /* average duration over `reps` launches (hipEvents on the context stream) */
+    double flops;           /* algorithmic FLOPs of this launch */
+    double bytes;           /* algorithmic bytes: weights + input + output once */
+    int grid[3];
+} ry_kernel_stat;
+/* Runs the forward `reps` times launch by launch, bracketing every kernel with HIP events. */
+int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,111 @@
+"""ctypes binding of libry355.so (C ABI: include/ry355.h).
+
+This is the whole host<->device boundary: plain pointers and sizes, no torch types.  The product
+library is `realtime_yukarin_amd/libry355.so`, built in-tree by `__graft_entry__.build()`
+(hipcc --offload-arch=gfx950).  There is NO CPU fallback: if the library is missing or no GPU is
+visible, every entry point of this package raises.  (tests/ may bind a different path -- the
+host-side SIMT emulator build of the same sources -- by constructing `Ry355Lib(path)` explicitly;
+nothing in this package ever does.)
+"""
+import ctypes
+from pathlib import Path
+
+import numpy
+
+LIB_NAME = 'libry355.so'
+DEFAULT_LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GLU = 0, 1, 2, 3
+ACTS = {None: ACT_NONE, 'none': ACT_NONE, 'lrelu': ACT_LRELU, 'relu': ACT_RELU, 'glu': ACT_GLU}
+PATH_AUTO, PATH_IGEMM, PATH_DIRECT = 0, 1, 2
+TILES = {None: 0, 'auto': 0, '128x128': 1, '256x64': 2, '64x128': 3, '32x128': 4}
+
+# every symbol include/ry355.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    'ry_init', 'ry_shutdown', 'ry_sync', 'ry_stream', 'ry_device_count', 'ry_last_error',
+    'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_forward',
+    'ry_ac_convert', 'ry_sr_convert', 'ry_conv1d', 'ry_conv2d',
+    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile',
+)
+
+
+class RyNetDesc(ctypes.Structure):
+    _fields_ = [('ndim', ctypes.c_int), ('in_ch', ctypes.c_int), ('out_ch', ctypes.c_int),
+                ('base', ctypes.c_int), ('extensive_layers', ctypes.c_int), ('width', ctypes.c_int),
+                ('bn_eps', ctypes.c_float), ('lrelu_slope', ctypes.c_float)]
+
+
+class RyKernelStat(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char * 48), ('layer', ctypes.c_char * 24), ('ms', ctypes.c_float),
+                ('flops', ctypes.c_double), ('bytes', ctypes.c_double), ('grid', ctypes.c_int * 3)]
+
+
+class Ry355Error(RuntimeError):
+    pass
+
+
+_FP = ctypes.POINTER(ctypes.c_float)
+_VP = ctypes.c_void_p
+
+
+def _fptr(a):
+    """float* of a C-contiguous float32 ndarray, or a raw device address (int)."""
+    if isinstance(a, int):
+        return ctypes.cast(ctypes.c_void_p(a), _FP)
+    if a is None:
+        return ctypes.cast(ctypes.c_void_p(0), _FP)
+    assert isinstance(a, numpy.ndarray) and a.dtype == numpy.float32 and a.flags['C_CONTIGUOUS'], \
+        'expected a C-contiguous float32 array'
+    return a.ctypes.data_as(_FP)
+
+
+class Ry355Lib(object):
+    def __init__(self, path=None):
+        path = Path(path) if path is not None else DEFAULT_LIB_PATH
+        if not path.exists():
+            raise Ry355Error(
+                '%s not found: the MI355X HIP library is not built (run `python -c "import __graft_entry__ as g; '
+                'g.build()"` at the repo root). This package has no CPU fallback.' % path)
+        self.path = path
+        self.dll = ctypes.CDLL(str(path))
+        d = self.dll
+        d.ry_last_error.restype = ctypes.c_char_p
+        d.ry_init.argtypes = [ctypes.c_int, ctypes.POINTER(_VP)]
+        d.ry_shutdown.argtypes = [_VP]
+        d.ry_shutdown.restype = None
+        d.ry_sync.argtypes = [_VP]
+        d.ry_stream.argtypes = [_VP]
+        d.ry_stream.restype = _VP
+        d.ry_device_count.restype = ctypes.c_int
+        d.ry_net_param_count.argtypes = [ctypes.POINTER(RyNetDesc)]
+        d.ry_net_param_count.restype = ctypes.c_size_t
+        d.ry_net_create.argtypes = [_VP, ctypes.POINTER(RyNetDesc), _FP, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(_VP)]
+        d.ry_net_destroy.argtypes = [_VP]
+        d.ry_net_destroy.restype = None
+        d.ry_net_forward.argtypes = [_VP, _FP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        d.ry_ac_convert.argtypes = [_VP, _FP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        d.ry_sr_convert.argtypes = [_VP, _FP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        d.ry_conv1d.argtypes = [_VP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP] + [ctypes.c_int] * 8 + [_FP]
+        d.ry_conv2d.argtypes = [_VP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP] + [ctypes.c_int] * 9 + [_FP]
+        d.ry_timer_start.argtypes = [_VP]
+        d.ry_timer_stop.argtypes = [_VP, ctypes.POINTER(ctypes.c_float)]
+        d.ry_net_profile.argtypes = [_VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RyKernelStat),
+                                     ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+
+    def check(self, rc):
+        if rc != 0:
+            raise Ry355Error('libry355: %s (code %d)' % ((self.dll.ry_last_error() or b'').decode('utf-8', 'replace'), rc))
+
+    def device_count(self):
+        return int(self.dll.ry_device_count())
+
+
+_default_lib = None
+
+
+def default_lib():
+    """The product library (never the emulator)."""
+    global _default_lib
+    if _default_lib is None:
+        _default_lib = Ry355Lib()
+    return _default_lib

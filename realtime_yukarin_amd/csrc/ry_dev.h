@@ -1,0 +1,36 @@
+// ry_dev.h -- the few device primitives the gfx950 kernels use, behind one include.
+//
+// Product build (hipcc --offload-arch=gfx950): the real HIP runtime and CDNA4 builtins.
+// Test build (-DRY_HOST_EMU, tests/emu/): the SAME kernel sources run on a host-side SIMT
+// emulator (cooperative fibers, 64-lane waves, emulated v_mfma_f32_32x32x2_f32 fragment maps)
+// so index arithmetic can be checked against the oracle without a GPU.  The emulator is test
+// infrastructure; libry355.so never contains it.
+#pragma once
+
+#ifdef RY_HOST_EMU
+#include "ry_emu.h"
+#else
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RY_DEV __device__ __forceinline__
+#define RY_KERNEL(...) __global__ __launch_bounds__(__VA_ARGS__)
+
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
+// D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] += sum_k A[row][k]*B[k][col]  (exact f32 fma chain).
+RY_DEV f32x16 ry_mfma_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+RY_DEV float ry_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+RY_DEV float ry_shfl(float v, int src) { return __shfl(v, src, 64); }
+RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }
+
+typedef hipStream_t ry_stream_t;
+#define RY_LAUNCH(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#endif
+
+RY_DEV f32x4 ry_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+RY_DEV void ry_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }

@@ -1,0 +1,493 @@
+// ry_kernels.h -- hand-written gfx950 (CDNA4) kernels for the convert hot path.
+//
+// Replaces what Chainer dispatches to cuDNN/CuPy for the two predictors the reference runs per
+// buffer (/root/reference/realtime_voice_conversion/yukarin_wrapper/voice_changer.py:33 stage-1,
+// :41 stage-2; SURVEY.md section 2.1 kernel inventory).  All activations are channels-last fp32:
+//   stage-1  x[b][l][c]        (the (N, C) feature matrix the reference transposes is already this)
+//   stage-2  x[b][h][w][c]
+// so the GEMM-K axis (input channels) is contiguous and every load/store is a 16-byte lane access.
+//
+// Kernels:
+//   ry_igemm_f32        stage-2 conv / 4-phase sub-pixel deconv as implicit GEMM on
+//                       v_mfma_f32_32x32x2_f32 (exact fp32), LDS-staged 128x128 / 256x64 / 64x128 /
+//                       32x128 tiles, folded BN + activation epilogue, optional split-K slabs
+//   ry_splitk_reduce    sum of split-K slabs + folded BN + activation
+//   ry_conv_direct      generic VALU conv (Cin=1 first layer, Cout=1 last layer, odd channel counts)
+//   ry_conv1d_ws        stage-1 weight-streaming 1-D conv/deconv: lanes = output channels (coalesced
+//                       16-byte weight reads), LDS-staged input tile whose staging applies the
+//                       PRODUCER's split-sum + folded BN + activation (deferred epilogue; skip
+//                       connections read through two source descriptors, no materialised concat)
+//   ry_materialize      split-sum + folded BN + activation (+GLU) into a dense tensor
+//   ry_colmin / ry_pad_rows / ry_sr_post   the numpy.pad('minimum') / log / exp / edge-pad wrappers
+#pragma once
+#include "ry_dev.h"
+
+enum { RY_ACT_NONE = 0, RY_ACT_LRELU = 1, RY_ACT_RELU = 2, RY_ACT_GLU = 3 };
+
+RY_DEV float ry_act(float v, int act, float slope) {
+    if (act == RY_ACT_LRELU) return v >= 0.f ? v : v * slope;
+    if (act == RY_ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+RY_DEV float ry_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+
+// ---------------------------------------------------------------------------------------------
+// Convolution geometry shared by the implicit-GEMM and the direct kernel.
+// GEMM rows enumerate (b, ry, rx) over an Mh x Mw grid per image; input coordinate of tap t is
+// (ry*stride - pad + tdy[t], rx*stride - pad + tdx[t]); output pixel is (ry*ostride + pdy, rx*ostride + pdx).
+//   conv  k s p : Mh=Ho, Mw=Wo, stride=s, pad=p, ostride=1, 1 phase, taps (ky,kx)
+//   deconv k4s2p1: Mh=Hi, Mw=Wi, stride=1, pad=0, ostride=2, 4 phases of 2x2 taps (sub-pixel form)
+// ---------------------------------------------------------------------------------------------
+struct RyConvGeom {
+    const float* src1;
+    const float* src2;          // second source of a skip concat (channels C1..C1+C2), or null
+    int C1, C2;
+    int B, Hi, Wi, Ho, Wo;
+    int Mh, Mw;
+    int stride, pad, ostride;
+    int nphases, ntaps;
+    int N;                      // output channels
+    signed char tdy[4][16], tdx[4][16];
+    signed char pdy[4], pdx[4];
+};
+
+struct RyIgemmParams {
+    RyConvGeom g;
+    const float* wt;            // [phase][N][tap][C1+C2]
+    const float* scale;         // [N] folded BN scale (1 when no BN)
+    const float* shift;         // [N] folded bias/BN shift
+    float* out;                 // splits==1: NHWC output; else slabs [split][B*Ho*Wo][N] of raw sums
+    int splits;
+    int act;
+    float slope;
+    long long slab_stride;
+};
+
+template <int BM, int BN, int WM, int WN>
+RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
+    constexpr int BK = 32, BKP = 36;               // 36-float row stride: conflict-free ds_read_b128
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AR = BM / 32, BR = BN / 32;      // 16-byte loads per thread per K chunk
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float As[BM * BKP];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * BKP];
+    __shared__ int rY[BM], rX[BM], rP[BM], rO[BM];
+
+    const RyConvGeom& g = p.g;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = (int)blockIdx.x * BM;
+    const int n0 = (int)blockIdx.y * BN;
+    const int phase = (int)blockIdx.z / p.splits;
+    const int split = (int)blockIdx.z % p.splits;
+    const int Ctot = g.C1 + g.C2;
+    const int Mimg = g.Mh * g.Mw;
+    const int M = g.B * Mimg;
+
+    // per-row geometry, once per workgroup
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        int yb = -(1 << 20), xb = 0, pb = 0, ob = -1;
+        if (m < M) {
+            const int b = m / Mimg, rem = m - b * Mimg;
+            const int ry = rem / g.Mw, rx = rem - ry * g.Mw;
+            yb = ry * g.stride - g.pad;
+            xb = rx * g.stride - g.pad;
+            pb = b * g.Hi * g.Wi;
+            ob = (b * g.Ho + ry * g.ostride + g.pdy[phase]) * g.Wo + rx * g.ostride + g.pdx[phase];
+        }
+        rY[r] = yb; rX[r] = xb; rP[r] = pb; rO[r] = ob;
+    }
+    __syncthreads();
+
+    const int c4 = (tid & 7) * 4;                  // float offset of this thread's 16 bytes in a K chunk
+    const int rbase = tid >> 3;                    // 0..31
+    int ayb[AR], axb[AR], apb[AR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+        ayb[j] = rY[rbase + 32 * j]; axb[j] = rX[rbase + 32 * j]; apb[j] = rP[rbase + 32 * j];
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int cpt = Ctot / BK;                     // K chunks per tap
+    const int nk = g.ntaps * cpt;
+    const int kc_begin = (int)(((long long)nk * split) / p.splits);
+    const int kc_end = (int)(((long long)nk * (split + 1)) / p.splits);
+    int tap = kc_begin / cpt;
+    int cib = kc_begin - tap * cpt;
+
+    f32x4 areg[AR], breg[BR];
+    auto load_chunk = [&](int tap_, int cib_) {
+        const int ci0 = cib_ * BK;
+        const float* src; int Cs, cil;
+        if (ci0 < g.C1) { src = g.src1; Cs = g.C1; cil = ci0; } else { src = g.src2; Cs = g.C2; cil = ci0 - g.C1; }
+        const int dy = g.tdy[phase][tap_], dx = g.tdx[phase][tap_];
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            const int iy = ayb[j] + dy, ix = axb[j] + dx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi)
+                v = ry_ld4(src + ((size_t)(apb[j] + iy * g.Wi + ix) * Cs + cil + c4));
+            areg[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int n = n0 + rbase + 32 * j;
+            breg[j] = ry_ld4(p.wt + (((size_t)(phase * g.N + n) * g.ntaps + tap_) * Ctot + ci0 + c4));
+        }
+    };
+
+    if (kc_begin < kc_end) load_chunk(tap, cib);
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        __syncthreads();                           // previous chunk's fragment reads are done
+#pragma unroll
+        for (int j = 0; j < AR; ++j) ry_st4(&As[(rbase + 32 * j) * BKP + c4], areg[j]);
+#pragma unroll
+        for (int j = 0; j < BR; ++j) ry_st4(&Bs[(rbase + 32 * j) * BKP + c4], breg[j]);
+        __syncthreads();
+        if (++cib == cpt) { cib = 0; ++tap; }
+        if (kc + 1 < kc_end) load_chunk(tap, cib);  // global loads in flight under the MFMAs below
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = ry_ld4(&As[((wm * TM + i) * 32 + lr) * BKP + s * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(&Bs[((wn * TN + j) * 32 + lr) * BKP + s * 8 + lh * 4]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
+        }
+    }
+
+    // epilogue: D[row=(r&3)+8*(r>>2)+4*lh][col=lr]; 32 lanes store 128 contiguous bytes of one pixel
+    float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + lr;
+        float sc = 1.f, sh = 0.f;
+        if (p.splits == 1) { sc = p.scale[n]; sh = p.shift[n]; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ob = rO[ml];
+                if (ob >= 0) {
+                    float v = acc[i][j][r];
+                    if (p.splits == 1) v = ry_act(fmaf(v, sc, sh), p.act, p.slope);
+                    outp[(size_t)ob * g.N + n] = v;
+                }
+            }
+        }
+    }
+}
+
+struct RyReduceParams {
+    const float* slabs;
+    int splits;
+    long long slab_stride;
+    const float* scale;
+    const float* shift;
+    float* out;
+    long long total;            // elements (multiple of 4)
+    int N;
+    int act;
+    float slope;
+};
+
+RY_KERNEL(256) void ry_splitk_reduce(RyReduceParams p) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= p.total) return;
+    f32x4 s = ry_ld4(p.slabs + i4);
+    for (int k = 1; k < p.splits; ++k) {
+        const f32x4 v = ry_ld4(p.slabs + (size_t)k * (size_t)p.slab_stride + i4);
+        s += v;
+    }
+    const int n = (int)(i4 % p.N);
+    const f32x4 sc = ry_ld4(p.scale + n), sh = ry_ld4(p.shift + n);
+    f32x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(s[u], sc[u], sh[u]), p.act, p.slope);
+    ry_st4(p.out + i4, o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic direct convolution (VALU): one thread per (output pixel, output channel), channel fastest.
+// ---------------------------------------------------------------------------------------------
+struct RyDirectParams {
+    RyConvGeom g;
+    const float* wd;            // [phase][tap][C1+C2][N]
+    const float* scale;
+    const float* shift;
+    float* out;                 // NHWC
+    int act;
+    float slope;
+};
+
+RY_KERNEL(256) void ry_conv_direct(RyDirectParams p) {
+    const RyConvGeom& g = p.g;
+    const int phase = (int)blockIdx.y;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int Mimg = g.Mh * g.Mw;
+    const long long total = (long long)g.B * Mimg * g.N;
+    if (idx >= total) return;
+    const int n = (int)(idx % g.N);
+    const int m = (int)(idx / g.N);
+    const int b = m / Mimg, rem = m - b * Mimg;
+    const int ry = rem / g.Mw, rx = rem - ry * g.Mw;
+    const int yb = ry * g.stride - g.pad, xb = rx * g.stride - g.pad;
+    const int Ctot = g.C1 + g.C2;
+    float acc = 0.f;
+    for (int t = 0; t < g.ntaps; ++t) {
+        const int iy = yb + g.tdy[phase][t], ix = xb + g.tdx[phase][t];
+        if ((unsigned)iy >= (unsigned)g.Hi || (unsigned)ix >= (unsigned)g.Wi) continue;
+        const size_t pix = (size_t)(b * g.Hi + iy) * g.Wi + ix;
+        const float* w = p.wd + ((size_t)(phase * g.ntaps + t) * Ctot) * g.N + n;
+        const float* s1 = g.src1 + pix * g.C1;
+        for (int c = 0; c < g.C1; ++c) acc = fmaf(s1[c], w[(size_t)c * g.N], acc);
+        if (g.C2 > 0) {
+            const float* s2 = g.src2 + pix * g.C2;
+            const float* w2 = w + (size_t)g.C1 * g.N;
+            for (int c = 0; c < g.C2; ++c) acc = fmaf(s2[c], w2[(size_t)c * g.N], acc);
+        }
+    }
+    const size_t ob = (size_t)(b * g.Ho + ry * g.ostride + g.pdy[phase]) * g.Wo + rx * g.ostride + g.pdx[phase];
+    p.out[ob * g.N + n] = ry_act(fmaf(acc, p.scale[n], p.shift[n]), p.act, p.slope);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage-1: weight-streaming 1-D conv / deconv with deferred producer epilogue.
+// ---------------------------------------------------------------------------------------------
+struct RySrc1d {
+    const float* raw;           // [splits][B*L][Craw] raw conv sums (or a plain activation, splits=1)
+    const float* scale;         // [Craw] or null (identity)
+    const float* shift;         // [Craw] or null
+    long long slab_stride;
+    int C;                      // channels this source contributes (GLU: Craw = 2*C)
+    int Craw;
+    int splits;
+    int act;
+};
+
+RY_DEV float ry_src1d_load(const RySrc1d& s, size_t pix, int c, float slope) {
+    const float* q = s.raw + pix * s.Craw + c;
+    float v = q[0];
+    for (int k = 1; k < s.splits; ++k) v += q[(size_t)k * (size_t)s.slab_stride];
+    if (s.scale) v = fmaf(v, s.scale[c], s.shift[c]);
+    if (s.act == RY_ACT_GLU) {
+        const float* qg = q + s.C;
+        float gte = qg[0];
+        for (int k = 1; k < s.splits; ++k) gte += qg[(size_t)k * (size_t)s.slab_stride];
+        if (s.scale) gte = fmaf(gte, s.scale[c + s.C], s.shift[c + s.C]);
+        return v * ry_sigmoid(gte);
+    }
+    return ry_act(v, s.act, slope);
+}
+
+enum { RY_C1D_S2 = 0, RY_C1D_S1 = 1, RY_C1D_DECONV = 2, RY_C1D_GEN = 3 };
+
+struct RyConv1dParams {
+    RySrc1d s[2];
+    int B, Lin, Lout;
+    int Ctot;                   // s[0].C + s[1].C
+    int N;                      // output channels
+    const float* wd;            // [Ctot][N][4]  (taps beyond k are zero)
+    int stride, pad, dil;       // conv modes (deconv is k4 s2 p1)
+    float* out;                 // raw slabs [splits][B*Lout][N]
+    int splits;
+    long long slab_stride;
+    float slope;
+};
+
+// positions of the input tile a wave needs for TL (conv) / TQ (deconv) outputs
+template <int MODE> struct RyC1dTile;
+template <> struct RyC1dTile<RY_C1D_S2> { static constexpr int TL = 16, PP = 36; };
+template <> struct RyC1dTile<RY_C1D_S1> { static constexpr int TL = 16, PP = 20; };
+template <> struct RyC1dTile<RY_C1D_DECONV> { static constexpr int TL = 8, PP = 12; };
+template <> struct RyC1dTile<RY_C1D_GEN> { static constexpr int TL = 16, PP = 132; };
+
+template <int MODE>
+RY_KERNEL(64) void ry_conv1d_ws(RyConv1dParams p) {
+    constexpr int TL = RyC1dTile<MODE>::TL, PP = RyC1dTile<MODE>::PP, CS = 32;
+    constexpr int NACC = (MODE == RY_C1D_DECONV) ? 2 * TL : TL;
+    __shared__ __attribute__((aligned(16))) float xs[CS * PP];
+
+    const int lane = (int)threadIdx.x;
+    const int co = (int)blockIdx.x * 64 + lane;
+    const int Lr = (MODE == RY_C1D_DECONV) ? p.Lin : p.Lout;         // row axis the tiles walk
+    const int tiles = (Lr + TL - 1) / TL;
+    const int b = (int)blockIdx.y / tiles;
+    const int l0 = ((int)blockIdx.y % tiles) * TL;
+    const int split = (int)blockIdx.z;
+    const int ci_begin = (int)(((long long)p.Ctot * split) / p.splits);
+    const int ci_end = (int)(((long long)p.Ctot * (split + 1)) / p.splits);
+    // first input position of the tile
+    int pos0, npos;
+    if (MODE == RY_C1D_DECONV) { pos0 = l0 - 1; npos = TL + 2; }
+    else if (MODE == RY_C1D_S2) { pos0 = l0 * 2 - 1; npos = 2 * TL + 2; }
+    else if (MODE == RY_C1D_S1) { pos0 = l0 - p.pad; npos = TL + 3; }
+    else { pos0 = l0 * p.stride - p.pad; npos = (TL - 1) * p.stride + 3 * p.dil + 1; }
+
+    float acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = 0.f;
+    const bool co_ok = co < p.N;
+    const int cw = co_ok ? co : 0;
+
+    for (int cc = ci_begin; cc < ci_end; cc += CS) {
+        __syncthreads();
+        // stage xs[cl][pos] = act(scale * sum_splits(raw) + shift) of the producer layer(s), 0 outside [0, Lin)
+        for (int e = lane; e < CS * (PP / 4); e += 64) {
+            const int cl = e % CS, p4 = e / CS;
+            const int ci = cc + cl;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ci < ci_end) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pl = p4 * 4 + u;
+                    const int pos = pos0 + pl;
+                    if (pl < npos && pos >= 0 && pos < p.Lin) {
+                        const size_t pix = (size_t)b * p.Lin + pos;
+                        v[u] = (ci < p.s[0].C) ? ry_src1d_load(p.s[0], pix, ci, p.slope)
+                                               : ry_src1d_load(p.s[1], pix, ci - p.s[0].C, p.slope);
+                    }
+                }
+            }
+            ry_st4(&xs[cl * PP + p4 * 4], v);
+        }
+        __syncthreads();
+        const int cn = (ci_end - cc < CS) ? (ci_end - cc) : CS;
+        for (int cl = 0; cl < cn; ++cl) {
+            const f32x4 w = ry_ld4(p.wd + ((size_t)(cc + cl) * p.N + cw) * 4);
+            const float* x = &xs[cl * PP];
+            if (MODE == RY_C1D_S2) {
+                float xr[PP];
+#pragma unroll
+                for (int q = 0; q < PP / 4; ++q) { const f32x4 t = ry_ld4(x + 4 * q); xr[4*q] = t[0]; xr[4*q+1] = t[1]; xr[4*q+2] = t[2]; xr[4*q+3] = t[3]; }
+#pragma unroll
+                for (int j = 0; j < TL; ++j)
+                    acc[j] = fmaf(w[3], xr[2*j+3], fmaf(w[2], xr[2*j+2], fmaf(w[1], xr[2*j+1], fmaf(w[0], xr[2*j], acc[j]))));
+            } else if (MODE == RY_C1D_S1) {
+                float xr[PP];
+#pragma unroll
+                for (int q = 0; q < PP / 4; ++q) { const f32x4 t = ry_ld4(x + 4 * q); xr[4*q] = t[0]; xr[4*q+1] = t[1]; xr[4*q+2] = t[2]; xr[4*q+3] = t[3]; }
+#pragma unroll
+                for (int j = 0; j < TL; ++j)
+                    acc[j] = fmaf(w[3], xr[j+3], fmaf(w[2], xr[j+2], fmaf(w[1], xr[j+1], fmaf(w[0], xr[j], acc[j]))));
+            } else if (MODE == RY_C1D_DECONV) {
+                float xr[PP];
+#pragma unroll
+                for (int q = 0; q < PP / 4; ++q) { const f32x4 t = ry_ld4(x + 4 * q); xr[4*q] = t[0]; xr[4*q+1] = t[1]; xr[4*q+2] = t[2]; xr[4*q+3] = t[3]; }
+                // out[2q]   = w1*x[q] + w3*x[q-1] ;  out[2q+1] = w0*x[q+1] + w2*x[q]   (xr[j] = x[l0-1+j])
+#pragma unroll
+                for (int j = 0; j < TL; ++j) {
+                    acc[2*j]   = fmaf(w[3], xr[j],   fmaf(w[1], xr[j+1], acc[2*j]));
+                    acc[2*j+1] = fmaf(w[2], xr[j+1], fmaf(w[0], xr[j+2], acc[2*j+1]));
+                }
+            } else {
+                for (int j = 0; j < TL; ++j) {
+                    float a = acc[j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a = fmaf(w[k], x[j * p.stride + k * p.dil], a);
+                    acc[j] = a;
+                }
+            }
+        }
+    }
+    if (!co_ok) return;
+    float* outp = p.out + (size_t)split * (size_t)p.slab_stride;
+    if (MODE == RY_C1D_DECONV) {
+#pragma unroll
+        for (int j = 0; j < 2 * TL; ++j) {
+            const int l = 2 * l0 + j;
+            if (l < p.Lout) outp[((size_t)b * p.Lout + l) * p.N + co] = acc[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TL; ++j) {
+            const int l = l0 + j;
+            if (l < p.Lout) outp[((size_t)b * p.Lout + l) * p.N + co] = acc[j];
+        }
+    }
+}
+
+struct RyMaterializeParams {
+    RySrc1d s;
+    long long npix;             // B*L
+    float* out;                 // [npix][s.C]
+    float slope;
+};
+
+RY_KERNEL(256) void ry_materialize(RyMaterializeParams p) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.npix * p.s.C) return;
+    const int c = (int)(idx % p.s.C);
+    const size_t pix = (size_t)(idx / p.s.C);
+    p.out[idx] = ry_src1d_load(p.s, pix, c, p.slope);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wrapper arithmetic: numpy.pad(mode='minimum') along time, log / drop-last-bin, exp / edge-pad / crop.
+// ---------------------------------------------------------------------------------------------
+struct RyColminParams { const float* in; int rows, cols; float* minv; long long in_bstride; int minv_bstride; };
+
+RY_KERNEL(256) void ry_colmin(RyColminParams p) {     // blockIdx.y = window of the batch
+    __shared__ float red[256];
+    const int tid = (int)threadIdx.x;
+    const int c = (int)blockIdx.x * 64 + (tid & 63);
+    const float* in = p.in + (size_t)blockIdx.y * (size_t)p.in_bstride;
+    float m = INFINITY;
+    if (c < p.cols)
+        for (int r = tid >> 6; r < p.rows; r += 4) m = fminf(m, in[(size_t)r * p.cols + c]);
+    red[tid] = m;
+    __syncthreads();
+    if (tid < 64 && c < p.cols)
+        p.minv[(size_t)blockIdx.y * p.minv_bstride + c] =
+            fminf(fminf(red[tid], red[tid + 64]), fminf(red[tid + 128], red[tid + 192]));
+}
+
+struct RyPadRowsParams {
+    const float* in;            // [batch][rows_in][cols_in]
+    const float* minv;          // [batch][cols_in] column minima (may be null when rows_out <= rows_in)
+    float* out;                 // [batch][rows_out][cols_out]  (cols_out <= cols_in: trailing bins dropped)
+    int rows_in, cols_in, rows_out, cols_out;
+    int take_log;
+    long long in_bstride, out_bstride;
+    int minv_bstride;
+};
+
+RY_KERNEL(256) void ry_pad_rows(RyPadRowsParams p) {  // blockIdx.y = window of the batch
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.rows_out * p.cols_out) return;
+    const int c = (int)(idx % p.cols_out);
+    const int r = (int)(idx / p.cols_out);
+    const float* in = p.in + (size_t)blockIdx.y * (size_t)p.in_bstride;
+    float v = (r < p.rows_in) ? in[(size_t)r * p.cols_in + c] : p.minv[(size_t)blockIdx.y * p.minv_bstride + c];
+    if (p.take_log) v = logf(v);
+    p.out[(size_t)blockIdx.y * (size_t)p.out_bstride + idx] = v;
+}
+
+struct RySrPostParams { const float* y; float* out; int rows, cols_in, cols_out; long long y_bstride, out_bstride; };
+
+RY_KERNEL(256) void ry_sr_post(RySrPostParams p) {   // out[r][f] = exp(y[r][min(f, cols_in-1)]), blockIdx.y = window
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.rows * p.cols_out) return;
+    const int f = (int)(idx % p.cols_out);
+    const int r = (int)(idx / p.cols_out);
+    const int fi = f < p.cols_in ? f : p.cols_in - 1;
+    p.out[(size_t)blockIdx.y * (size_t)p.out_bstride + idx] =
+        expf(p.y[(size_t)blockIdx.y * (size_t)p.y_bstride + (size_t)r * p.cols_in + fi]);
+}

@@ -1,0 +1,177 @@
+"""Host-side handles over the C ABI: one `Context` per (process, GPU), one `Net` per predictor.
+
+Mirrors what the reference's dependencies do around their Chainer models ([MEM]; call sites
+/root/reference/realtime_voice_conversion/converter/yukarin_converter.py:40-55): build the predictor
+from the config's `model` section, load the npz, move it to the GPU, then run `model(x)` per buffer.
+Contexts are created lazily per process id: the reference constructs the converter objects in the
+parent and ships them to a child `Process` (/root/reference/run.py:39-46,69-79), and a HIP context
+must never cross a fork.
+"""
+import ctypes
+import os
+from typing import Dict, List, Optional
+
+import numpy
+
+from . import _lib
+from .netspec import NetDesc, pad_frames, param_count
+
+
+class Context(object):
+    def __init__(self, device: int = 0, lib: Optional[_lib.Ry355Lib] = None):
+        self.lib = lib if lib is not None else _lib.default_lib()
+        self.device = int(device)
+        self.pid = os.getpid()
+        n = self.lib.device_count()
+        if n < 1:
+            raise _lib.Ry355Error('no HIP device is visible: realtime_yukarin_amd needs an MI355X (there is no CPU path)')
+        h = ctypes.c_void_p()
+        self.lib.check(self.lib.dll.ry_init(self.device, ctypes.byref(h)))
+        self.handle = h
+
+    def sync(self):
+        self.lib.check(self.lib.dll.ry_sync(self.handle))
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.dll.ry_stream(self.handle) or 0)
+
+    def timer_start(self):
+        self.lib.check(self.lib.dll.ry_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = ctypes.c_float()
+        self.lib.check(self.lib.dll.ry_timer_stop(self.handle, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if self.handle is not None and self.pid == os.getpid():
+            self.lib.dll.ry_shutdown(self.handle)
+        self.handle = None
+
+    # ---- single operators (Chainer layouts in, channels-last activations) ----
+    def conv1d(self, x, W, b=None, bn=None, stride=1, pad=0, dilate=1, transposed=False, act=None, splits=0):
+        """x (B, L, Cin) -> (B, Lout, Cout).  W (Cout,Cin,k) or transposed (Cin,Cout,k); bn = (gamma,beta,mean,var)."""
+        x = numpy.ascontiguousarray(x, dtype=numpy.float32)
+        W = numpy.ascontiguousarray(W, dtype=numpy.float32)
+        B, L, Cin = x.shape
+        Cout = W.shape[1] if transposed else W.shape[0]
+        k = W.shape[2]
+        Lout = 2 * L if transposed else (L + 2 * pad - dilate * (k - 1) - 1) // stride + 1
+        a = _lib.ACTS[act]
+        y = numpy.empty((B, max(Lout, 0), Cout // 2 if a == _lib.ACT_GLU else Cout), dtype=numpy.float32)
+        bnv = None if bn is None else numpy.ascontiguousarray(numpy.concatenate([numpy.ravel(v) for v in bn]), dtype=numpy.float32)
+        bv = None if b is None else numpy.ascontiguousarray(b, dtype=numpy.float32)
+        self.lib.check(self.lib.dll.ry_conv1d(self.handle, _lib._fptr(x), B, L, Cin, _lib._fptr(W), _lib._fptr(bv), _lib._fptr(bnv),
+                                              Cout, k, stride, pad, dilate, int(bool(transposed)), a, int(splits), _lib._fptr(y)))
+        return y
+
+    def conv2d(self, x, W, b=None, bn=None, stride=1, pad=0, transposed=False, act=None, path='auto', tile=None, splits=0):
+        """x (B, H, W, Cin) -> (B, Ho, Wo, Cout).  W (Cout,Cin,k,k) or transposed (Cin,Cout,k,k)."""
+        x = numpy.ascontiguousarray(x, dtype=numpy.float32)
+        W = numpy.ascontiguousarray(W, dtype=numpy.float32)
+        B, H, Wd, Cin = x.shape
+        Cout = W.shape[1] if transposed else W.shape[0]
+        k = W.shape[2]
+        Ho = 2 * H if transposed else (H + 2 * pad - k) // stride + 1
+        Wo = 2 * Wd if transposed else (Wd + 2 * pad - k) // stride + 1
+        y = numpy.empty((B, max(Ho, 0), max(Wo, 0), Cout), dtype=numpy.float32)
+        bnv = None if bn is None else numpy.ascontiguousarray(numpy.concatenate([numpy.ravel(v) for v in bn]), dtype=numpy.float32)
+        bv = None if b is None else numpy.ascontiguousarray(b, dtype=numpy.float32)
+        pth = {'auto': 0, 'igemm': 1, 'direct': 2}[path]
+        self.lib.check(self.lib.dll.ry_conv2d(self.handle, _lib._fptr(x), B, H, Wd, Cin, _lib._fptr(W), _lib._fptr(bv), _lib._fptr(bnv),
+                                              Cout, k, stride, pad, int(bool(transposed)), _lib.ACTS[act], pth, _lib.TILES[tile],
+                                              int(splits), _lib._fptr(y)))
+        return y
+
+
+_contexts: Dict = {}
+
+
+def get_context(device: int = 0, lib: Optional[_lib.Ry355Lib] = None) -> Context:
+    """Per-(pid, device) context, created on first use in the calling process (fork-safe laziness)."""
+    key = (os.getpid(), int(device), id(lib) if lib is not None else 0)
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = Context(device, lib)
+        _contexts[key] = ctx
+    return ctx
+
+
+class Net(object):
+    """A predictor resident on one GPU.  `blob` = flat float32 weights (netspec K-list order), either a
+    host ndarray or (ptr, n) of a device buffer (e.g. the tensor an RCCL broadcast filled)."""
+
+    def __init__(self, ctx: Context, desc: NetDesc, blob, width: int = 512, bn_eps: float = 2e-5, lrelu_slope: float = 0.2):
+        self.ctx = ctx
+        self.desc = desc
+        self.width = int(width) if desc.ndim == 2 else 1
+        self.cdesc = _lib.RyNetDesc(desc.ndim, desc.in_ch, desc.out_ch, desc.base, desc.extensive_layers, self.width,
+                                    bn_eps, lrelu_slope)
+        lib = ctx.lib
+        want = int(lib.dll.ry_net_param_count(ctypes.byref(self.cdesc)))
+        if want != param_count(desc):
+            raise _lib.Ry355Error('library and netspec disagree on the parameter count: %d vs %d' % (want, param_count(desc)))
+        h = ctypes.c_void_p()
+        if isinstance(blob, tuple):
+            ptr, n = blob
+            lib.check(lib.dll.ry_net_create(ctx.handle, ctypes.byref(self.cdesc), _lib._fptr(int(ptr)), int(n), 1, ctypes.byref(h)))
+        else:
+            blob = numpy.ascontiguousarray(blob, dtype=numpy.float32)
+            lib.check(lib.dll.ry_net_create(ctx.handle, ctypes.byref(self.cdesc), _lib._fptr(blob), blob.size, 0, ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle is not None and self.ctx.handle is not None and self.ctx.pid == os.getpid():
+            self.ctx.lib.dll.ry_net_destroy(self.handle)
+        self.handle = None
+
+    # ---- host-array API ----
+    def forward(self, x: numpy.ndarray) -> numpy.ndarray:
+        """Raw predictor on a padded block.  stage-1: (B, T, in_ch) -> (B, T, out_ch); stage-2: (B, T, width) -> same."""
+        x = numpy.ascontiguousarray(x, dtype=numpy.float32)
+        B, T = x.shape[0], x.shape[1]
+        cin = self.desc.in_ch if self.desc.ndim == 1 else self.width
+        cout = self.desc.out_ch if self.desc.ndim == 1 else self.width
+        if x.shape != (B, T, cin):
+            raise ValueError('expected (B, T, %d), got %s' % (cin, x.shape))
+        y = numpy.empty((B, T, cout), dtype=numpy.float32)
+        self.ctx.lib.check(self.ctx.lib.dll.ry_net_forward(self.handle, _lib._fptr(x), _lib._fptr(y), B, T, 0))
+        return y
+
+    def convert(self, x: numpy.ndarray) -> numpy.ndarray:
+        """The wrapper arithmetic + predictor: stage-1 `AcousticConverter.convert` array part
+        ((B,) N, in_ch) -> ((B,) N, out_ch); stage-2 `SuperResolution.convert` ((B,) N, width+1) -> same."""
+        x = numpy.ascontiguousarray(x, dtype=numpy.float32)
+        squeeze = x.ndim == 2
+        if squeeze:
+            x = x[numpy.newaxis]
+        B, N, C = x.shape
+        if self.desc.ndim == 1:
+            if C != self.desc.in_ch:
+                raise ValueError('stage-1 input needs %d channels, got %d' % (self.desc.in_ch, C))
+            y = numpy.empty((B, N, self.desc.out_ch), dtype=numpy.float32)
+            fn = self.ctx.lib.dll.ry_ac_convert
+        else:
+            if C != self.width + 1:
+                raise ValueError('stage-2 input needs %d bins, got %d' % (self.width + 1, C))
+            y = numpy.empty((B, N, C), dtype=numpy.float32)
+            fn = self.ctx.lib.dll.ry_sr_convert
+        self.ctx.lib.check(fn(self.handle, _lib._fptr(x), _lib._fptr(y), B, N, 0))
+        return y[0] if squeeze else y
+
+    # ---- device-pointer API (inputs already resident in HBM; only enqueues on the context stream) ----
+    def forward_device(self, x_ptr: int, y_ptr: int, batch: int, frames: int):
+        self.ctx.lib.check(self.ctx.lib.dll.ry_net_forward(self.handle, _lib._fptr(int(x_ptr)), _lib._fptr(int(y_ptr)), batch, frames, 1))
+
+    def convert_device(self, x_ptr: int, y_ptr: int, batch: int, n_frames: int):
+        fn = self.ctx.lib.dll.ry_ac_convert if self.desc.ndim == 1 else self.ctx.lib.dll.ry_sr_convert
+        self.ctx.lib.check(fn(self.handle, _lib._fptr(int(x_ptr)), _lib._fptr(int(y_ptr)), batch, n_frames, 1))
+
+    def profile(self, batch: int, frames: int, reps: int = 5) -> List[dict]:
+        stats = (_lib.RyKernelStat * 96)()
+        n = ctypes.c_int()
+        self.ctx.lib.check(self.ctx.lib.dll.ry_net_profile(self.handle, batch, frames, reps, stats, 96, ctypes.byref(n)))
+        return [dict(name=stats[i].name.decode(), layer=stats[i].layer.decode(), ms=float(stats[i].ms),
+                     flops=float(stats[i].flops), bytes=float(stats[i].bytes), grid=tuple(stats[i].grid))
+                for i in range(n.value)]

@@ -1,0 +1,186 @@
+// ry_emu.cpp -- fiber scheduler of the host-side SIMT emulator.  TEST INFRASTRUCTURE ONLY.
+#include "ry_emu.h"
+
+#include <ucontext.h>
+
+#include <atomic>
+#include <cstdio>
+#include <thread>
+#include <vector>
+
+namespace ry_emu {
+
+thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+
+namespace {
+constexpr size_t kStack = 256 * 1024;
+constexpr int kMaxWaves = 16;
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+};
+
+struct State {
+    std::vector<Fiber> fibers;
+    ucontext_t sched;
+    int cur = 0;
+    int nthreads = 0;
+    int bar_arrived = 0, bar_gen = 0;
+    int wave_arrived[kMaxWaves] = {0}, wave_gen[kMaxWaves] = {0};
+    float wa[kMaxWaves][64], wb[kMaxWaves][64];
+    const std::function<void()>* body = nullptr;
+};
+thread_local State* S = nullptr;
+
+void yield_to_sched() { swapcontext(&S->fibers[S->cur].ctx, &S->sched); }
+
+void trampoline() {
+    (*S->body)();
+    S->fibers[S->cur].done = true;
+    // falls through to uc_link (= scheduler)
+}
+
+int wave_size(int w) {
+    int lo = w * 64, hi = lo + 64;
+    if (hi > S->nthreads) hi = S->nthreads;
+    return hi - lo;
+}
+
+void sync_wave() {
+    const int w = S->cur >> 6;
+    const int g = S->wave_gen[w];
+    if (++S->wave_arrived[w] == wave_size(w)) {
+        S->wave_arrived[w] = 0;
+        ++S->wave_gen[w];
+    } else {
+        while (S->wave_gen[w] == g) yield_to_sched();
+    }
+}
+
+void run_block(State& st, dim3 bidx, dim3 grid, dim3 block) {
+    S = &st;
+    const int n = (int)block.x;
+    st.nthreads = n;
+    st.bar_arrived = 0;
+    for (int w = 0; w < kMaxWaves; ++w) st.wave_arrived[w] = 0;
+    if ((int)st.fibers.size() < n) {
+        st.fibers.resize(n);
+    }
+    for (int i = 0; i < n; ++i) {
+        Fiber& f = st.fibers[i];
+        if (!f.stack) f.stack = (char*)malloc(kStack);
+        f.done = false;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = &st.sched;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    g_blockIdx = bidx;
+    g_gridDim = grid;
+    g_blockDim = block;
+    int remaining = n;
+    while (remaining > 0) {
+        for (int i = 0; i < n; ++i) {
+            Fiber& f = st.fibers[i];
+            if (f.done) continue;
+            st.cur = i;
+            g_threadIdx = dim3((unsigned)i, 0, 0);
+            swapcontext(&st.sched, &f.ctx);
+            g_threadIdx = dim3((unsigned)i, 0, 0);
+            if (f.done) --remaining;
+        }
+    }
+}
+}  // namespace
+
+void sync_block() {
+    const int g = S->bar_gen;
+    if (++S->bar_arrived == S->nthreads) {
+        S->bar_arrived = 0;
+        ++S->bar_gen;
+    } else {
+        while (S->bar_gen == g) {
+            yield_to_sched();
+            g_threadIdx = dim3((unsigned)S->cur, 0, 0);
+        }
+    }
+    g_threadIdx = dim3((unsigned)S->cur, 0, 0);
+}
+
+// Emulated v_mfma_f32_32x32x2_f32 (cdna_hip_programming.md section 3):
+//   A operand of lane l = A[i = l & 31][k = l >> 5],  B operand of lane l = B[k = l >> 5][j = l & 31]
+//   D register r of lane l = D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31]
+//   numerics: k-ordered f32 fma chain  D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)).
+f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    const int me = S->cur, w = me >> 6, l = me & 63;
+    S->wa[w][l] = a;
+    S->wb[w][l] = b;
+    sync_wave();
+    f32x16 d = c;
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = d[r];
+        acc = fmaf(S->wa[w][row], S->wb[w][col], acc);
+        acc = fmaf(S->wa[w][row + 32], S->wb[w][col + 32], acc);
+        d[r] = acc;
+    }
+    sync_wave();
+    return d;
+}
+
+float shfl_xor(float v, int mask) {
+    const int me = S->cur, w = me >> 6, l = me & 63;
+    S->wa[w][l] = v;
+    sync_wave();
+    const float r = S->wa[w][(l ^ mask) & 63];
+    sync_wave();
+    return r;
+}
+
+float shfl(float v, int src) {
+    const int me = S->cur, w = me >> 6, l = me & 63;
+    S->wa[w][l] = v;
+    sync_wave();
+    const float r = S->wa[w][src & 63];
+    sync_wave();
+    return r;
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    if (block.y != 1 || block.z != 1 || block.x > 64 * kMaxWaves) {
+        fprintf(stderr, "ry_emu: only 1-D blocks up to %d threads\n", 64 * kMaxWaves);
+        abort();
+    }
+    const long nblocks = (long)grid.x * grid.y * grid.z;
+    if (nblocks <= 0) return;
+    int nos = 8;
+    if (const char* e = getenv("RY_EMU_THREADS")) nos = atoi(e);
+    if (nos < 1) nos = 1;
+    if (nos > nblocks) nos = (int)nblocks;
+    std::atomic<long> next{0};
+    auto worker = [&]() {
+        State st;
+        st.body = &body;
+        for (;;) {
+            const long b = next.fetch_add(1);
+            if (b >= nblocks) break;
+            dim3 bidx((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y)));
+            run_block(st, bidx, grid, block);
+        }
+        for (auto& f : st.fibers) free(f.stack);
+        S = nullptr;
+    };
+    if (nos == 1) {
+        worker();
+    } else {
+        std::vector<std::thread> ts;
+        for (int i = 0; i < nos; ++i) ts.emplace_back(worker);
+        for (auto& t : ts) t.join();
+    }
+}
+
+}  // namespace ry_emu

@@ -1,0 +1,51 @@
+// ry_emu.h -- host-side SIMT emulator for the gfx950 kernel sources.  TEST INFRASTRUCTURE ONLY.
+//
+// Compiles realtime_yukarin_amd/csrc/*.h kernels as plain C++ (-DRY_HOST_EMU): every GPU thread is
+// a cooperative fiber (ucontext), a workgroup is a set of fibers on one OS thread, `__shared__` is a
+// thread_local static shared by those fibers, `__syncthreads()` / wave collectives are fiber
+// rendezvous, and v_mfma_f32_32x32x2_f32 is emulated with the fragment maps documented in
+// /opt/skills/guides/cdna_hip_programming.md section 3.  Used by tests/ (-m "not gpu") to check kernel index
+// arithmetic against the oracle where no GPU exists.  Never linked into libry355.so.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace ry_emu {
+extern thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+void sync_block();
+f32x16 mfma_32x32x2(float a, float b, f32x16 c);
+float shfl_xor(float v, int mask);
+float shfl(float v, int src);
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+}  // namespace ry_emu
+
+#define threadIdx ry_emu::g_threadIdx
+#define blockIdx ry_emu::g_blockIdx
+#define blockDim ry_emu::g_blockDim
+#define gridDim ry_emu::g_gridDim
+#define __shared__ static thread_local
+#define __syncthreads() ry_emu::sync_block()
+
+#define RY_DEV static inline
+#define RY_KERNEL(...)
+
+RY_DEV f32x16 ry_mfma_32x32x2(float a, float b, f32x16 c) { return ry_emu::mfma_32x32x2(a, b, c); }
+RY_DEV float ry_shfl_xor(float v, int mask) { return ry_emu::shfl_xor(v, mask); }
+RY_DEV float ry_shfl(float v, int src) { return ry_emu::shfl(v, src); }
+RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }
+
+typedef void* ry_stream_t;
+#define RY_LAUNCH(kernel, grid, block, stream, ...) \
+    ry_emu::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
