@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- stage-1 + stage-2 forward throughput of the convert hot path on N MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under
+torch.distributed.run (one rank per GPU, RCCL).  One "step" = one pass of the hot path over one batch of
+synthetic windows already resident in HBM: `AcousticConverter.convert` array part (stage-1) followed by
+`SuperResolution.convert` (stage-2) for `--windows` windows of `--frames` real frames per GPU
+(default: 1 window of 300 frames = buffer_time 0.5 s + 2 x convert_extra_time 0.5 s at 5 ms frames, the
+window /root/reference/config.yaml:14 gives BASELINE config #3).  Windows are independent, so N GPUs take
+N times the windows (weak scaling) with one RCCL broadcast of the weight blobs at start-up and no
+collective in the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 measured copy
+F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--frames', type=int, default=300, help='real frames per window (N)')
+    ap.add_argument('--windows', type=int, default=1, help='windows per GPU per step')
+    ap.add_argument('--model', default='SYN-64')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--profile-reps', type=int, default=5)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    from realtime_yukarin_amd import engine, synth
+    from realtime_yukarin_amd.netspec import flops as net_flops, pad_frames, param_count
+    from realtime_yukarin_amd.weights import flatten_params
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d' % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    N, Wn = args.frames, args.windows
+    T = N + pad_frames(N)
+    d1, d2 = synth.model_descs(args.model)
+    # ---- weights: rank 0 builds the blobs, one RCCL broadcast each over xGMI, every rank adopts the device buffer
+    blobs = []
+    for d, seed in ((d1, synth.SEED_STAGE1), (d2, synth.SEED_STAGE2)):
+        n = param_count(d)
+        if rank == 0:
+            from realtime_yukarin_amd.weights import synthetic_params
+            t = torch.from_numpy(flatten_params(d, synthetic_params(d, seed))).to(dev)
+        else:
+            t = torch.empty(n, dtype=torch.float32, device=dev)
+        if dist is not None:
+            dist.broadcast(t, src=0)
+        blobs.append(t)
+    torch.cuda.synchronize()
+    ctx = engine.get_context(local_rank)
+    net1 = engine.Net(ctx, d1, (blobs[0].data_ptr(), blobs[0].numel()))
+    net2 = engine.Net(ctx, d2, (blobs[1].data_ptr(), blobs[1].numel()), width=synth.FFT_BINS - 1)
+    del blobs
+
+    # ---- synthetic windows, resident in HBM before the timed region (different data per rank)
+    x1 = torch.from_numpy(synth.stage1_input(N, Wn, seed=synth.SEED_INPUT + 10 * rank)).to(dev)
+    sp = torch.from_numpy(synth.stage2_input(N, Wn, seed=synth.SEED_INPUT + 10 * rank + 1)).to(dev)
+    y1 = torch.empty(Wn, N, d1.out_ch, dtype=torch.float32, device=dev)
+    y2 = torch.empty_like(sp)
+    torch.cuda.synchronize()
+
+    def step():
+        net1.convert_device(x1.data_ptr(), y1.data_ptr(), Wn, N)
+        net2.convert_device(sp.data_ptr(), y2.data_ptr(), Wn, N)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        step()
+    dev_ms = ctx.timer_stop()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    assert bool(torch.isfinite(y2).all()) and bool(torch.isfinite(y1).all())
+
+    frames_total = world * Wn * N * args.steps
+    value = frames_total / elapsed
+    out = {
+        'metric': 'acoustic frames/s (stage1+stage2 fwd) @16kHz/5ms',
+        'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'x_realtime': round(value * 0.005, 1), 'x_realtime_per_gpu': round(value * 0.005 / world, 1),
+        'device_ms_per_step_rank0': round(dev_ms / args.steps, 4),
+        'config': {'workload': 'BASELINE config #3: stage-1 + stage-2 SR forward, buffer_time 0.5 s + 2x0.5 s convert_extra_time '
+                               '@16 kHz / 5 ms -> %d real frames (%d padded) per window, %d window(s) per GPU per step, %s random-init weights'
+                               % (N, T, Wn, args.model),
+                   'model': args.model, 'frames': N, 'padded_frames': T, 'windows_per_gpu': Wn,
+                   'parallelism': 'chunk-dp%d (independent windows, RCCL weight broadcast at init, no steady-state collective)' % world},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP events around every launch of the stage-2 predictor, live
+        st2 = net2.profile(Wn, T, args.profile_reps)
+        st1 = net1.profile(Wn, T, args.profile_reps)
+        fam = {}
+        for s in st2 + st1:
+            f = fam.setdefault(s['name'], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            f['ms'] += s['ms']; f['flops'] += s['flops']; f['bytes'] += s['bytes']; f['launches'] += 1
+        dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
+        dname, dv = dom
+        ach = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
+        out['roofline'] = {'kernel': dname, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+                           'frac': round(ach / F32_MFMA_PEAK_TF, 4), 'traffic': None,
+                           'launches': dv['launches'], 'avg_launch_ms': round(dv['ms'] / dv['launches'], 4),
+                           'alg_flops_per_launch': dv['flops'] / dv['launches']}
+        c1 = [s for s in st1 if s['name'].startswith('ry_conv1d_ws')]
+        ms1 = sum(s['ms'] for s in c1); by1 = sum(s['bytes'] for s in c1)
+        out['roofline_stage1'] = {'kernel': 'ry_conv1d_ws<*> (16 launches)', 'bound': 'hbm', 'achieved': round(by1 / (ms1 * 1e-3) / 1e9, 1),
+                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  'traffic': None, 'alg_bytes_per_forward': by1, 'kernel_ms_per_forward': round(ms1, 4)}
+        out['kernels'] = {k: {'ms': round(v['ms'], 4), 'launches': v['launches'], 'tflops': round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 2)}
+                          for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])}
+        out['stage_ms'] = {'stage1_kernels': round(sum(s['ms'] for s in st1), 4), 'stage2_kernels': round(sum(s['ms'] for s in st2), 4)}
+        out['alg'] = {'stage1_gflop': net_flops(d1, T) * Wn / 1e9, 'stage2_gflop': net_flops(d2, T, synth.FFT_BINS - 1) * Wn / 1e9}
+
+        # ---- CPU baseline beside it: the oracle's torch/oneDNN restatement on this box's host cores (bounded sample)
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import torch_ref
+            from realtime_yukarin_amd.weights import synthetic_params
+            import torch as _t
+            P1 = synthetic_params(d1, synth.SEED_STAGE1); P2 = synthetic_params(d2, synth.SEED_STAGE2)
+            t1n, t2n = torch_ref.TorchUNet(P1), torch_ref.TorchUNet(P2)
+            xs = synth.stage1_input(N)[0]; sps = synth.stage2_input(N)[0]
+            torch_ref.stage1_convert_core(t1n, xs); torch_ref.stage2_convert(t2n, sps)   # warm-up
+            reps, tb = 0, time.perf_counter()
+            while True:
+                torch_ref.stage1_convert_core(t1n, xs); torch_ref.stage2_convert(t2n, sps)
+                reps += 1
+                if time.perf_counter() - tb > args.cpu_seconds or reps >= 50:
+                    break
+            cpu_s = (time.perf_counter() - tb) / reps
+            out['cpu_baseline'] = {'value': round(N / cpu_s, 1), 'unit': 'frames/s', 'cores': _t.get_num_threads(), 'kind': 'port',
+                                   'sample': '%d x (stage-1 + stage-2 convert of one %d-frame window), CPU restatement (torch/oneDNN fp32), not Chainer; host has %d logical cpus'
+                                             % (reps, N, os.cpu_count())}
+        print(json.dumps(out), flush=True)
+    net1.close(); net2.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

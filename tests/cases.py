@@ -1,0 +1,71 @@
+"""Shared parity cases: the same operator / predictor cases run on the emulator (CPU) and on the MI355X."""
+import numpy
+
+from oracle import ops_numpy as ops
+from oracle import unet
+
+TOL = 1e-4   # BASELINE.json north_star: "within 1e-4 relative fp32"
+
+# B, L, Cin, Cout, k, stride, pad, dilate, transposed, act, splits
+CONV1D_CASES = [
+    (1, 40, 9, 64, 3, 1, 1, 1, False, 'lrelu', 0),        # encoder c0 shape
+    (2, 64, 64, 128, 4, 2, 1, 1, False, 'lrelu', 0),      # encoder down layer, batch 2
+    (1, 8, 128, 70, 4, 2, 1, 1, False, 'relu', 4),        # ragged Cout, split over input channels
+    (1, 5, 96, 64, 4, 2, 1, 1, True, 'relu', 3),          # decoder up layer, odd length
+    (2, 33, 40, 128, 4, 2, 1, 1, True, None, 0),
+    (1, 50, 16, 32, 3, 1, 3, 3, False, 'glu', 0),         # dilated conv + GLU (north_star operator coverage)
+    (1, 37, 8, 16, 1, 1, 0, 1, False, None, 0),           # 'same' 1x1 layer (extensive_layers < 8)
+    (1, 64, 12, 20, 4, 3, 2, 2, False, 'relu', 2),        # generic stride/dilation path
+    (1, 1, 16, 64, 4, 2, 1, 1, True, 'relu', 0),          # deepest decoder layer: length 1 -> 2
+    (1, 2, 16, 64, 4, 2, 1, 1, False, 'lrelu', 2),        # deepest encoder layer: length 2 -> 1
+]
+
+# B, H, W, Cin, Cout, k, stride, pad, transposed, act, path, tile, splits
+CONV2D_CASES = [
+    (1, 8, 12, 1, 16, 3, 1, 1, False, 'lrelu', 'direct', None, 0),     # SR encoder c0 (Cin = 1)
+    (1, 6, 8, 24, 1, 3, 1, 1, False, None, 'direct', None, 0),         # SR decoder c7 (Cout = 1)
+    (2, 6, 8, 8, 12, 4, 2, 1, False, 'lrelu', 'direct', None, 0),
+    (1, 3, 4, 8, 12, 4, 2, 1, True, 'relu', 'direct', None, 0),
+    (1, 12, 16, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '32x128', 0),
+    (1, 12, 16, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '64x128', 2),
+    (2, 16, 16, 64, 128, 4, 2, 1, False, 'lrelu', 'igemm', '128x128', 1),
+    (1, 16, 36, 32, 64, 4, 2, 1, False, 'relu', 'igemm', '256x64', 3),
+    (1, 3, 4, 64, 128, 4, 2, 1, True, 'relu', 'igemm', '32x128', 0),   # M = 12 rows: ragged tile
+    (1, 6, 10, 32, 64, 4, 2, 1, True, 'relu', 'igemm', '256x64', 2),
+    (1, 5, 7, 64, 128, 3, 1, 1, False, None, 'igemm', '64x128', 0),
+    (1, 5, 7, 32, 128, 1, 1, 0, False, 'relu', 'igemm', '32x128', 1),
+    (1, 2, 4, 64, 128, 4, 2, 1, False, 'lrelu', 'igemm', None, 0),     # deepest encoder layer, auto tile/split
+]
+
+
+def run_conv1d(ctx, rng, case, bn_params):
+    B, L, Cin, Cout, k, s, p, d, tr, act, splits = case
+    x = rng.normal(size=(B, L, Cin)).astype('f4')
+    W = rng.normal(0, 0.1, size=(Cin, Cout, k) if tr else (Cout, Cin, k)).astype('f4')
+    b = rng.normal(0, 0.1, Cout).astype('f4')
+    bn = bn_params(rng, Cout)
+    y = ctx.conv1d(x, W, b, bn, stride=s, pad=p, dilate=d, transposed=tr, act=act, splits=splits)
+    xn = x.transpose(0, 2, 1)
+    r = ops.deconv_nd(xn, W, b, stride=s, pad=p) if tr else ops.conv_nd(xn, W, b, stride=s, pad=p, dilate=d)
+    r = ops.apply_act(ops.batch_norm_inference(r, *bn), act).transpose(0, 2, 1)
+    return y, r
+
+
+def run_conv2d(ctx, rng, case, bn_params):
+    B, H, W_, Cin, Cout, k, s, p, tr, act, path, tile, splits = case
+    x = rng.normal(size=(B, H, W_, Cin)).astype('f4')
+    Wt = rng.normal(0, 0.1, size=(Cin, Cout, k, k) if tr else (Cout, Cin, k, k)).astype('f4')
+    b = rng.normal(0, 0.1, Cout).astype('f4')
+    bn = bn_params(rng, Cout)
+    y = ctx.conv2d(x, Wt, b, bn, stride=s, pad=p, transposed=tr, act=act, path=path, tile=tile, splits=splits)
+    xn = x.transpose(0, 3, 1, 2)
+    r = ops.deconv_nd(xn, Wt, b, stride=s, pad=p) if tr else ops.conv_nd(xn, Wt, b, stride=s, pad=p)
+    r = ops.apply_act(ops.batch_norm_inference(r, *bn), act).transpose(0, 2, 3, 1)
+    return y, r
+
+
+def oracle_forward(desc, P, x):
+    """channels-last block -> oracle (NC...) -> channels-last."""
+    if desc.ndim == 1:
+        return unet.unet_forward(x.transpose(0, 2, 1), P, desc.extensive_layers).transpose(0, 2, 1)
+    return unet.unet_forward(x[:, numpy.newaxis], P, desc.extensive_layers)[:, 0]

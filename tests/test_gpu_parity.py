@@ -1,0 +1,124 @@
+"""Parity gate: the HIP path on a real MI355X (through the C ABI) against the CPU oracle.
+
+Tolerance: 1e-4 relative fp32 (BASELINE.json north_star), metric max|y - ref| / max|ref| for activations
+and max|y / ref - 1| for the (positive) stage-2 spectrogram output.  Operator and small-predictor cases are
+shared with the emulator tests (tests/cases.py); full-size cases use the canonical SYN-64 configs at
+BASELINE.json's window sizes, checked against the torch/oneDNN restatement (the numpy one is too slow there)
+and through size-independent properties (batch invariance, window independence, determinism)."""
+import numpy
+import pytest
+
+from conftest import bn_params, rel_max
+import cases
+from oracle import torch_ref, unet
+from realtime_yukarin_amd import engine, synth
+from realtime_yukarin_amd.netspec import NetDesc
+from realtime_yukarin_amd.weights import flatten_params, synthetic_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('case', cases.CONV1D_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv1d_gpu(gpu_ctx, case):
+    y, r = cases.run_conv1d(gpu_ctx, numpy.random.default_rng(11), case, bn_params)
+    assert rel_max(y, r) < cases.TOL
+
+
+@pytest.mark.parametrize('case', cases.CONV2D_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_gpu(gpu_ctx, case):
+    y, r = cases.run_conv2d(gpu_ctx, numpy.random.default_rng(12), case, bn_params)
+    assert rel_max(y, r) < cases.TOL
+
+
+def test_mfma_fragment_map_is_transpose_detecting(gpu_ctx):
+    """Asymmetric 1x1 'conv' = plain GEMM with A = identity rows: catches a swapped C/D row/col map."""
+    Cin, Cout = 32, 128
+    x = numpy.zeros((1, 4, 8, Cin), 'f4')
+    for i in range(32):
+        x[0, i // 8, i % 8, i] = 1.0                      # pixel i selects input channel i
+    W = (numpy.arange(Cout * Cin, dtype='f4').reshape(Cout, Cin, 1, 1) % 251) / 251.0
+    y = gpu_ctx.conv2d(x, W, None, None, stride=1, pad=0, path='igemm', tile='32x128', splits=1)
+    ref = W[:, :, 0, 0].T                                 # y[pixel i][n] = W[n][i]
+    assert numpy.array_equal(y.reshape(32, Cout), ref)
+
+
+SMALL_NETS = [
+    (1, 9, 9, 8, 8, 128, 1, 1), (1, 9, 9, 64, 8, 128, 1, 2), (1, 523, 9, 16, 8, 256, 1, 1), (1, 9, 9, 8, 3, 40, 1, 1),
+    (2, 1, 1, 8, 8, 128, 128, 1), (2, 1, 1, 32, 8, 128, 128, 1),
+]
+
+
+@pytest.mark.parametrize('cfg', SMALL_NETS, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_predictor_gpu(gpu_ctx, cfg):
+    nd, inc, outc, base, e, T, width, B = cfg
+    d = NetDesc(nd, inc, outc, base, e)
+    P = synthetic_params(d, 400 + nd, bias_std=0.05)
+    net = engine.Net(gpu_ctx, d, flatten_params(d, P), width=width)
+    x = numpy.random.default_rng(13).normal(size=(B, T, inc if nd == 1 else width)).astype('f4')
+    y = net.forward(x)
+    assert rel_max(y, cases.oracle_forward(d, P, x)) < cases.TOL
+    assert numpy.array_equal(y, net.forward(x)), 'graph replay must be deterministic'
+    net.close()
+
+
+@pytest.fixture(scope='module')
+def syn64(gpu_ctx):
+    (d1, P1), (d2, P2) = synth.model_params('SYN-64')
+    n1 = engine.Net(gpu_ctx, d1, flatten_params(d1, P1))
+    n2 = engine.Net(gpu_ctx, d2, flatten_params(d2, P2), width=synth.FFT_BINS - 1)
+    yield (n1, torch_ref.TorchUNet(P1)), (n2, torch_ref.TorchUNet(P2))
+    n1.close(); n2.close()
+
+
+@pytest.mark.parametrize('n_frames', [100, 300, 1000, 600, 128, 1])   # BASELINE configs #3/#4, #3+extra, #2, #1, pad edge, 1 frame
+def test_stage1_syn64_convert(syn64, n_frames):
+    (n1, t1), _ = syn64
+    x = synth.stage1_input(n_frames)[0]
+    y = n1.convert(x)
+    assert y.shape == (n_frames, synth.MC_DIMS)
+    assert rel_max(y, torch_ref.stage1_convert_core(t1, x)) < cases.TOL
+
+
+@pytest.mark.parametrize('n_frames', [100, 300])                      # BASELINE configs #3/#4
+def test_stage2_syn64_convert(syn64, n_frames):
+    _, (n2, t2) = syn64
+    sp = synth.stage2_input(n_frames)[0]
+    y = n2.convert(sp)
+    r = torch_ref.stage2_convert(t2, sp)
+    assert y.shape == r.shape == (n_frames, synth.FFT_BINS)
+    assert numpy.isfinite(y).all()
+    assert float(numpy.abs(y / r - 1).max()) < cases.TOL
+    assert numpy.array_equal(y[:, -1], y[:, -2]), "pad(mode='edge') repeats the last predicted bin"
+
+
+def test_windows_are_independent_and_batch_invariant(syn64):
+    """Chunk-parallel property: a window's result does not depend on its batch neighbours."""
+    (n1, _), (n2, _) = syn64
+    x = synth.stage1_input(100, windows=3)
+    sp = synth.stage2_input(100, windows=2)
+    yb = n1.convert(x)
+    for w in range(3):
+        assert rel_max(yb[w], n1.convert(x[w])) < 1e-6
+    sb = n2.convert(sp)
+    for w in range(2):
+        assert float(numpy.abs(sb[w] / n2.convert(sp[w]) - 1).max()) < 1e-5
+
+
+def test_stage2_syn64_forward_400_frames(syn64):
+    """BASELINE config #5 window (N=400 -> 512 padded frames), raw predictor."""
+    _, (n2, t2) = syn64
+    x = numpy.log(synth.stage2_input(512)[:, :, :-1])
+    y = n2.forward(x)
+    r = t2.forward_np(x[:, numpy.newaxis])[:, 0]
+    assert rel_max(y, r) < cases.TOL
+
+
+def test_errors_are_reported_not_fatal(gpu_ctx):
+    d = NetDesc(1, 9, 9, 8, 8)
+    P = synthetic_params(d, 1)
+    net = engine.Net(gpu_ctx, d, flatten_params(d, P))
+    with pytest.raises(Exception) as ei:
+        net.forward(numpy.zeros((1, 100, 9), 'f4'))       # 100 is not a multiple of 128
+    assert 'multiple' in str(ei.value)
+    assert net.forward(numpy.zeros((1, 128, 9), 'f4')).shape == (1, 128, 9)   # still usable afterwards
+    net.close()

@@ -1,0 +1,74 @@
+"""The gfx950 kernel sources, compiled for the host-side SIMT emulator, against the oracle (CPU, no GPU).
+
+This checks index arithmetic, MFMA fragment maps (as documented), split-K, deferred epilogues, the
+wrapper kernels and the executor.  It is NOT the parity gate (tests/test_gpu_parity.py is); it exists so
+kernel logic can be iterated where no MI355X is attached."""
+import numpy
+import pytest
+
+from conftest import bn_params, rel_max
+import cases
+from oracle import unet
+from realtime_yukarin_amd import engine
+from realtime_yukarin_amd.netspec import NetDesc
+from realtime_yukarin_amd.weights import flatten_params, synthetic_params
+
+
+@pytest.mark.parametrize('case', cases.CONV1D_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv1d_emu(emu_ctx, case):
+    y, r = cases.run_conv1d(emu_ctx, numpy.random.default_rng(11), case, bn_params)
+    assert rel_max(y, r) < cases.TOL
+
+
+@pytest.mark.parametrize('case', cases.CONV2D_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_emu(emu_ctx, case):
+    y, r = cases.run_conv2d(emu_ctx, numpy.random.default_rng(12), case, bn_params)
+    assert rel_max(y, r) < cases.TOL
+
+
+NETS = [
+    # ndim, in, out, base, e, T, width, batch
+    (1, 9, 9, 8, 8, 128, 1, 1),
+    (1, 9, 9, 64, 8, 128, 1, 2),
+    (1, 523, 9, 16, 8, 256, 1, 1),      # "mel+f0+ap" stress variant
+    (1, 9, 9, 8, 3, 40, 1, 1),          # extensive_layers 3: 'same' layers
+    (2, 1, 1, 8, 8, 128, 128, 1),       # all-direct path
+    (2, 1, 1, 32, 8, 128, 128, 1),      # implicit-GEMM middle layers
+]
+
+
+@pytest.mark.parametrize('cfg', NETS, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_predictor_emu(emu_ctx, cfg):
+    nd, inc, outc, base, e, T, width, B = cfg
+    d = NetDesc(nd, inc, outc, base, e)
+    P = synthetic_params(d, 400 + nd, bias_std=0.05)
+    net = engine.Net(emu_ctx, d, flatten_params(d, P), width=width)
+    rng = numpy.random.default_rng(13)
+    x = rng.normal(size=(B, T, inc if nd == 1 else width)).astype('f4')
+    assert rel_max(net.forward(x), cases.oracle_forward(d, P, x)) < cases.TOL
+    net.close()
+
+
+@pytest.mark.parametrize('n_frames', [1, 37, 100, 128])
+def test_stage1_convert_emu(emu_ctx, n_frames):
+    d = NetDesc(1, 9, 9, 8, 8)
+    P = synthetic_params(d, 410, bias_std=0.05)
+    net = engine.Net(emu_ctx, d, flatten_params(d, P))
+    x = numpy.random.default_rng(14).normal(size=(n_frames, 9)).astype('f4')
+    y = net.convert(x)
+    assert y.shape == (n_frames, 9)
+    assert rel_max(y, unet.stage1_convert_core(x, P)) < cases.TOL
+    net.close()
+
+
+@pytest.mark.parametrize('n_frames', [5, 100])
+def test_stage2_convert_emu(emu_ctx, n_frames):
+    d = NetDesc(2, 1, 1, 8, 8)
+    P = synthetic_params(d, 411, bias_std=0.05)
+    net = engine.Net(emu_ctx, d, flatten_params(d, P), width=128)
+    sp = (numpy.exp(numpy.random.default_rng(15).normal(-6, 1.5, size=(2, n_frames, 129))) + 1e-16).astype('f4')
+    y = net.convert(sp)                                   # two windows in one call
+    for w in range(2):
+        r = unet.stage2_convert(sp[w], P)
+        assert float(numpy.abs(y[w] / r - 1).max()) < cases.TOL
+    net.close()
