@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--profile-reps', type=int, default=5)
+    ap.add_argument('--layers-out', default=None, help='write the per-launch profile (layer, kernel, ms, TFLOP/s, GB/s) to this file')
     return ap.parse_args()
 
 
@@ -140,6 +141,13 @@ def main():
         # ---- roofline of the dominant kernel: HIP events around every launch of the stage-2 predictor, live
         st2 = net2.profile(Wn, T, args.profile_reps)
         st1 = net1.profile(Wn, T, args.profile_reps)
+        if args.layers_out:
+            with open(args.layers_out, 'w') as f:
+                for tag, st in (('stage1', st1), ('stage2', st2)):
+                    for s in st:
+                        f.write('%-7s %-12s %-26s grid=%-16s %9.2f us %8.2f TFLOP/s %9.1f GB/s\n' % (
+                            tag, s['layer'], s['name'], 'x'.join(map(str, s['grid'])), s['ms'] * 1e3,
+                            s['flops'] / max(s['ms'], 1e-9) / 1e9, s['bytes'] / max(s['ms'], 1e-9) / 1e6))
         fam = {}
         for s in st2 + st1:
             f = fam.setdefault(s['name'], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))

@@ -1,0 +1,48 @@
+"""`become_yukarin.SuperResolution` on the MI355X ([MEM] body; signature and call sites: /root/reference/check.py:60-63,
+realtime_voice_conversion/converter/yukarin_converter.py:50-55, yukarin_wrapper/voice_changer.py:41).
+
+`convert(sp)` is the stage-2 hot path, run end to end by `ry_sr_convert`: pad 'minimum' along time, log, drop the
+last bin, SRPredictor, edge-pad one bin, exp, crop -- one graph replay on the GPU.  Picklable / fork-safe like
+`yukarin.AcousticConverter` (lazy per-process context)."""
+import os
+from pathlib import Path
+
+import numpy
+
+from realtime_yukarin_amd import engine
+from realtime_yukarin_amd.netspec import NetDesc
+from realtime_yukarin_amd.weights import flatten_params, load_npz
+
+from .config.sr_config import SRConfig
+
+
+class SuperResolution(object):
+    def __init__(self, config: SRConfig, model_path: Path, gpu: int = None) -> None:
+        self.config = config
+        self.model_path = model_path
+        self.gpu = gpu
+        m = config.model
+        self.desc = NetDesc(2, 1, 1, m.generator_base_channels, m.generator_extensive_layers)
+        self._params = load_npz(self.desc, model_path)
+        self._net = None
+        self._net_pid = None
+        self._bins = None
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d['_net'] = None
+        d['_net_pid'] = None
+        return d
+
+    def _get_net(self, bins: int) -> engine.Net:
+        if self._net is None or self._net_pid != os.getpid() or self._bins != bins:
+            device = int(os.environ.get('RY_DEVICE', '0')) if self.gpu is None else int(self.gpu)
+            ctx = engine.get_context(device)
+            self._net = engine.Net(ctx, self.desc, flatten_params(self.desc, self._params), width=bins - 1)
+            self._net_pid, self._bins = os.getpid(), bins
+        return self._net
+
+    def convert(self, input: numpy.ndarray) -> numpy.ndarray:
+        """(N, fft_size/2 + 1) float32 spectrogram -> same shape."""
+        sp = numpy.ascontiguousarray(input, dtype=numpy.float32)
+        return self._get_net(sp.shape[1]).convert(sp)

@@ -75,10 +75,12 @@ class AcousticFeature(object):
 
     @staticmethod
     def concatenate(fs: List['AcousticFeature'], keys: Iterable[str]):
-        return AcousticFeature(**{k: numpy.concatenate([getattr(f, k) for f in fs]) for k in keys})
+        # members left at their NaN default (feature not extracted) stay NaN, as the reference's tests rely on
+        return AcousticFeature(**{k: (numpy.concatenate([getattr(f, k) for f in fs]) if AcousticFeature._is_array(getattr(fs[0], k)) else _NAN)
+                                  for k in keys})
 
     def pick(self, first: int, last: int, keys: Iterable[str]):
-        return AcousticFeature(**{k: getattr(self, k)[first:last] for k in keys})
+        return AcousticFeature(**{k: (getattr(self, k)[first:last] if self._is_array(getattr(self, k)) else _NAN) for k in keys})
 
     def indexing(self, index: numpy.ndarray):
         return AcousticFeature(**{k: (getattr(self, k)[index] if self._is_array(getattr(self, k)) else getattr(self, k))

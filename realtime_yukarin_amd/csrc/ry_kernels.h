@@ -269,6 +269,117 @@ RY_KERNEL(256) void ry_conv_direct(RyDirectParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage-2 end layers.  encoder c0: 1 -> N channels, 3x3 (HBM-write bound: one 16-byte store per lane).
+// decoder c7: (C1 + C2) -> 1 channel, 3x3 over the un-materialised concat of two sources, with the
+// SuperResolution.convert post-processing (exp, edge-pad of the dropped bin, crop) fused in.
+// ---------------------------------------------------------------------------------------------
+struct RySrFirstParams {
+    const float* x;             // [B][H][W]
+    const float* w;             // [9][N]
+    const float* scale;
+    const float* shift;
+    float* out;                 // [B][H][W][N]
+    int B, H, W, N;
+    int act;
+    float slope;
+};
+
+template <int PX>
+RY_KERNEL(256) void ry_sr_first(RySrFirstParams p) {
+    const int quads = p.N >> 2;
+    const int gpr = (p.W + PX - 1) / PX;                       // pixel groups per row
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.B * p.H * gpr * quads;
+    if (idx >= total) return;
+    const int cq = (int)(idx % quads);
+    long long pg = idx / quads;
+    const int gx = (int)(pg % gpr); pg /= gpr;
+    const int y = (int)(pg % p.H);
+    const int b = (int)(pg / p.H);
+    const int x0 = gx * PX;
+    f32x4 wr[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t] = ry_ld4(p.w + (size_t)t * p.N + cq * 4);
+    const f32x4 sc = ry_ld4(p.scale + cq * 4), sh = ry_ld4(p.shift + cq * 4);
+    float xv[3][PX + 2];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = y + dy - 1;
+#pragma unroll
+        for (int j = 0; j < PX + 2; ++j) {
+            const int ix = x0 + j - 1;
+            xv[dy][j] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? p.x[((size_t)b * p.H + iy) * p.W + ix] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        if (x0 + j >= p.W) break;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float xs_ = xv[t / 3][j + t % 3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = fmaf(xs_, wr[t][u], acc[u]);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(acc[u], sc[u], sh[u]), p.act, p.slope);
+        ry_st4(p.out + (((size_t)b * p.H + y) * p.W + x0 + j) * p.N + cq * 4, o);
+    }
+}
+
+struct RySrLastParams {
+    const float* src1;
+    const float* src2;
+    int C1, C2;
+    const float* w;             // [9][C1+C2]
+    const float* scale;         // [1]
+    const float* shift;         // [1]
+    float* out;                 // [B][rows_valid][out_cols]
+    int B, H, W;
+    int rows_valid;             // rows >= rows_valid are padding and are not computed
+    int out_cols;               // W, or W + 1 with the last bin repeated (pad mode 'edge')
+    int do_exp;
+};
+
+RY_KERNEL(256) void ry_sr_last(RySrLastParams p) {     // 32 lanes per output pixel, 16 bytes of channels per lane per tap
+    const int l = (int)threadIdx.x & 31;
+    const long long pix = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const long long total = (long long)p.B * p.rows_valid * p.W;
+    const bool live = pix < total;
+    const long long pp = live ? pix : 0;
+    const int x = (int)(pp % p.W);
+    const int y = (int)((pp / p.W) % p.rows_valid);
+    const int b = (int)(pp / ((long long)p.W * p.rows_valid));
+    const int Ctot = p.C1 + p.C2;
+    float acc = 0.f;
+    if (live) {
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+            if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
+            const size_t ipx = ((size_t)b * p.H + iy) * p.W + ix;
+            for (int c = l * 4; c < Ctot; c += 128) {
+                const f32x4 v = (c < p.C1) ? ry_ld4(p.src1 + ipx * p.C1 + c) : ry_ld4(p.src2 + ipx * p.C2 + (c - p.C1));
+                const f32x4 wv = ry_ld4(p.w + (size_t)t * Ctot + c);
+                acc = fmaf(v[3], wv[3], fmaf(v[2], wv[2], fmaf(v[1], wv[1], fmaf(v[0], wv[0], acc))));
+            }
+        }
+    }
+    acc += ry_shfl_xor(acc, 16);
+    acc += ry_shfl_xor(acc, 8);
+    acc += ry_shfl_xor(acc, 4);
+    acc += ry_shfl_xor(acc, 2);
+    acc += ry_shfl_xor(acc, 1);
+    if (live && l == 0) {
+        float v = fmaf(acc, p.scale[0], p.shift[0]);
+        if (p.do_exp) v = expf(v);
+        float* o = p.out + ((size_t)b * p.rows_valid + y) * p.out_cols;
+        o[x] = v;
+        if (x == p.W - 1 && p.out_cols > p.W) o[p.W] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage-1: weight-streaming 1-D conv / deconv with deferred producer epilogue.
 // ---------------------------------------------------------------------------------------------
 struct RySrc1d {
@@ -297,6 +408,40 @@ RY_DEV float ry_src1d_load(const RySrc1d& s, size_t pix, int c, float slope) {
     return ry_act(v, s.act, slope);
 }
 
+// Four consecutive positions of one channel at once: the split-K partial sums of the producer are
+// four independent load streams (same split order as ry_src1d_load, so results are identical).
+RY_DEV f32x4 ry_src1d_load4(const RySrc1d& s, long long pix0, int c, int valid_mask, float slope) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (valid_mask == 0) return v;
+    if (s.act == RY_ACT_GLU) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (valid_mask & (1 << u)) v[u] = ry_src1d_load(s, (size_t)(pix0 + u), c, slope);
+        return v;
+    }
+    // masked-off positions (zero padding, tile tail) alias a valid stream and are zeroed afterwards
+    int first = 0;
+    while (!(valid_mask & (1 << first))) ++first;
+    const float* q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int uu = (valid_mask & (1 << u)) ? u : first;
+        q[u] = s.raw + (size_t)(pix0 + uu) * (size_t)s.Craw + c;
+    }
+    float a0 = q[0][0], a1 = q[1][0], a2 = q[2][0], a3 = q[3][0];
+    for (int k = 1; k < s.splits; ++k) {
+        const size_t o = (size_t)k * (size_t)s.slab_stride;
+        a0 += q[0][o]; a1 += q[1][o]; a2 += q[2][o]; a3 += q[3][o];
+    }
+    float sc = 1.f, sh = 0.f;
+    if (s.scale) { sc = s.scale[c]; sh = s.shift[c]; }
+    v[0] = (valid_mask & 1) ? ry_act(fmaf(a0, sc, sh), s.act, slope) : 0.f;
+    v[1] = (valid_mask & 2) ? ry_act(fmaf(a1, sc, sh), s.act, slope) : 0.f;
+    v[2] = (valid_mask & 4) ? ry_act(fmaf(a2, sc, sh), s.act, slope) : 0.f;
+    v[3] = (valid_mask & 8) ? ry_act(fmaf(a3, sc, sh), s.act, slope) : 0.f;
+    return v;
+}
+
 enum { RY_C1D_S2 = 0, RY_C1D_S1 = 1, RY_C1D_DECONV = 2, RY_C1D_GEN = 3 };
 
 struct RyConv1dParams {
@@ -319,14 +464,17 @@ template <> struct RyC1dTile<RY_C1D_S1> { static constexpr int TL = 16, PP = 20;
 template <> struct RyC1dTile<RY_C1D_DECONV> { static constexpr int TL = 8, PP = 12; };
 template <> struct RyC1dTile<RY_C1D_GEN> { static constexpr int TL = 16, PP = 132; };
 
+// Workgroup = up to 4 waves; wave w owns output channels [(blockIdx.x*4 + w)*64, +64) and all waves share
+// the LDS-staged input tile (same positions, same input-channel split).
 template <int MODE>
-RY_KERNEL(64) void ry_conv1d_ws(RyConv1dParams p) {
+RY_KERNEL(256) void ry_conv1d_ws(RyConv1dParams p) {
     constexpr int TL = RyC1dTile<MODE>::TL, PP = RyC1dTile<MODE>::PP, CS = 32;
     constexpr int NACC = (MODE == RY_C1D_DECONV) ? 2 * TL : TL;
     __shared__ __attribute__((aligned(16))) float xs[CS * PP];
 
-    const int lane = (int)threadIdx.x;
-    const int co = (int)blockIdx.x * 64 + lane;
+    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+    const int lane = tid & 63;
+    const int co = ((int)blockIdx.x * 4 + (tid >> 6)) * 64 + lane;
     const int Lr = (MODE == RY_C1D_DECONV) ? p.Lin : p.Lout;         // row axis the tiles walk
     const int tiles = (Lr + TL - 1) / TL;
     const int b = (int)blockIdx.y / tiles;
@@ -350,21 +498,22 @@ RY_KERNEL(64) void ry_conv1d_ws(RyConv1dParams p) {
     for (int cc = ci_begin; cc < ci_end; cc += CS) {
         __syncthreads();
         // stage xs[cl][pos] = act(scale * sum_splits(raw) + shift) of the producer layer(s), 0 outside [0, Lin)
-        for (int e = lane; e < CS * (PP / 4); e += 64) {
+        for (int e = tid; e < CS * (PP / 4); e += nthr) {
             const int cl = e % CS, p4 = e / CS;
             const int ci = cc + cl;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ci < ci_end) {
+                int mask = 0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int pl = p4 * 4 + u;
                     const int pos = pos0 + pl;
-                    if (pl < npos && pos >= 0 && pos < p.Lin) {
-                        const size_t pix = (size_t)b * p.Lin + pos;
-                        v[u] = (ci < p.s[0].C) ? ry_src1d_load(p.s[0], pix, ci, p.slope)
-                                               : ry_src1d_load(p.s[1], pix, ci - p.s[0].C, p.slope);
-                    }
+                    if (pl < npos && pos >= 0 && pos < p.Lin) mask |= 1 << u;
                 }
+                // pix0 may be "negative" for masked-off leading positions; only masked-in streams are dereferenced
+                const long long pix0 = (long long)b * p.Lin + pos0 + p4 * 4;
+                v = (ci < p.s[0].C) ? ry_src1d_load4(p.s[0], pix0, ci, mask, p.slope)
+                                    : ry_src1d_load4(p.s[1], pix0, ci - p.s[0].C, mask, p.slope);
             }
             ry_st4(&xs[cl * PP + p4 * 4], v);
         }

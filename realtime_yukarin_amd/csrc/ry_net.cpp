@@ -303,7 +303,7 @@ static bool igemm_eligible(const Layer& l) {
 // ------------------------------------------------------------------------------------------------
 // per-layer launch plans
 // ------------------------------------------------------------------------------------------------
-enum { PATH_IGEMM = 1, PATH_DIRECT = 2 };
+enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4 };
 enum { TILE_128x128 = 1, TILE_256x64 = 2, TILE_64x128 = 3, TILE_32x128 = 4 };
 
 struct LayerPlan {
@@ -317,6 +317,7 @@ struct LayerPlan {
     int path = 0, tile = 0;
     float* out = nullptr;                     // NHWC activation
     float* slabs = nullptr;
+    int last_rows = 0, last_cols = 0, last_exp = 0;   // PATH_LAST: fused exp / edge-pad / crop
     double flops = 0, bytes = 0;
 };
 
@@ -332,6 +333,8 @@ struct Plan {
     float* x_in = nullptr;                    // padded predictor input
     float* y_full = nullptr;                  // stage-1 dense predictor output [B][T][out_ch]
     size_t user_in_floats = 0, user_out_floats = 0;
+    const float* cur_in = nullptr;            // where the forward reads the caller's block (staging, or the caller's device buffer)
+    float* cur_out = nullptr;                 // where it writes the result
 #ifndef RY_HOST_EMU
     hipGraphExec_t gexec = nullptr;
     bool graph_tried = false;
@@ -455,12 +458,19 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
     if (*tile == 0) *tile = t;
     int bm, bn; tile_dims(*tile, &bm, &bn);
     if (*splits == 0) {
+        // MFMA-bound: every CU should get the same number of workgroups, so pick the split count whose grid is
+        // closest to a whole number of waves over the 256 CUs (>= 2 workgroups per CU, >= 4 K-chunks per split)
         const long blocks = (long)((M + bm - 1) / bm) * (l.cout / bn) * nphases;
-        int s = (int)((512 + blocks - 1) / blocks);
-        if (s > nk / 4) s = nk / 4;
-        if (s > 32) s = 32;
-        if (s < 1) s = 1;
-        *splits = s;
+        int best = 1; double best_eff = -1.0;
+        for (int s = 1; s <= 32 && s <= (nk >= 4 ? nk / 4 : 1); ++s) {
+            const long g = blocks * s;
+            const long rounds = (g + 255) / 256;
+            double eff = (double)g / (double)(rounds * 256);
+            if (rounds < 2) eff *= 0.5 * rounds + 0.25;          // a single thin wave cannot hide its own barriers
+            eff -= 0.004 * (s - 1);                               // each extra split adds slab traffic + a reduce pass
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+        }
+        *splits = best;
     }
     if (*splits > nk) *splits = nk;
 }
@@ -495,6 +505,25 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             RY_LAUNCH(ry_splitk_reduce, rg, 256, Lc.stream, r);
             RY_TRY(Lc.end());
         }
+    } else if (lp.path == PATH_FIRST) {
+        RySrFirstParams p;
+        p.x = s1; p.w = l.wdir; p.scale = l.scale; p.shift = l.shift; p.out = lp.out;
+        p.B = B; p.H = lp.Hi; p.W = lp.Wi; p.N = l.cout; p.act = l.act; p.slope = slope;
+        const long long total = (long long)B * lp.Hi * ((lp.Wi + 3) / 4) * (l.cout / 4);
+        dim3 grid((unsigned)((total + 255) / 256));
+        RY_TRY(Lc.begin("ry_sr_first", l.name, lp.flops, lp.bytes, grid));
+        RY_LAUNCH((ry_sr_first<4>), grid, 256, Lc.stream, p);
+        RY_TRY(Lc.end());
+    } else if (lp.path == PATH_LAST) {
+        RySrLastParams p;
+        p.src1 = s1; p.src2 = s2; p.C1 = C1; p.C2 = C2; p.w = l.wdir; p.scale = l.scale; p.shift = l.shift;
+        p.out = lp.out; p.B = B; p.H = lp.Hi; p.W = lp.Wi;
+        p.rows_valid = lp.last_rows; p.out_cols = lp.last_cols; p.do_exp = lp.last_exp;
+        const long long total = (long long)B * p.rows_valid * lp.Wi;
+        dim3 grid((unsigned)((total + 7) / 8));
+        RY_TRY(Lc.begin("ry_sr_last", l.name, lp.flops, lp.bytes, grid));
+        RY_LAUNCH(ry_sr_last, grid, 256, Lc.stream, p);
+        RY_TRY(Lc.end());
     } else {
         RyDirectParams p;
         p.g = g; p.wd = l.wdir; p.scale = l.scale; p.shift = l.shift; p.out = lp.out; p.act = l.act; p.slope = slope;
@@ -529,26 +558,31 @@ static int launch_conv1d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     const int TL = c1d_tile_len(mode);
     const int rows = mode == RY_C1D_DECONV ? lp.Wi : lp.Wo;
     const int tiles = (rows + TL - 1) / TL;
-    dim3 grid((unsigned)((l.cout + 63) / 64), (unsigned)(B * tiles), (unsigned)lp.splits);
+    const int cogroups = (l.cout + 63) / 64;
+    const int wpb = cogroups < 4 ? cogroups : 4;                       // waves per workgroup
+    dim3 grid((unsigned)((cogroups + 3) / 4), (unsigned)(B * tiles), (unsigned)lp.splits);
     if (grid.y > 65535u) return fail(RY_EINVAL, "%s: batch*tiles = %u exceeds the grid limit", l.name, grid.y);
     const char* nm = mode == RY_C1D_DECONV ? "ry_conv1d_ws<deconv>" : mode == RY_C1D_S2 ? "ry_conv1d_ws<s2>" : mode == RY_C1D_S1 ? "ry_conv1d_ws<s1>" : "ry_conv1d_ws<gen>";
     RY_TRY(Lc.begin(nm, l.name, lp.flops, lp.bytes, grid));
     switch (mode) {
-        case RY_C1D_DECONV: RY_LAUNCH((ry_conv1d_ws<RY_C1D_DECONV>), grid, 64, Lc.stream, p); break;
-        case RY_C1D_S2: RY_LAUNCH((ry_conv1d_ws<RY_C1D_S2>), grid, 64, Lc.stream, p); break;
-        case RY_C1D_S1: RY_LAUNCH((ry_conv1d_ws<RY_C1D_S1>), grid, 64, Lc.stream, p); break;
-        default: RY_LAUNCH((ry_conv1d_ws<RY_C1D_GEN>), grid, 64, Lc.stream, p); break;
+        case RY_C1D_DECONV: RY_LAUNCH((ry_conv1d_ws<RY_C1D_DECONV>), grid, wpb * 64, Lc.stream, p); break;
+        case RY_C1D_S2: RY_LAUNCH((ry_conv1d_ws<RY_C1D_S2>), grid, wpb * 64, Lc.stream, p); break;
+        case RY_C1D_S1: RY_LAUNCH((ry_conv1d_ws<RY_C1D_S1>), grid, wpb * 64, Lc.stream, p); break;
+        default: RY_LAUNCH((ry_conv1d_ws<RY_C1D_GEN>), grid, wpb * 64, Lc.stream, p); break;
     }
     return Lc.end();
 }
 
 static int choose_splits_1d(const Layer& l, int B, int rows, int mode) {
+    // weight streaming wants many workgroups, but every split is re-summed by each consumer tile: aim for
+    // ~128 workgroups, at most 16 splits, at least 16 input channels per split
     const int TL = c1d_tile_len(mode);
-    const long waves = (long)((l.cout + 63) / 64) * ((rows + TL - 1) / TL) * B;
-    int s = (int)((1024 + waves - 1) / waves);
-    const int maxs = l.cin() / 8 > 0 ? l.cin() / 8 : 1;
+    const int cogroups = (l.cout + 63) / 64;
+    const long wgs = (long)((cogroups + 3) / 4) * ((rows + TL - 1) / TL) * B;
+    int s = (int)((128 + wgs - 1) / wgs);
+    const int maxs = l.cin() / 16 > 0 ? l.cin() / 16 : 1;
     if (s > maxs) s = maxs;
-    if (s > 64) s = 64;
+    if (s > 16) s = 16;
     if (s < 1) s = 1;
     return s;
 }
@@ -606,6 +640,15 @@ static int build_plan(ry_net* net, Plan& P) {
                 if (lp.splits > 1) RY_TRY(P.arena.alloc(&lp.slabs, out_elems * lp.splits));
             } else {
                 lp.path = PATH_DIRECT; lp.splits = 1;
+                if (!l.deconv && l.k == 3 && l.stride == 1 && l.pad == 1) {
+                    if (l.src_a < 0 && l.cin() == 1 && l.cout % 4 == 0) lp.path = PATH_FIRST;
+                    if (i == 15 && l.cout == 1 && l.cin() % 128 == 0 && l.cin_a % 4 == 0) {
+                        lp.path = PATH_LAST;      // exp / edge-pad / crop of SuperResolution.convert fused into the last layer
+                        lp.last_rows = P.mode == 1 ? P.n_frames : lp.Ho;
+                        lp.last_cols = P.mode == 1 ? lp.Wo + 1 : lp.Wo;
+                        lp.last_exp = P.mode == 1;
+                    }
+                }
             }
         }
     }
@@ -621,10 +664,9 @@ static int build_plan(ry_net* net, Plan& P) {
         RY_TRY(P.arena.alloc(&P.minv, (size_t)B * cin_user));
         RY_TRY(P.arena.alloc(&P.x_in, (size_t)B * P.T * (nd == 1 ? d.in_ch : d.width)));
     } else {
-        P.x_in = P.user_in;
+        P.x_in = nullptr;                      // raw forward reads the caller's block directly (cur_in)
     }
     if (nd == 1) RY_TRY(P.arena.alloc(&P.y_full, (size_t)B * P.T * d.out_ch));
-    if (nd == 2 && P.mode == 0) P.lp[15].out = P.user_out;      // raw forward: last layer writes the caller's block
     return RY_OK;
 }
 
@@ -633,7 +675,7 @@ static RySrc1d src1d_of(const ry_net* net, const Plan& P, int idx) {
     memset(&s, 0, sizeof s);
     if (idx == -2) { s.C = 0; s.Craw = 1; s.splits = 1; return s; }
     if (idx == -1) {
-        s.raw = P.x_in; s.C = net->desc.in_ch; s.Craw = s.C; s.splits = 1; s.act = RY_ACT_NONE;
+        s.raw = P.mode == 1 ? P.x_in : P.cur_in; s.C = net->desc.in_ch; s.Craw = s.C; s.splits = 1; s.act = RY_ACT_NONE;
         return s;
     }
     const Layer& l = net->layers[idx];
@@ -652,14 +694,14 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
         const int cols_in = nd == 1 ? d.in_ch : d.width + 1;
         const int cols_out = nd == 1 ? d.in_ch : d.width;
         RyColminParams c;
-        c.in = P.user_in; c.rows = P.n_frames; c.cols = cols_in; c.minv = P.minv;
+        c.in = P.cur_in; c.rows = P.n_frames; c.cols = cols_in; c.minv = P.minv;
         c.in_bstride = (long long)P.n_frames * cols_in; c.minv_bstride = cols_in;
         dim3 cg((unsigned)((cols_in + 63) / 64), (unsigned)B);
         RY_TRY(Lc.begin("ry_colmin", "pad", 0, 4.0 * B * P.n_frames * cols_in, cg));
         RY_LAUNCH(ry_colmin, cg, 256, Lc.stream, c);
         RY_TRY(Lc.end());
         RyPadRowsParams q;
-        q.in = P.user_in; q.minv = P.minv; q.out = P.x_in;
+        q.in = P.cur_in; q.minv = P.minv; q.out = P.x_in;
         q.rows_in = P.n_frames; q.cols_in = cols_in; q.rows_out = P.T; q.cols_out = cols_out; q.take_log = nd == 2;
         q.in_bstride = c.in_bstride; q.out_bstride = (long long)P.T * cols_out; q.minv_bstride = cols_in;
         dim3 pg((unsigned)(((long long)P.T * cols_out + 255) / 256), (unsigned)B);
@@ -673,22 +715,24 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
         if (nd == 1) {
             RY_TRY(launch_conv1d(Lc, l, lp, B, src1d_of(net, P, l.src_a), src1d_of(net, P, l.src_b), slope));
         } else {
-            const float* s1 = l.src_a < 0 ? P.x_in : P.lp[l.src_a].out;
+            const float* s1 = l.src_a < 0 ? (P.mode == 1 ? P.x_in : P.cur_in) : P.lp[l.src_a].out;
             const float* s2 = l.src_b >= 0 ? P.lp[l.src_b].out : nullptr;
-            RY_TRY(launch_conv2d(Lc, l, lp, B, s1, l.cin_a, s2, l.cin_b, slope));
+            LayerPlan lq = lp;
+            if (i == 15 && (P.mode == 0 || lp.path == PATH_LAST)) lq.out = P.cur_out;   // last layer writes the caller's block
+            RY_TRY(launch_conv2d(Lc, l, lq, B, s1, l.cin_a, s2, l.cin_b, slope));
         }
     }
     if (nd == 1) {
         RyMaterializeParams m;
         m.s = src1d_of(net, P, 15); m.npix = (long long)B * P.T; m.slope = slope;
-        m.out = P.mode == 1 ? P.y_full : P.user_out;
+        m.out = P.mode == 1 ? P.y_full : P.cur_out;
         dim3 mg((unsigned)((m.npix * d.out_ch + 255) / 256));
         RY_TRY(Lc.begin("ry_materialize", "decoder/c7", 0, 4.0 * m.npix * d.out_ch * 2, mg));
         RY_LAUNCH(ry_materialize, mg, 256, Lc.stream, m);
         RY_TRY(Lc.end());
         if (P.mode == 1) {   // crop: first n_frames rows of every window
             RyPadRowsParams q;
-            q.in = P.y_full; q.minv = nullptr; q.out = P.user_out;
+            q.in = P.y_full; q.minv = nullptr; q.out = P.cur_out;
             q.rows_in = P.T; q.cols_in = d.out_ch; q.rows_out = P.n_frames; q.cols_out = d.out_ch; q.take_log = 0;
             q.in_bstride = (long long)P.T * d.out_ch; q.out_bstride = (long long)P.n_frames * d.out_ch; q.minv_bstride = 0;
             dim3 pg((unsigned)(((long long)P.n_frames * d.out_ch + 255) / 256), (unsigned)B);
@@ -696,9 +740,9 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
             RY_LAUNCH(ry_pad_rows, pg, 256, Lc.stream, q);
             RY_TRY(Lc.end());
         }
-    } else if (P.mode == 1) {
+    } else if (P.mode == 1 && P.lp[15].path != PATH_LAST) {
         RySrPostParams q;
-        q.y = P.lp[15].out; q.out = P.user_out; q.rows = P.n_frames; q.cols_in = d.width; q.cols_out = d.width + 1;
+        q.y = P.lp[15].out; q.out = P.cur_out; q.rows = P.n_frames; q.cols_in = d.width; q.cols_out = d.width + 1;
         q.y_bstride = (long long)P.T * d.width; q.out_bstride = (long long)P.n_frames * (d.width + 1);
         dim3 pg((unsigned)(((long long)P.n_frames * (d.width + 1) + 255) / 256), (unsigned)B);
         RY_TRY(Lc.begin("ry_sr_post", "post", 0, 8.0 * B * P.n_frames * (d.width + 1), pg));
@@ -727,8 +771,18 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
     ry_ctx* ctx = net->ctx;
     RT_TRY(rt::set_device(ctx->device));
     const size_t in_bytes = P.user_in_floats * sizeof(float), out_bytes = P.user_out_floats * sizeof(float);
-    if (on_device) RT_TRY(rt::d2d(P.user_in, x, in_bytes, ctx->stream));
-    else RT_TRY(rt::h2d(P.user_in, x, in_bytes, ctx->stream));
+    // device callers: kernels read / write the caller's buffers directly (no staging copies); the graph is
+    // re-captured only when those addresses change.  host callers: pinned-size staging buffers of the plan.
+    const float* want_in = on_device ? x : P.user_in;
+    float* want_out = on_device ? y : P.user_out;
+    if (want_in != P.cur_in || want_out != P.cur_out) {
+        P.cur_in = want_in; P.cur_out = want_out;
+#ifndef RY_HOST_EMU
+        if (P.gexec) { hipGraphExecDestroy(P.gexec); P.gexec = nullptr; }
+        P.graph_tried = false;
+#endif
+    }
+    if (!on_device) RT_TRY(rt::h2d(P.user_in, x, in_bytes, ctx->stream));
     Launcher Lc{net, ctx, ctx->stream, nullptr, nullptr};
 #ifndef RY_HOST_EMU
     if (net->use_graph && !P.graph_tried) {
@@ -752,8 +806,7 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
     {
         RY_TRY(enqueue_forward(net, P, Lc));
     }
-    if (on_device) RT_TRY(rt::d2d(y, P.user_out, out_bytes, ctx->stream));
-    else {
+    if (!on_device) {
         RT_TRY(rt::d2h(y, P.user_out, out_bytes, ctx->stream));
         RT_TRY(rt::stream_sync(ctx->stream));
     }
@@ -900,6 +953,7 @@ int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat*
     RY_TRY(get_plan(net, batch, frames, 0, 0, &P));
     ry_ctx* ctx = net->ctx;
     RT_TRY(rt::set_device(ctx->device));
+    if (!P->cur_in) { P->cur_in = P->user_in; P->cur_out = P->user_out; }
     std::vector<KernelRec> rec;
     std::vector<double> total;
     for (int r = 0; r < reps; ++r) {
@@ -1003,9 +1057,13 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
     lp.Wo = transposed ? 2 * Wd : (Wd + 2 * pad - k) / stride + 1;
     if (lp.Ho < 1 || lp.Wo < 1) return fail(RY_EINVAL, "conv2d output would be empty");
     if (path == PATH_IGEMM && !l.wig) return fail(RY_EINVAL, "implicit-GEMM path needs Cin %% 32 == 0 and Cout %% 64 == 0");
+    const bool k3 = !transposed && k == 3 && stride == 1 && pad == 1;
+    if (path == PATH_FIRST && !(k3 && Cin == 1 && Cout % 4 == 0)) return fail(RY_EINVAL, "'first' path is the 1 -> N (N %% 4 == 0) 3x3 layer");
+    if (path == PATH_LAST && !(k3 && Cout == 1 && Cin % 128 == 0)) return fail(RY_EINVAL, "'last' path is the C -> 1 (C %% 128 == 0) 3x3 layer");
     lp.path = path ? path : (l.wig ? PATH_IGEMM : PATH_DIRECT);
     const size_t out_elems = (size_t)B * lp.Ho * lp.Wo * Cout;
     lp.splits = 1;
+    lp.last_rows = lp.Ho; lp.last_cols = lp.Wo; lp.last_exp = 0;
     if (lp.path == PATH_IGEMM) {
         const TapTable t = make_taps(l);
         const int M = B * (transposed ? H * Wd : lp.Ho * lp.Wo);
@@ -1017,9 +1075,26 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
     float* dx = nullptr;
     RY_TRY(arena.alloc(&dx, (size_t)B * H * Wd * Cin));
     RY_TRY(arena.alloc(&lp.out, out_elems));
-    RT_TRY(rt::h2d(dx, x, (size_t)B * H * Wd * Cin * sizeof(float), ctx->stream));
     Launcher Lc{nullptr, ctx, ctx->stream, nullptr, nullptr};
-    RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Cin, nullptr, 0, 0.2f));
+    if (lp.path == PATH_LAST) {
+        // exercise the un-materialised skip concat: the channels are handed over as two half-width sources
+        const int Ch = Cin / 2;
+        const size_t npix = (size_t)B * H * Wd;
+        std::vector<float> ha(npix * Ch), hb(npix * Ch);
+        for (size_t q = 0; q < npix; ++q) {
+            memcpy(&ha[q * Ch], x + q * Cin, Ch * sizeof(float));
+            memcpy(&hb[q * Ch], x + q * Cin + Ch, Ch * sizeof(float));
+        }
+        float* dx2 = nullptr;
+        RY_TRY(arena.alloc(&dx2, npix * Ch));
+        RT_TRY(rt::h2d(dx, ha.data(), npix * Ch * sizeof(float), ctx->stream));
+        RT_TRY(rt::h2d(dx2, hb.data(), npix * Ch * sizeof(float), ctx->stream));
+        RT_TRY(rt::stream_sync(ctx->stream));
+        RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Ch, dx2, Ch, 0.2f));
+    } else {
+        RT_TRY(rt::h2d(dx, x, (size_t)B * H * Wd * Cin * sizeof(float), ctx->stream));
+        RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Cin, nullptr, 0, 0.2f));
+    }
     RT_TRY(rt::d2h(y, lp.out, out_elems * sizeof(float), ctx->stream));
     RT_TRY(rt::stream_sync(ctx->stream));
     return RY_OK;

@@ -78,7 +78,7 @@ class Context(object):
         y = numpy.empty((B, max(Ho, 0), max(Wo, 0), Cout), dtype=numpy.float32)
         bnv = None if bn is None else numpy.ascontiguousarray(numpy.concatenate([numpy.ravel(v) for v in bn]), dtype=numpy.float32)
         bv = None if b is None else numpy.ascontiguousarray(b, dtype=numpy.float32)
-        pth = {'auto': 0, 'igemm': 1, 'direct': 2}[path]
+        pth = {'auto': 0, 'igemm': 1, 'direct': 2, 'first': 3, 'last': 4}[path]
         self.lib.check(self.lib.dll.ry_conv2d(self.handle, _lib._fptr(x), B, H, Wd, Cin, _lib._fptr(W), _lib._fptr(bv), _lib._fptr(bnv),
                                               Cout, k, stride, pad, int(bool(transposed)), _lib.ACTS[act], pth, _lib.TILES[tile],
                                               int(splits), _lib._fptr(y)))

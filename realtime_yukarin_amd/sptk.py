@@ -1,0 +1,51 @@
+"""Host-side restatement of the two SPTK routines `AcousticConverter.decode_spectrogram` uses ([MEM]:
+`pysptk.mc2sp(mc, alpha=pysptk.util.mcepalpha(out_rate), fftlen=1024)`, reached from
+/root/reference/realtime_voice_conversion/yukarin_wrapper/voice_changer.py:38).  In the reference this runs on
+the CPU in SPTK C between the two CNNs; it stays on the host here (SURVEY.md section 8(f) row 1 lists the device
+version as the next row after the CNNs)."""
+import numpy
+
+
+def mcepalpha(fs: int, start: float = 0.0, stop: float = 1.0, step: float = 0.001, num_points: int = 1000) -> float:
+    """pysptk.util.mcepalpha: all-pass constant whose warping is closest (RMS) to the mel scale."""
+    alphas = numpy.arange(start, stop, step)
+    hz = (fs / 2.0) / num_points * numpy.arange(num_points)
+    mel = 1000.0 / numpy.log(2) * numpy.log(1 + hz / 1000.0)
+    mel = mel / mel[-1]
+    omega = numpy.pi / num_points * numpy.arange(num_points)
+    best, best_d = alphas[0], numpy.inf
+    for a in alphas:
+        warp = numpy.arctan2((1 - a * a) * numpy.sin(omega), (1 + a * a) * numpy.cos(omega) - 2 * a)
+        warp[warp < 0] += numpy.pi
+        warp = warp / warp[-1]
+        d = numpy.sqrt(numpy.mean((mel - warp) ** 2))
+        if d < best_d:
+            best, best_d = a, d
+    return float(best)
+
+
+def freqt(c: numpy.ndarray, order: int, alpha: float) -> numpy.ndarray:
+    """SPTK freqt (frequency transform of cepstra), vectorised over frames: c (N, m1+1) -> (N, order+1)."""
+    c = numpy.asarray(c, dtype=numpy.float64)
+    n, m1 = c.shape[0], c.shape[1] - 1
+    beta = 1.0 - alpha * alpha
+    g = numpy.zeros((n, order + 1))
+    for i in range(-m1, 1):
+        d = g.copy()
+        g[:, 0] = c[:, -i] + alpha * d[:, 0]
+        if order >= 1:
+            g[:, 1] = beta * d[:, 0] + alpha * d[:, 1]
+        for j in range(2, order + 1):
+            g[:, j] = d[:, j - 1] + alpha * (d[:, j] - g[:, j - 1])
+    return g
+
+
+def mc2sp(mc: numpy.ndarray, alpha: float, fftlen: int) -> numpy.ndarray:
+    """pysptk.mc2sp: mel-cepstrum (N, order+1) -> power spectrum (N, fftlen/2+1)."""
+    c = freqt(mc, fftlen // 2, -alpha)
+    c[:, 0] *= 2.0
+    symc = numpy.zeros((c.shape[0], fftlen))
+    symc[:, 0] = c[:, 0]
+    symc[:, 1:c.shape[1]] = c[:, 1:]
+    symc[:, -1:-c.shape[1]:-1] = c[:, 1:]
+    return numpy.exp(numpy.fft.rfft(symc, axis=1).real)
