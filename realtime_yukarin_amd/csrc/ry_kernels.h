@@ -46,6 +46,7 @@ struct RyConvGeom {
     int Mh, Mw;
     int stride, pad, ostride;
     int nphases, ntaps;
+    int kw;                     // taps per kernel row (conv: k, sub-pixel deconv: 2); taps are row-major
     int N;                      // output channels
     signed char tdy[4][16], tdx[4][16];
     signed char pdy[4], pdx[4];
@@ -85,6 +86,10 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     const int Ctot = g.C1 + g.C2;
     const int Mimg = g.Mh * g.Mw;
     const int M = g.B * Mimg;
+    // sub-pixel deconv: phase (py,px) reads input offset (py - ty, px - tx) for tap (ty,tx); conv reads (ky,kx).
+    // Offsets are derived from (ky,kx) counters -- no table loads inside the K loop.
+    const bool subpix = g.ostride == 2;
+    const int pdy = subpix ? (phase >> 1) : 0, pdx = subpix ? (phase & 1) : 0;
 
     // per-row geometry, once per workgroup
     for (int r = tid; r < BM; r += 256) {
@@ -96,7 +101,7 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
             yb = ry * g.stride - g.pad;
             xb = rx * g.stride - g.pad;
             pb = b * g.Hi * g.Wi;
-            ob = (b * g.Ho + ry * g.ostride + g.pdy[phase]) * g.Wo + rx * g.ostride + g.pdx[phase];
+            ob = (b * g.Ho + ry * g.ostride + pdy) * g.Wo + rx * g.ostride + pdx;
         }
         rY[r] = yb; rX[r] = xb; rP[r] = pb; rO[r] = ob;
     }
@@ -124,20 +129,24 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     const int kc_end = (int)(((long long)nk * (split + 1)) / p.splits);
     int tap = kc_begin / cpt;
     int cib = kc_begin - tap * cpt;
+    int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
 
     f32x4 areg[AR], breg[BR];
-    auto load_chunk = [&](int tap_, int cib_) {
+    unsigned amask = 0;                            // bit j: row j of this thread's A loads is real data (not padding)
+    auto load_chunk = [&](int tap_, int cib_, int ky_, int kx_) {
+        amask = 0;
         const int ci0 = cib_ * BK;
         const float* src; int Cs, cil;
         if (ci0 < g.C1) { src = g.src1; Cs = g.C1; cil = ci0; } else { src = g.src2; Cs = g.C2; cil = ci0 - g.C1; }
-        const int dy = g.tdy[phase][tap_], dx = g.tdx[phase][tap_];
+        const int dy = subpix ? pdy - ky_ : ky_, dx = subpix ? pdx - kx_ : kx_;
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             const int iy = ayb[j] + dy, ix = axb[j] + dx;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi)
-                v = ry_ld4(src + ((size_t)(apb[j] + iy * g.Wi + ix) * Cs + cil + c4));
-            areg[j] = v;
+            const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            // zero padding / ragged rows: load a valid address and discard (no divergent control flow around the load)
+            const size_t off = ok ? ((size_t)(apb[j] + iy * g.Wi + ix) * Cs + cil + c4) : (size_t)c4;
+            areg[j] = ry_ld4(src + off);           // zeroed when it is written to LDS, so the wait sits after the MFMAs
+            amask |= ok ? (1u << j) : 0u;
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
@@ -146,16 +155,20 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
         }
     };
 
-    if (kc_begin < kc_end) load_chunk(tap, cib);
+    if (kc_begin < kc_end) load_chunk(tap, cib, ky, kx);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
         __syncthreads();                           // previous chunk's fragment reads are done
 #pragma unroll
-        for (int j = 0; j < AR; ++j) ry_st4(&As[(rbase + 32 * j) * BKP + c4], areg[j]);
+        for (int j = 0; j < AR; ++j) {
+            f32x4 v = areg[j];
+            if (!(amask & (1u << j))) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+            ry_st4(&As[(rbase + 32 * j) * BKP + c4], v);
+        }
 #pragma unroll
         for (int j = 0; j < BR; ++j) ry_st4(&Bs[(rbase + 32 * j) * BKP + c4], breg[j]);
         __syncthreads();
-        if (++cib == cpt) { cib = 0; ++tap; }
-        if (kc + 1 < kc_end) load_chunk(tap, cib);  // global loads in flight under the MFMAs below
+        if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
+        if (kc + 1 < kc_end) load_chunk(tap, cib, ky, kx);  // global loads in flight under the MFMAs below
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) {
             f32x4 af[TM], bf[TN];
@@ -429,7 +442,18 @@ RY_DEV f32x4 ry_src1d_load4(const RySrc1d& s, long long pix0, int c, int valid_m
         q[u] = s.raw + (size_t)(pix0 + uu) * (size_t)s.Craw + c;
     }
     float a0 = q[0][0], a1 = q[1][0], a2 = q[2][0], a3 = q[3][0];
-    for (int k = 1; k < s.splits; ++k) {
+    int k = 1;
+    for (; k + 3 < s.splits; k += 4) {             // 16 independent loads in flight; additions stay in split order
+        const size_t o0 = (size_t)k * (size_t)s.slab_stride, o1 = o0 + (size_t)s.slab_stride;
+        const size_t o2 = o1 + (size_t)s.slab_stride, o3 = o2 + (size_t)s.slab_stride;
+        const float b00 = q[0][o0], b10 = q[1][o0], b20 = q[2][o0], b30 = q[3][o0];
+        const float b01 = q[0][o1], b11 = q[1][o1], b21 = q[2][o1], b31 = q[3][o1];
+        const float b02 = q[0][o2], b12 = q[1][o2], b22 = q[2][o2], b32 = q[3][o2];
+        const float b03 = q[0][o3], b13 = q[1][o3], b23 = q[2][o3], b33 = q[3][o3];
+        a0 = ((a0 + b00) + b01) + b02 + b03; a1 = ((a1 + b10) + b11) + b12 + b13;
+        a2 = ((a2 + b20) + b21) + b22 + b23; a3 = ((a3 + b30) + b31) + b32 + b33;
+    }
+    for (; k < s.splits; ++k) {
         const size_t o = (size_t)k * (size_t)s.slab_stride;
         a0 += q[0][o]; a1 += q[1][o]; a2 += q[2][o]; a3 += q[3][o];
     }
@@ -519,39 +543,62 @@ RY_KERNEL(256) void ry_conv1d_ws(RyConv1dParams p) {
         }
         __syncthreads();
         const int cn = (ci_end - cc < CS) ? (ci_end - cc) : CS;
-        for (int cl = 0; cl < cn; ++cl) {
-            const f32x4 w = ry_ld4(p.wd + ((size_t)(cc + cl) * p.N + cw) * 4);
-            const float* x = &xs[cl * PP];
-            if (MODE == RY_C1D_S2) {
-                float xr[PP];
+        // weights: 8 input channels (8 x 16 bytes per lane) are requested ahead of the FMAs that use them
+        constexpr int WB = 8;
+        f32x4 wnext[WB];
 #pragma unroll
-                for (int q = 0; q < PP / 4; ++q) { const f32x4 t = ry_ld4(x + 4 * q); xr[4*q] = t[0]; xr[4*q+1] = t[1]; xr[4*q+2] = t[2]; xr[4*q+3] = t[3]; }
+        for (int u = 0; u < WB; ++u) {
+            const int cl = u < cn ? u : cn - 1;
+            wnext[u] = ry_ld4(p.wd + ((size_t)(cc + cl) * p.N + cw) * 4);
+        }
+        for (int cb = 0; cb < cn; cb += WB) {
+            f32x4 wcur[WB];
 #pragma unroll
-                for (int j = 0; j < TL; ++j)
-                    acc[j] = fmaf(w[3], xr[2*j+3], fmaf(w[2], xr[2*j+2], fmaf(w[1], xr[2*j+1], fmaf(w[0], xr[2*j], acc[j]))));
-            } else if (MODE == RY_C1D_S1) {
-                float xr[PP];
+            for (int u = 0; u < WB; ++u) wcur[u] = wnext[u];
+            if (cb + WB < cn) {
 #pragma unroll
-                for (int q = 0; q < PP / 4; ++q) { const f32x4 t = ry_ld4(x + 4 * q); xr[4*q] = t[0]; xr[4*q+1] = t[1]; xr[4*q+2] = t[2]; xr[4*q+3] = t[3]; }
-#pragma unroll
-                for (int j = 0; j < TL; ++j)
-                    acc[j] = fmaf(w[3], xr[j+3], fmaf(w[2], xr[j+2], fmaf(w[1], xr[j+1], fmaf(w[0], xr[j], acc[j]))));
-            } else if (MODE == RY_C1D_DECONV) {
-                float xr[PP];
-#pragma unroll
-                for (int q = 0; q < PP / 4; ++q) { const f32x4 t = ry_ld4(x + 4 * q); xr[4*q] = t[0]; xr[4*q+1] = t[1]; xr[4*q+2] = t[2]; xr[4*q+3] = t[3]; }
-                // out[2q]   = w1*x[q] + w3*x[q-1] ;  out[2q+1] = w0*x[q+1] + w2*x[q]   (xr[j] = x[l0-1+j])
-#pragma unroll
-                for (int j = 0; j < TL; ++j) {
-                    acc[2*j]   = fmaf(w[3], xr[j],   fmaf(w[1], xr[j+1], acc[2*j]));
-                    acc[2*j+1] = fmaf(w[2], xr[j+1], fmaf(w[0], xr[j+2], acc[2*j+1]));
+                for (int u = 0; u < WB; ++u) {
+                    const int cl = cb + WB + u < cn ? cb + WB + u : cn - 1;
+                    wnext[u] = ry_ld4(p.wd + ((size_t)(cc + cl) * p.N + cw) * 4);
                 }
-            } else {
-                for (int j = 0; j < TL; ++j) {
-                    float a = acc[j];
+            }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) a = fmaf(w[k], x[j * p.stride + k * p.dil], a);
-                    acc[j] = a;
+            for (int u = 0; u < WB; ++u) {
+                const int cl = cb + u;
+                if (cl >= cn) break;
+                const f32x4 w = wcur[u];
+                const float* x = &xs[cl * PP];
+                if (MODE == RY_C1D_S2) {
+                    float xr[PP];
+#pragma unroll
+                    for (int q = 0; q < PP / 4; ++q) { const f32x4 t = ry_ld4(x + 4 * q); xr[4*q] = t[0]; xr[4*q+1] = t[1]; xr[4*q+2] = t[2]; xr[4*q+3] = t[3]; }
+#pragma unroll
+                    for (int j = 0; j < TL; ++j)
+                        acc[j] = fmaf(w[3], xr[2*j+3], fmaf(w[2], xr[2*j+2], fmaf(w[1], xr[2*j+1], fmaf(w[0], xr[2*j], acc[j]))));
+                } else if (MODE == RY_C1D_S1) {
+                    float xr[PP];
+#pragma unroll
+                    for (int q = 0; q < PP / 4; ++q) { const f32x4 t = ry_ld4(x + 4 * q); xr[4*q] = t[0]; xr[4*q+1] = t[1]; xr[4*q+2] = t[2]; xr[4*q+3] = t[3]; }
+#pragma unroll
+                    for (int j = 0; j < TL; ++j)
+                        acc[j] = fmaf(w[3], xr[j+3], fmaf(w[2], xr[j+2], fmaf(w[1], xr[j+1], fmaf(w[0], xr[j], acc[j]))));
+                } else if (MODE == RY_C1D_DECONV) {
+                    float xr[PP];
+#pragma unroll
+                    for (int q = 0; q < PP / 4; ++q) { const f32x4 t = ry_ld4(x + 4 * q); xr[4*q] = t[0]; xr[4*q+1] = t[1]; xr[4*q+2] = t[2]; xr[4*q+3] = t[3]; }
+                    // out[2q]   = w1*x[q] + w3*x[q-1] ;  out[2q+1] = w0*x[q+1] + w2*x[q]   (xr[j] = x[l0-1+j])
+#pragma unroll
+                    for (int j = 0; j < TL; ++j) {
+                        acc[2*j]   = fmaf(w[3], xr[j],   fmaf(w[1], xr[j+1], acc[2*j]));
+                        acc[2*j+1] = fmaf(w[2], xr[j+1], fmaf(w[0], xr[j+2], acc[2*j+1]));
+                    }
+                } else {
+                    for (int j = 0; j < TL; ++j) {
+                        float a = acc[j];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a = fmaf(w[k], x[j * p.stride + k * p.dil], a);
+                        acc[j] = a;
+                    }
                 }
             }
         }

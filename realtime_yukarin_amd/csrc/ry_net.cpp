@@ -423,7 +423,7 @@ static void fill_geom(RyConvGeom& g, const Layer& l, const LayerPlan& lp, int B,
     g.B = B; g.Hi = lp.Hi; g.Wi = lp.Wi; g.Ho = lp.Ho; g.Wo = lp.Wo;
     if (l.deconv) { g.Mh = lp.Hi; g.Mw = lp.Wi; g.stride = 1; g.pad = 0; g.ostride = 2; }
     else { g.Mh = lp.Ho; g.Mw = lp.Wo; g.stride = l.stride; g.pad = l.pad; g.ostride = 1; }
-    g.nphases = t.nphases; g.ntaps = t.ntaps; g.N = l.cout;
+    g.nphases = t.nphases; g.ntaps = t.ntaps; g.N = l.cout; g.kw = l.deconv ? 2 : l.k;
     for (int ph = 0; ph < 4; ++ph) {
         g.pdy[ph] = (signed char)t.pdy[ph]; g.pdx[ph] = (signed char)t.pdx[ph];
         for (int tt = 0; tt < 16; ++tt) { g.tdy[ph][tt] = (signed char)t.dy[ph][tt]; g.tdx[ph][tt] = (signed char)t.dx[ph][tt]; }
