@@ -109,11 +109,20 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 
     const int c4 = (tid & 7) * 4;                  // float offset of this thread's 16 bytes in a K chunk
     const int rbase = tid >> 3;                    // 0..31
-    int ayb[AR], axb[AR], apb[AR];
+    // Per-row state: base coordinates (for the padding test) and the element offset of the row's base pixel.
+    // Offsets are 32-bit (the executor bounds every activation below 2^31 elements); a tap only adds a
+    // workgroup-uniform delta, so the K loop does one vector add per row instead of 64-bit multiplies.
+    int ayb[AR], axb[AR], aoff1[AR], aoff2[AR];
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
-        ayb[j] = rY[rbase + 32 * j]; axb[j] = rX[rbase + 32 * j]; apb[j] = rP[rbase + 32 * j];
+        ayb[j] = rY[rbase + 32 * j]; axb[j] = rX[rbase + 32 * j];
+        const int pixb = rP[rbase + 32 * j] + ayb[j] * g.Wi + axb[j];     // may be "negative" on padded rows: never dereferenced
+        aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + c4 : 0;
+        aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + c4 : 0;
     }
+    unsigned boff[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) boff[j] = (unsigned)(((phase * g.N + n0 + rbase + 32 * j) * g.ntaps) * Ctot + c4);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -136,23 +145,24 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     auto load_chunk = [&](int tap_, int cib_, int ky_, int kx_) {
         amask = 0;
         const int ci0 = cib_ * BK;
-        const float* src; int Cs, cil;
-        if (ci0 < g.C1) { src = g.src1; Cs = g.C1; cil = ci0; } else { src = g.src2; Cs = g.C2; cil = ci0 - g.C1; }
+        const bool first = ci0 < g.C1;
+        const float* src = first ? g.src1 : g.src2;
+        const int Cs = first ? g.C1 : g.C2;
+        const int cil = first ? ci0 : ci0 - g.C1;
         const int dy = subpix ? pdy - ky_ : ky_, dx = subpix ? pdx - kx_ : kx_;
+        const int delta = (dy * g.Wi + dx) * Cs + cil;          // workgroup-uniform (scalar unit)
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             const int iy = ayb[j] + dy, ix = axb[j] + dx;
             const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
             // zero padding / ragged rows: load a valid address and discard (no divergent control flow around the load)
-            const size_t off = ok ? ((size_t)(apb[j] + iy * g.Wi + ix) * Cs + cil + c4) : (size_t)c4;
-            areg[j] = ry_ld4(src + off);           // zeroed when it is written to LDS, so the wait sits after the MFMAs
+            const int off = ok ? (first ? aoff1[j] : aoff2[j]) + delta : c4;
+            areg[j] = ry_ld4(src + (unsigned)off);  // zeroed when it is written to LDS, so the wait sits after the MFMAs
             amask |= ok ? (1u << j) : 0u;
         }
+        const unsigned bdelta = (unsigned)(tap_ * Ctot + ci0);
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            const int n = n0 + rbase + 32 * j;
-            breg[j] = ry_ld4(p.wt + (((size_t)(phase * g.N + n) * g.ntaps + tap_) * Ctot + ci0 + c4));
-        }
+        for (int j = 0; j < BR; ++j) breg[j] = ry_ld4(p.wt + (boff[j] + bdelta));
     };
 
     if (kc_begin < kc_end) load_chunk(tap, cib, ky, kx);
@@ -355,7 +365,8 @@ struct RySrLastParams {
     int do_exp;
 };
 
-RY_KERNEL(256) void ry_sr_last(RySrLastParams p) {     // 32 lanes per output pixel, 16 bytes of channels per lane per tap
+// Simple form: 32 lanes per output pixel, 9 taps gathered per pixel (any width).
+RY_KERNEL(256) void ry_sr_last_gather(RySrLastParams p) {
     const int l = (int)threadIdx.x & 31;
     const long long pix = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
     const long long total = (long long)p.B * p.rows_valid * p.W;
@@ -385,6 +396,87 @@ RY_KERNEL(256) void ry_sr_last(RySrLastParams p) {     // 32 lanes per output pi
     acc += ry_shfl_xor(acc, 1);
     if (live && l == 0) {
         float v = fmaf(acc, p.scale[0], p.shift[0]);
+        if (p.do_exp) v = expf(v);
+        float* o = p.out + ((size_t)b * p.rows_valid + y) * p.out_cols;
+        o[x] = v;
+        if (x == p.W - 1 && p.out_cols > p.W) o[p.W] = v;
+    }
+}
+
+// Rolling form (C1 + C2 == 128, W % 16 == 0): a 32-lane group owns a strip of 16 output pixels of one row;
+// lane = 4 channels.  Every input pixel vector of the 3 x 18 halo is loaded ONCE, multiplied by the three
+// kx taps of its row and accumulated into the outputs it touches; the 16 per-lane partial sums are then
+// reduced across the 32 lanes with a transposing (reduce-scatter) butterfly: 15 + 1 shuffles instead of 80.
+RY_KERNEL(256) void ry_sr_last(RySrLastParams p) {
+    constexpr int SW = 16;
+    const int l = (int)threadIdx.x & 31;
+    const int strips = p.W / SW;
+    const long long sid = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const long long total = (long long)p.B * p.rows_valid * strips;
+    const bool live = sid < total;
+    const long long ss = live ? sid : 0;
+    const int x0 = (int)(ss % strips) * SW;
+    const int y = (int)((ss / strips) % p.rows_valid);
+    const int b = (int)(ss / ((long long)strips * p.rows_valid));
+    const int c = l * 4;
+    const bool first = c < p.C1;
+    const float* src = first ? p.src1 + c : p.src2 + (c - p.C1);
+    const int Cs = first ? p.C1 : p.C2;
+    float acc[SW + 2];                             // acc[j] = output column x0 - 1 + j (two halo slots are discarded)
+#pragma unroll
+    for (int j = 0; j < SW + 2; ++j) acc[j] = 0.f;
+    if (live) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+            if ((unsigned)iy >= (unsigned)p.H) continue;
+            const f32x4 w0 = ry_ld4(p.w + (size_t)(ky * 3 + 0) * 128 + c);
+            const f32x4 w1 = ry_ld4(p.w + (size_t)(ky * 3 + 1) * 128 + c);
+            const f32x4 w2 = ry_ld4(p.w + (size_t)(ky * 3 + 2) * 128 + c);
+            const float* row = src + ((size_t)b * p.H + iy) * p.W * Cs;
+#pragma unroll
+            for (int j = 0; j < SW + 2; ++j) {     // input column ix = x0 - 1 + j
+                const int ix = x0 - 1 + j;
+                if ((unsigned)ix >= (unsigned)p.W) continue;
+                const f32x4 v = ry_ld4(row + (size_t)ix * Cs);
+                // out[ox] += w[kx] . in[ox + kx - 1]  ->  input ix feeds ox = ix + 1 - kx, i.e. acc[j + 1 - kx]
+                const float d0 = fmaf(v[3], w0[3], fmaf(v[2], w0[2], fmaf(v[1], w0[1], v[0] * w0[0])));
+                const float d1 = fmaf(v[3], w1[3], fmaf(v[2], w1[2], fmaf(v[1], w1[1], v[0] * w1[0])));
+                const float d2 = fmaf(v[3], w2[3], fmaf(v[2], w2[2], fmaf(v[1], w2[1], v[0] * w2[0])));
+                if (j + 1 < SW + 2) acc[j + 1] += d0;
+                acc[j] += d1;
+                if (j >= 1) acc[j - 1] += d2;
+            }
+        }
+    }
+    // reduce-scatter over the 32 lanes: after the steps with masks 16, 8, 4, 2 a lane holds ONE output column
+    float r8[8], r4[4], r2[2], r1;
+    const bool h16 = (l & 16) != 0, h8 = (l & 8) != 0, h4 = (l & 4) != 0, h2 = (l & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float lo = acc[1 + i], hi = acc[1 + i + 8];
+        const float recv = ry_shfl_xor(h16 ? lo : hi, 16);
+        r8[i] = (h16 ? hi : lo) + recv;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float recv = ry_shfl_xor(h8 ? r8[i] : r8[i + 4], 8);
+        r4[i] = (h8 ? r8[i + 4] : r8[i]) + recv;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float recv = ry_shfl_xor(h4 ? r4[i] : r4[i + 2], 4);
+        r2[i] = (h4 ? r4[i + 2] : r4[i]) + recv;
+    }
+    {
+        const float recv = ry_shfl_xor(h2 ? r2[0] : r2[1], 2);
+        r1 = (h2 ? r2[1] : r2[0]) + recv;
+    }
+    r1 += ry_shfl_xor(r1, 1);
+    if (live && (l & 1) == 0) {
+        const int col = (h16 ? 8 : 0) + (h8 ? 4 : 0) + (h4 ? 2 : 0) + (h2 ? 1 : 0);
+        const int x = x0 + col;
+        float v = fmaf(r1, p.scale[0], p.shift[0]);
         if (p.do_exp) v = expf(v);
         float* o = p.out + ((size_t)b * p.rows_valid + y) * p.out_cols;
         o[x] = v;

@@ -49,6 +49,7 @@ static err_t event_destroy(Event&) { return 0; }
 static err_t event_record(Event&, ry_stream_t) { return 0; }
 static err_t event_sync(Event&) { return 0; }
 static err_t event_elapsed(float* ms, Event&, Event&) { *ms = 0.f; return 0; }
+static err_t stream_wait_event(ry_stream_t, Event&) { return 0; }
 #else
 typedef hipError_t err_t;
 static const char* err_str(err_t e) { return hipGetErrorString(e); }
@@ -69,6 +70,7 @@ static err_t event_destroy(Event& e) { return hipEventDestroy(e); }
 static err_t event_record(Event& e, ry_stream_t s) { return hipEventRecord(e, s); }
 static err_t event_sync(Event& e) { return hipEventSynchronize(e); }
 static err_t event_elapsed(float* ms, Event& a, Event& b) { return hipEventElapsedTime(ms, a, b); }
+static err_t stream_wait_event(ry_stream_t s, Event& e) { return hipStreamWaitEvent(s, e, 0); }
 #endif
 }  // namespace rt
 
@@ -96,7 +98,9 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 // ------------------------------------------------------------------------------------------------
+struct ry_net;
 struct ry_ctx {
+    std::vector<ry_net*> nets;
     int device = 0;
     ry_stream_t stream = nullptr;
     rt::Event t0, t1;
@@ -304,7 +308,7 @@ static bool igemm_eligible(const Layer& l) {
 // per-layer launch plans
 // ------------------------------------------------------------------------------------------------
 enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4 };
-enum { TILE_128x128 = 1, TILE_256x64 = 2, TILE_64x128 = 3, TILE_32x128 = 4 };
+enum { TILE_128x128 = 1, TILE_256x64 = 2, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5 };
 
 struct LayerPlan {
     // geometry
@@ -350,6 +354,9 @@ struct KernelRec {           // filled by the launch helpers when profiling
 
 struct ry_net {
     ry_ctx* ctx = nullptr;
+    ry_stream_t stream = nullptr;            // each predictor enqueues on its own stream: stage-1 of one window overlaps stage-2 of another
+    rt::Event done;                          // recorded after the last enqueue; ry_sync / ry_timer_stop wait on it
+    bool has_done = false;
     ry_net_desc desc;
     std::vector<Layer> layers;
     Arena weights;
@@ -435,6 +442,7 @@ static void tile_dims(int tile, int* bm, int* bn) {
         case TILE_128x128: *bm = 128; *bn = 128; break;
         case TILE_256x64: *bm = 256; *bn = 64; break;
         case TILE_64x128: *bm = 64; *bn = 128; break;
+        case TILE_128x64: *bm = 128; *bn = 64; break;
         default: *bm = 32; *bn = 128; break;
     }
 }
@@ -444,14 +452,17 @@ static const char* tile_name(int tile) {
         case TILE_128x128: return "ry_igemm_f32<128,128>";
         case TILE_256x64: return "ry_igemm_f32<256,64>";
         case TILE_64x128: return "ry_igemm_f32<64,128>";
+        case TILE_128x64: return "ry_igemm_f32<128,64>";
         default: return "ry_igemm_f32<32,128>";
     }
 }
 
+static int g_tile64 = TILE_256x64;   // tile for 64-channel outputs (RY_TILE64=128 selects 128x64)
+
 // choose tile + split-K for one stage-2 layer
 static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits) {
     int t;
-    if (l.cout % 128 != 0) t = TILE_256x64;
+    if (l.cout % 128 != 0) t = g_tile64;
     else if (M >= 1024) t = TILE_128x128;
     else if (M > 32) t = TILE_64x128;
     else t = TILE_32x128;
@@ -462,12 +473,18 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
         // closest to a whole number of waves over the 256 CUs (>= 2 workgroups per CU, >= 4 K-chunks per split)
         const long blocks = (long)((M + bm - 1) / bm) * (l.cout / bn) * nphases;
         int best = 1; double best_eff = -1.0;
-        for (int s = 1; s <= 32 && s <= (nk >= 4 ? nk / 4 : 1); ++s) {
+        const bool tinyM = M <= 64;                               // pure weight streaming: latency-bound per workgroup
+        const int smax = tinyM ? 128 : 32;
+        const int min_chunks = tinyM ? 2 : 4;
+        for (int s = 1; s <= smax && s <= (nk >= min_chunks ? nk / min_chunks : 1); ++s) {
             const long g = blocks * s;
             const long rounds = (g + 255) / 256;
             double eff = (double)g / (double)(rounds * 256);
-            if (rounds < 2) eff *= 0.5 * rounds + 0.25;          // a single thin wave cannot hide its own barriers
-            eff -= 0.004 * (s - 1);                               // each extra split adds slab traffic + a reduce pass
+            if (tinyM) eff = g >= 1024 ? 1.0 - 1e-4 * s : (double)g / 1024.0;   // fill the chip with loads in flight
+            else {
+                if (rounds < 2) eff *= 0.5 * rounds + 0.25;      // a single thin wave cannot hide its own barriers
+                eff -= 0.004 * (s - 1);                           // each extra split adds slab traffic + a reduce pass
+            }
             if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
         }
         *splits = best;
@@ -492,6 +509,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             case TILE_128x128: RY_LAUNCH((ry_igemm_f32<128, 128, 2, 2>), grid, 256, Lc.stream, p); break;
             case TILE_256x64: RY_LAUNCH((ry_igemm_f32<256, 64, 4, 1>), grid, 256, Lc.stream, p); break;
             case TILE_64x128: RY_LAUNCH((ry_igemm_f32<64, 128, 1, 4>), grid, 256, Lc.stream, p); break;
+            case TILE_128x64: RY_LAUNCH((ry_igemm_f32<128, 64, 4, 1>), grid, 256, Lc.stream, p); break;
             default: RY_LAUNCH((ry_igemm_f32<32, 128, 1, 4>), grid, 256, Lc.stream, p); break;
         }
         RY_TRY(Lc.end());
@@ -521,8 +539,15 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         p.rows_valid = lp.last_rows; p.out_cols = lp.last_cols; p.do_exp = lp.last_exp;
         const long long total = (long long)B * p.rows_valid * lp.Wi;
         dim3 grid((unsigned)((total + 7) / 8));
-        RY_TRY(Lc.begin("ry_sr_last", l.name, lp.flops, lp.bytes, grid));
-        RY_LAUNCH(ry_sr_last, grid, 256, Lc.stream, p);
+        if (C1 + C2 == 128 && lp.Wi % 16 == 0) {
+            const long long strips = (long long)B * p.rows_valid * (lp.Wi / 16);
+            dim3 sg((unsigned)((strips + 7) / 8));
+            RY_TRY(Lc.begin("ry_sr_last", l.name, lp.flops, lp.bytes, sg));
+            RY_LAUNCH(ry_sr_last, sg, 256, Lc.stream, p);
+        } else {
+            RY_TRY(Lc.begin("ry_sr_last_gather", l.name, lp.flops, lp.bytes, grid));
+            RY_LAUNCH(ry_sr_last_gather, grid, 256, Lc.stream, p);
+        }
         RY_TRY(Lc.end());
     } else {
         RyDirectParams p;
@@ -782,15 +807,15 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
         P.graph_tried = false;
 #endif
     }
-    if (!on_device) RT_TRY(rt::h2d(P.user_in, x, in_bytes, ctx->stream));
-    Launcher Lc{net, ctx, ctx->stream, nullptr, nullptr};
+    if (!on_device) RT_TRY(rt::h2d(P.user_in, x, in_bytes, net->stream));
+    Launcher Lc{net, ctx, net->stream, nullptr, nullptr};
 #ifndef RY_HOST_EMU
     if (net->use_graph && !P.graph_tried) {
         P.graph_tried = true;
         hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        if (hipStreamBeginCapture(net->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int r = enqueue_forward(net, P, Lc);
-            hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+            hipError_t e = hipStreamEndCapture(net->stream, &graph);
             if (r == RY_OK && e == hipSuccess && graph) {
                 if (hipGraphInstantiate(&P.gexec, graph, nullptr, nullptr, 0) != hipSuccess) P.gexec = nullptr;
             }
@@ -800,15 +825,17 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
         }
     }
     if (P.gexec) {
-        RT_TRY(hipGraphLaunch(P.gexec, ctx->stream));
+        RT_TRY(hipGraphLaunch(P.gexec, net->stream));
     } else
 #endif
     {
         RY_TRY(enqueue_forward(net, P, Lc));
     }
     if (!on_device) {
-        RT_TRY(rt::d2h(y, P.user_out, out_bytes, ctx->stream));
-        RT_TRY(rt::stream_sync(ctx->stream));
+        RT_TRY(rt::d2h(y, P.user_out, out_bytes, net->stream));
+        RT_TRY(rt::stream_sync(net->stream));
+    } else {
+        RT_TRY(rt::event_record(net->done, net->stream));      // lets ry_sync / ry_timer_stop join this predictor's stream
     }
     return RY_OK;
 }
@@ -854,6 +881,7 @@ void ry_shutdown(ry_ctx* ctx) {
 
 int ry_sync(ry_ctx* ctx) {
     if (!ctx) return fail(RY_ESTATE, "null context");
+    for (ry_net* n : ctx->nets) RT_TRY(rt::stream_sync(n->stream));
     RT_TRY(rt::stream_sync(ctx->stream));
     return RY_OK;
 }
@@ -863,11 +891,16 @@ void* ry_stream(ry_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int ry_timer_start(ry_ctx* ctx) {
     if (!ctx) return fail(RY_ESTATE, "null context");
     RT_TRY(rt::event_record(ctx->t0, ctx->stream));
+    for (ry_net* n : ctx->nets) RT_TRY(rt::stream_wait_event(n->stream, ctx->t0));   // predictors start after t0
     return RY_OK;
 }
 
 int ry_timer_stop(ry_ctx* ctx, float* ms) {
     if (!ctx || !ms) return fail(RY_EINVAL, "null argument");
+    for (ry_net* n : ctx->nets) {                                                      // t1 after every predictor stream
+        RT_TRY(rt::event_record(n->done, n->stream));
+        RT_TRY(rt::stream_wait_event(ctx->stream, n->done));
+    }
     RT_TRY(rt::event_record(ctx->t1, ctx->stream));
     RT_TRY(rt::event_sync(ctx->t1));
     RT_TRY(rt::event_elapsed(ms, ctx->t0, ctx->t1));
@@ -902,6 +935,10 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
     if (net->desc.bn_eps <= 0.f) net->desc.bn_eps = 2e-5f;
     net->layers = build_topology(*desc);
     if (const char* e = getenv("RY_GRAPH")) net->use_graph = atoi(e) != 0;
+    if (const char* e = getenv("RY_TILE64")) g_tile64 = atoi(e) == 128 ? TILE_128x64 : TILE_256x64;
+    RT_TRY(rt::stream_create(&net->stream));
+    RT_TRY(rt::event_create(&net->done));
+    net->has_done = true;
     size_t off = 0;
     for (Layer& l : net->layers) {
         const size_t nw = (size_t)l.cin() * l.cout * ipow((size_t)l.k, desc->ndim);
@@ -911,6 +948,7 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
         if (l.bn) { bn = blob + off; off += 4 * (size_t)l.cout; }
         RY_TRY(prepare_layer(ctx, net->weights, l, desc->ndim, net->desc.bn_eps, W, b, bn));
     }
+    ctx->nets.push_back(net.get());
     *out = net.release();
     return RY_OK;
 }
@@ -918,7 +956,14 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
 void ry_net_destroy(ry_net* net) {
     if (!net) return;
     rt::set_device(net->ctx->device);
+    rt::stream_sync(net->stream);
     rt::stream_sync(net->ctx->stream);
+    auto& v = net->ctx->nets;
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i] == net) { v.erase(v.begin() + i); break; }
+    net->plans.clear();
+    if (net->has_done) rt::event_destroy(net->done);
+    rt::stream_destroy(net->stream);
     delete net;
 }
 
@@ -959,9 +1004,9 @@ int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat*
     for (int r = 0; r < reps; ++r) {
         std::vector<KernelRec> rr;
         std::vector<std::pair<rt::Event, rt::Event>> ev;
-        Launcher Lc{net, ctx, ctx->stream, &rr, &ev};
+        Launcher Lc{net, ctx, net->stream, &rr, &ev};
         int rc = enqueue_forward(net, *P, Lc);
-        if (rc == RY_OK && rt::stream_sync(ctx->stream) != 0) rc = fail(RY_EHIP, "stream sync failed while profiling");
+        if (rc == RY_OK && rt::stream_sync(net->stream) != 0) rc = fail(RY_EHIP, "stream sync failed while profiling");
         if (rc == RY_OK) {
             if (total.empty()) total.assign(ev.size(), 0.0);
             for (size_t i = 0; i < ev.size() && i < total.size(); ++i) {
@@ -1068,7 +1113,7 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
         const TapTable t = make_taps(l);
         const int M = B * (transposed ? H * Wd : lp.Ho * lp.Wo);
         lp.tile = tile; lp.splits = splits;
-        if (tile == TILE_256x64 ? Cout % 64 : (tile != 0 && Cout % 128)) return fail(RY_EINVAL, "tile does not divide Cout");
+        if ((tile == TILE_256x64 || tile == TILE_128x64) ? Cout % 64 : (tile != 0 && Cout % 128)) return fail(RY_EINVAL, "tile does not divide Cout");
         choose_igemm(l, M, t.nphases, t.ntaps * (Cin / 32), &lp.tile, &lp.splits);
         if (lp.splits > 1) RY_TRY(arena.alloc(&lp.slabs, out_elems * lp.splits));
     }

@@ -38,6 +38,10 @@ CONV2D_CASES = [
     (2, 7, 10, 1, 64, 3, 1, 1, False, 'lrelu', 'first', None, 0),      # specialised SR encoder c0 (ragged width)
     (2, 5, 9, 128, 1, 3, 1, 1, False, None, 'last', None, 0),          # specialised SR decoder c7 (two-source concat)
     (1, 4, 6, 256, 1, 3, 1, 1, False, None, 'last', None, 0),
+    (2, 5, 32, 128, 1, 3, 1, 1, False, None, 'last', None, 0),         # rolling-window form (W % 16 == 0, 128 channels)
+    (1, 3, 16, 128, 1, 3, 1, 1, False, None, 'last', None, 0),
+    (1, 16, 20, 32, 64, 4, 2, 1, False, 'relu', 'igemm', '128x64', 2),
+    (1, 6, 10, 64, 64, 4, 2, 1, True, 'relu', 'igemm', '128x64', 0),
 ]
 
 
