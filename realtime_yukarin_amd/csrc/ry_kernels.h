@@ -234,11 +234,18 @@ struct RyReduceParams {
 RY_KERNEL(256) void ry_splitk_reduce(RyReduceParams p) {
     const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i4 >= p.total) return;
-    f32x4 s = ry_ld4(p.slabs + i4);
-    for (int k = 1; k < p.splits; ++k) {
-        const f32x4 v = ry_ld4(p.slabs + (size_t)k * (size_t)p.slab_stride + i4);
-        s += v;
+    // four independent partial sums (slabs k = 0,1,2,3 mod 4) keep >= 4 loads in flight; the order is fixed,
+    // so the result is deterministic
+    f32x4 s0 = ry_ld4(p.slabs + i4), s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+    const size_t st = (size_t)p.slab_stride;
+    int k = 1;
+    for (; k + 3 < p.splits; k += 4) {
+        const f32x4 a = ry_ld4(p.slabs + (size_t)k * st + i4), b = ry_ld4(p.slabs + (size_t)(k + 1) * st + i4);
+        const f32x4 c = ry_ld4(p.slabs + (size_t)(k + 2) * st + i4), d = ry_ld4(p.slabs + (size_t)(k + 3) * st + i4);
+        s1 += a; s2 += b; s3 += c; s0 += d;
     }
+    for (; k < p.splits; ++k) s1 += ry_ld4(p.slabs + (size_t)k * st + i4);
+    const f32x4 s = (s0 + s1) + (s2 + s3);
     const int n = (int)(i4 % p.N);
     const f32x4 sc = ry_ld4(p.scale + n), sh = ry_ld4(p.shift + n);
     f32x4 o;
@@ -407,7 +414,7 @@ RY_KERNEL(256) void ry_sr_last_gather(RySrLastParams p) {
 // lane = 4 channels.  Every input pixel vector of the 3 x 18 halo is loaded ONCE, multiplied by the three
 // kx taps of its row and accumulated into the outputs it touches; the 16 per-lane partial sums are then
 // reduced across the 32 lanes with a transposing (reduce-scatter) butterfly: 15 + 1 shuffles instead of 80.
-RY_KERNEL(256) void ry_sr_last(RySrLastParams p) {
+RY_KERNEL(256, 2) void ry_sr_last(RySrLastParams p) {
     constexpr int SW = 16;
     const int l = (int)threadIdx.x & 31;
     const int strips = p.W / SW;
@@ -429,23 +436,31 @@ RY_KERNEL(256) void ry_sr_last(RySrLastParams p) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = y + ky - 1;
-            if ((unsigned)iy >= (unsigned)p.H) continue;
-            const f32x4 w0 = ry_ld4(p.w + (size_t)(ky * 3 + 0) * 128 + c);
-            const f32x4 w1 = ry_ld4(p.w + (size_t)(ky * 3 + 1) * 128 + c);
-            const f32x4 w2 = ry_ld4(p.w + (size_t)(ky * 3 + 2) * 128 + c);
-            const float* row = src + ((size_t)b * p.H + iy) * p.W * Cs;
+            const bool rok = (unsigned)iy < (unsigned)p.H;
+            const int iyc = rok ? iy : y;                       // padded rows read a valid row and are zeroed by `rz`
+            const float rz = rok ? 1.f : 0.f;
+            f32x4 w0 = ry_ld4(p.w + (size_t)(ky * 3 + 0) * 128 + c);
+            f32x4 w1 = ry_ld4(p.w + (size_t)(ky * 3 + 1) * 128 + c);
+            f32x4 w2 = ry_ld4(p.w + (size_t)(ky * 3 + 2) * 128 + c);
+            w0 *= rz; w1 *= rz; w2 *= rz;
+            const float* row = src + ((size_t)b * p.H + iyc) * p.W * Cs;
+            // interior columns x0 .. x0+SW-1 are always inside the image (W % SW == 0): no tests, loads batch freely
 #pragma unroll
-            for (int j = 0; j < SW + 2; ++j) {     // input column ix = x0 - 1 + j
-                const int ix = x0 - 1 + j;
-                if ((unsigned)ix >= (unsigned)p.W) continue;
-                const f32x4 v = ry_ld4(row + (size_t)ix * Cs);
+            for (int j = 1; j <= SW; ++j) {
+                const f32x4 v = ry_ld4(row + (size_t)(x0 - 1 + j) * Cs);
                 // out[ox] += w[kx] . in[ox + kx - 1]  ->  input ix feeds ox = ix + 1 - kx, i.e. acc[j + 1 - kx]
-                const float d0 = fmaf(v[3], w0[3], fmaf(v[2], w0[2], fmaf(v[1], w0[1], v[0] * w0[0])));
-                const float d1 = fmaf(v[3], w1[3], fmaf(v[2], w1[2], fmaf(v[1], w1[1], v[0] * w1[0])));
-                const float d2 = fmaf(v[3], w2[3], fmaf(v[2], w2[2], fmaf(v[1], w2[1], v[0] * w2[0])));
-                if (j + 1 < SW + 2) acc[j + 1] += d0;
-                acc[j] += d1;
-                if (j >= 1) acc[j - 1] += d2;
+                acc[j + 1] += fmaf(v[3], w0[3], fmaf(v[2], w0[2], fmaf(v[1], w0[1], v[0] * w0[0])));
+                acc[j]     += fmaf(v[3], w1[3], fmaf(v[2], w1[2], fmaf(v[1], w1[1], v[0] * w1[0])));
+                acc[j - 1] += fmaf(v[3], w2[3], fmaf(v[2], w2[2], fmaf(v[1], w2[1], v[0] * w2[0])));
+            }
+            // the two halo columns x0-1 and x0+SW (zero outside the image)
+            {
+                const bool lok = x0 > 0, rgt = x0 + SW < p.W;
+                const f32x4 vl = ry_ld4(row + (size_t)(lok ? x0 - 1 : x0) * Cs);
+                const f32x4 vr = ry_ld4(row + (size_t)(rgt ? x0 + SW : x0) * Cs);
+                const float zl = lok ? 1.f : 0.f, zr = rgt ? 1.f : 0.f;
+                acc[1]  += zl * fmaf(vl[3], w0[3], fmaf(vl[2], w0[2], fmaf(vl[1], w0[1], vl[0] * w0[0])));   // ix = x0-1 feeds ox = x0 via kx = 0
+                acc[SW] += zr * fmaf(vr[3], w2[3], fmaf(vr[2], w2[2], fmaf(vr[1], w2[1], vr[0] * w2[0])));   // ix = x0+SW feeds ox = x0+SW-1 via kx = 2
             }
         }
     }
