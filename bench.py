@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--profile-reps', type=int, default=5)
+    ap.add_argument('--profile-only', action='store_true', help='only print the per-kernel-family profile of stage-2 (tuning aid)')
     ap.add_argument('--layers-out', default=None, help='write the per-launch profile (layer, kernel, ms, TFLOP/s, GB/s) to this file')
     return ap.parse_args()
 
@@ -93,6 +94,27 @@ def main():
     y1 = torch.empty(Wn, N, d1.out_ch, dtype=torch.float32, device=dev)
     y2 = torch.empty_like(sp)
     torch.cuda.synchronize()
+
+    if args.profile_only:
+        xin = torch.randn(Wn, T, synth.FFT_BINS - 1, device=dev); yout = torch.empty_like(xin)
+        for _ in range(3):
+            net2.forward_device(xin.data_ptr(), yout.data_ptr(), Wn, T)
+        ctx.sync()
+        st = net2.profile(Wn, T, args.profile_reps)
+        fam = {}
+        for q in st:
+            f = fam.setdefault(q['name'], [0.0, 0.0])
+            f[0] += q['ms']; f[1] += q['flops']
+        print(' | '.join('%s %.1fus %.1fTF' % (k, v[0] * 1e3, v[1] / max(v[0], 1e-9) / 1e9) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:5]), flush=True)
+        if os.environ.get('RY_TIMING'):
+            import ctypes
+            buf = (ctypes.c_ulonglong * 8)()
+            ctx.lib.dll.ry_debug_igemm_phases.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
+            ctx.lib.check(ctx.lib.dll.ry_debug_igemm_phases(ctx.handle, buf))
+            tot = float(sum(buf[:7])) or 1.0
+            names = ['barrier1', 'lds_write(+vmcnt)', 'barrier2', 'setup/loads', 'mfma steps', 'prologue', 'epilogue']
+            print('   phases: ' + ' '.join('%s=%.1f%%' % (n, 100.0 * buf[i] / tot) for i, n in enumerate(names)) + '  waves=%d cyc/wave=%.0f' % (buf[7], tot / max(buf[7], 1)), flush=True)
+        return
 
     def step():
         net1.convert_device(x1.data_ptr(), y1.data_ptr(), Wn, N)

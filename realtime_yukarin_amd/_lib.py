@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     'ry_init', 'ry_shutdown', 'ry_sync', 'ry_stream', 'ry_device_count', 'ry_last_error',
     'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_forward',
     'ry_ac_convert', 'ry_sr_convert', 'ry_conv1d', 'ry_conv2d',
-    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile',
+    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_debug_igemm_phases',
 )
 
 

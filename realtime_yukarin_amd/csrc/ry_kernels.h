@@ -62,13 +62,29 @@ struct RyIgemmParams {
     int act;
     float slope;
     long long slab_stride;
+    unsigned long long* dbg;    // VAR bit 1 (diagnostic build of the kernel): per-phase shader-clock totals, else unused
 };
 
-template <int BM, int BN, int WM, int WN>
+// VAR bit 1 (RY_TIMING=1, diagnostics only): every wave accumulates s_memtime deltas per loop phase into p.dbg.
+// ILV = 1: the global loads of chunk k+1 are issued in BK/8 slices between the MFMA steps of chunk k instead of
+// in one burst before them (a burst of 8-12 16-byte loads per lane from every wave of the CU back-pressures the
+// vector-memory queue and the wave cannot issue its MFMAs while it is stuck issuing loads).
+template <int BM, int BN, int WM, int WN, int BK, int VAR>
 RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
-    constexpr int BK = 32, BKP = 36;               // 36-float row stride: conflict-free ds_read_b128
+    constexpr int ILV = VAR & 1;
+    constexpr bool TIMING = (VAR & 2) != 0;
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+#if defined(RY_HOST_EMU)
+#define RY_STAMP(i)
+#else
+#define RY_STAMP(i) if (TIMING) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); tph[i] += t_now - t_prev; t_prev = t_now; }
+    if (TIMING) t_prev = __builtin_amdgcn_s_memtime();
+#endif
+    constexpr int BKP = BK + 4;                    // +4-float row pad: conflict-free ds_read_b128
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int AR = BM / 32, BR = BN / 32;      // 16-byte loads per thread per K chunk
+    constexpr int TPR = BK / 4;                    // threads per row of a K chunk (16 bytes each)
+    constexpr int RSTEP = 256 / TPR;               // rows covered by one pass of the workgroup
+    constexpr int AR = BM / RSTEP, BR = BN / RSTEP; // 16-byte loads per thread per K chunk
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
     __shared__ __attribute__((aligned(16))) float As[BM * BKP];
     __shared__ __attribute__((aligned(16))) float Bs[BN * BKP];
@@ -107,22 +123,22 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     }
     __syncthreads();
 
-    const int c4 = (tid & 7) * 4;                  // float offset of this thread's 16 bytes in a K chunk
-    const int rbase = tid >> 3;                    // 0..31
+    const int c4 = (tid % TPR) * 4;                // float offset of this thread's 16 bytes in a K chunk
+    const int rbase = tid / TPR;                   // 0..RSTEP-1
     // Per-row state: base coordinates (for the padding test) and the element offset of the row's base pixel.
     // Offsets are 32-bit (the executor bounds every activation below 2^31 elements); a tap only adds a
     // workgroup-uniform delta, so the K loop does one vector add per row instead of 64-bit multiplies.
     int ayb[AR], axb[AR], aoff1[AR], aoff2[AR];
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
-        ayb[j] = rY[rbase + 32 * j]; axb[j] = rX[rbase + 32 * j];
-        const int pixb = rP[rbase + 32 * j] + ayb[j] * g.Wi + axb[j];     // may be "negative" on padded rows: never dereferenced
+        ayb[j] = rY[rbase + RSTEP * j]; axb[j] = rX[rbase + RSTEP * j];
+        const int pixb = rP[rbase + RSTEP * j] + ayb[j] * g.Wi + axb[j];     // may be "negative" on padded rows: never dereferenced
         aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + c4 : 0;
         aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + c4 : 0;
     }
     unsigned boff[BR];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) boff[j] = (unsigned)(((phase * g.N + n0 + rbase + 32 * j) * g.ntaps) * Ctot + c4);
+    for (int j = 0; j < BR; ++j) boff[j] = (unsigned)(((phase * g.N + n0 + rbase + RSTEP * j) * g.ntaps) * Ctot + c4);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -142,60 +158,316 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 
     f32x4 areg[AR], breg[BR];
     unsigned amask = 0;                            // bit j: row j of this thread's A loads is real data (not padding)
-    auto load_chunk = [&](int tap_, int cib_, int ky_, int kx_) {
-        amask = 0;
+    // chunk state of the loads in flight (workgroup-uniform)
+    const float* src = g.src1;
+    int delta = 0, dy = 0, dx = 0;
+    bool first = true;
+    unsigned bdelta = 0;
+    auto chunk_setup = [&](int tap_, int cib_, int ky_, int kx_) {
         const int ci0 = cib_ * BK;
-        const bool first = ci0 < g.C1;
-        const float* src = first ? g.src1 : g.src2;
+        first = ci0 < g.C1;
+        src = first ? g.src1 : g.src2;
         const int Cs = first ? g.C1 : g.C2;
         const int cil = first ? ci0 : ci0 - g.C1;
-        const int dy = subpix ? pdy - ky_ : ky_, dx = subpix ? pdx - kx_ : kx_;
-        const int delta = (dy * g.Wi + dx) * Cs + cil;          // workgroup-uniform (scalar unit)
-#pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            const int iy = ayb[j] + dy, ix = axb[j] + dx;
-            const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-            // zero padding / ragged rows: load a valid address and discard (no divergent control flow around the load)
-            const int off = ok ? (first ? aoff1[j] : aoff2[j]) + delta : c4;
-            areg[j] = ry_ld4(src + (unsigned)off);  // zeroed when it is written to LDS, so the wait sits after the MFMAs
-            amask |= ok ? (1u << j) : 0u;
-        }
-        const unsigned bdelta = (unsigned)(tap_ * Ctot + ci0);
-#pragma unroll
-        for (int j = 0; j < BR; ++j) breg[j] = ry_ld4(p.wt + (boff[j] + bdelta));
+        dy = subpix ? pdy - ky_ : ky_; dx = subpix ? pdx - kx_ : kx_;
+        delta = (dy * g.Wi + dx) * Cs + cil;                    // workgroup-uniform (scalar unit)
+        bdelta = (unsigned)(tap_ * Ctot + ci0);
+        amask = 0;
     };
+    auto load_a = [&](int j) {
+        const int iy = ayb[j] + dy, ix = axb[j] + dx;
+        const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+        // zero padding / ragged rows: load a valid address and discard (no divergent control flow around the load)
+        const int off = ok ? (first ? aoff1[j] : aoff2[j]) + delta : c4;
+        areg[j] = ry_ld4(src + (unsigned)off);      // zeroed when it is written to LDS, so the wait sits after the MFMAs
+        amask |= ok ? (1u << j) : 0u;
+    };
+    auto load_b = [&](int j) { breg[j] = ry_ld4(p.wt + (boff[j] + bdelta)); };
 
-    if (kc_begin < kc_end) load_chunk(tap, cib, ky, kx);
+    if (kc_begin < kc_end) {
+        chunk_setup(tap, cib, ky, kx);
+#pragma unroll
+        for (int j = 0; j < AR; ++j) load_a(j);
+#pragma unroll
+        for (int j = 0; j < BR; ++j) load_b(j);
+    }
+    constexpr int NS = BK / 8;                     // MFMA steps per chunk (8 K values each)
+    RY_STAMP(5)
     for (int kc = kc_begin; kc < kc_end; ++kc) {
         __syncthreads();                           // previous chunk's fragment reads are done
+        RY_STAMP(0)
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             f32x4 v = areg[j];
             if (!(amask & (1u << j))) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
-            ry_st4(&As[(rbase + 32 * j) * BKP + c4], v);
+            ry_st4(&As[(rbase + RSTEP * j) * BKP + c4], v);
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) ry_st4(&Bs[(rbase + 32 * j) * BKP + c4], breg[j]);
+        for (int j = 0; j < BR; ++j) ry_st4(&Bs[(rbase + RSTEP * j) * BKP + c4], breg[j]);
+        RY_STAMP(1)
         __syncthreads();
+        RY_STAMP(2)
         if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
-        if (kc + 1 < kc_end) load_chunk(tap, cib, ky, kx);  // global loads in flight under the MFMAs below
+        const bool more = kc + 1 < kc_end;
+        if (more) {
+            chunk_setup(tap, cib, ky, kx);
+            if (!ILV) {                            // global loads in flight under the MFMAs below
 #pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
+                for (int j = 0; j < AR; ++j) load_a(j);
+#pragma unroll
+                for (int j = 0; j < BR; ++j) load_b(j);
+            }
+        }
+        RY_STAMP(3)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
             f32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = ry_ld4(&As[((wm * TM + i) * 32 + lr) * BKP + s * 8 + lh * 4]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(&Bs[((wn * TN + j) * 32 + lr) * BKP + s * 8 + lh * 4]);
+            if (ILV && more) {                     // slice s of the next chunk's loads
+#pragma unroll
+                for (int j = 0; j < AR; ++j) if (j % NS == s) load_a(j);
+#pragma unroll
+                for (int j = 0; j < BR; ++j) if (j % NS == s) load_b(j);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
+#ifndef RY_HOST_EMU
+            if (ILV) __builtin_amdgcn_sched_barrier(0);       // keep the load slices where they are
+#endif
         }
+        RY_STAMP(4)
     }
 
     // epilogue: D[row=(r&3)+8*(r>>2)+4*lh][col=lr]; 32 lanes store 128 contiguous bytes of one pixel
+    float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + lr;
+        float sc = 1.f, sh = 0.f;
+        if (p.splits == 1) { sc = p.scale[n]; sh = p.shift[n]; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ob = rO[ml];
+                if (ob >= 0) {
+                    float v = acc[i][j][r];
+                    if (p.splits == 1) v = ry_act(fmaf(v, sc, sh), p.act, p.slope);
+                    outp[(size_t)ob * g.N + n] = v;
+                }
+            }
+        }
+    }
+    RY_STAMP(6)
+#if !defined(RY_HOST_EMU)
+    if (TIMING && p.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) atomicAdd(p.dbg + i, tph[i]);
+        atomicAdd(p.dbg + 7, 1ull);
+    }
+#endif
+#undef RY_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------
+// ry_igemm_f32_p -- software-pipelined form of ry_igemm_f32 (same math, same fragment maps, same epilogue).
+// The two-barrier loop of ry_igemm_f32 loses ~30% of every wave's time at its first barrier: the four waves of a
+// workgroup sit on four SIMDs, each sharing its MFMA pipe with other workgroups' waves, so they drift apart and
+// the fastest waits for the slowest twice per chunk (s_memtime phase stamps).  Here:
+//   * LDS is double-buffered: chunk k is read from buf[k&1] while chunk k+1 is written to buf[(k+1)&1]
+//     -> ONE barrier per chunk;
+//   * one staging register set: during iteration k the registers (chunk k+1, requested one iteration ago) are
+//     written to LDS in the first MFMA steps and immediately re-used for the global loads of chunk k+2 in the
+//     later steps, so loads have a whole iteration to land and LDS writes / load issue hide under the MFMAs;
+//   * MFMA fragments of step s+1 are read from LDS while step s computes.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+RY_KERNEL(256) void ry_igemm_f32_p(RyIgemmParams p) {
+    constexpr int BK = 32, BKP = 36, NS = BK / 8;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RSTEP = 32;
+    constexpr int AR = BM / RSTEP, BR = BN / RSTEP;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+    constexpr int ABUF = BM * BKP, BBUF = BN * BKP;
+    __shared__ __attribute__((aligned(16))) float As[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BBUF];
+    __shared__ int rY[BM], rX[BM], rP[BM], rO[BM];
+
+    const RyConvGeom& g = p.g;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = (int)blockIdx.x * BM;
+    const int n0 = (int)blockIdx.y * BN;
+    const int phase = (int)blockIdx.z / p.splits;
+    const int split = (int)blockIdx.z % p.splits;
+    const int Ctot = g.C1 + g.C2;
+    const int Mimg = g.Mh * g.Mw;
+    const int M = g.B * Mimg;
+    const bool subpix = g.ostride == 2;
+    const int pdy = subpix ? (phase >> 1) : 0, pdx = subpix ? (phase & 1) : 0;
+
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        int yb = -(1 << 20), xb = 0, pb = 0, ob = -1;
+        if (m < M) {
+            const int b = m / Mimg, rem = m - b * Mimg;
+            const int ry = rem / g.Mw, rx = rem - ry * g.Mw;
+            yb = ry * g.stride - g.pad;
+            xb = rx * g.stride - g.pad;
+            pb = b * g.Hi * g.Wi;
+            ob = (b * g.Ho + ry * g.ostride + pdy) * g.Wo + rx * g.ostride + pdx;
+        }
+        rY[r] = yb; rX[r] = xb; rP[r] = pb; rO[r] = ob;
+    }
+    __syncthreads();
+
+    const int c4 = (tid & 7) * 4;
+    const int rbase = tid >> 3;
+    int ayb[AR], axb[AR], aoff1[AR], aoff2[AR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+        ayb[j] = rY[rbase + RSTEP * j]; axb[j] = rX[rbase + RSTEP * j];
+        const int pixb = rP[rbase + RSTEP * j] + ayb[j] * g.Wi + axb[j];
+        aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + c4 : 0;
+        aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + c4 : 0;
+    }
+    unsigned boff[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) boff[j] = (unsigned)(((phase * g.N + n0 + rbase + RSTEP * j) * g.ntaps) * Ctot + c4);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int cpt = Ctot / BK;
+    const int nk = g.ntaps * cpt;
+    const int kc_begin = (int)(((long long)nk * split) / p.splits);
+    const int kc_end = (int)(((long long)nk * (split + 1)) / p.splits);
+    // walk state of the NEXT chunk to be requested from global memory
+    int tap = kc_begin / cpt;
+    int cib = kc_begin - tap * cpt;
+    int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
+
+    f32x4 areg[AR], breg[BR];
+    unsigned amask = 0, amask_next = 0;            // validity bits of the rows held in areg (and of the loads being issued)
+    const float* src = g.src1;
+    int delta = 0, dy = 0, dx = 0;
+    bool first = true;
+    unsigned bdelta = 0;
+    auto chunk_setup = [&]() {                     // scalars of the chunk (tap, cib); then advances the walk
+        const int ci0 = cib * BK;
+        first = ci0 < g.C1;
+        src = first ? g.src1 : g.src2;
+        const int Cs = first ? g.C1 : g.C2;
+        const int cil = first ? ci0 : ci0 - g.C1;
+        dy = subpix ? pdy - ky : ky; dx = subpix ? pdx - kx : kx;
+        delta = (dy * g.Wi + dx) * Cs + cil;
+        bdelta = (unsigned)(tap * Ctot + ci0);
+        amask_next = 0;
+        if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
+    };
+    auto load_a = [&](int j) {
+        const int iy = ayb[j] + dy, ix = axb[j] + dx;
+        const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+        const int off = ok ? (first ? aoff1[j] : aoff2[j]) + delta : c4;
+        areg[j] = ry_ld4(src + (unsigned)off);
+        amask_next |= ok ? (1u << j) : 0u;
+    };
+    auto load_b = [&](int j) { breg[j] = ry_ld4(p.wt + (boff[j] + bdelta)); };
+    auto store_a = [&](int j, int buf) {
+        f32x4 v = areg[j];
+        if (!(amask & (1u << j))) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+        ry_st4(&As[buf * ABUF + (rbase + RSTEP * j) * BKP + c4], v);
+    };
+    auto store_b = [&](int j, int buf) { ry_st4(&Bs[buf * BBUF + (rbase + RSTEP * j) * BKP + c4], breg[j]); };
+
+    const int nchunks = kc_end - kc_begin;
+    if (nchunks > 0) {                             // prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers
+        chunk_setup();
+#pragma unroll
+        for (int j = 0; j < AR; ++j) load_a(j);
+#pragma unroll
+        for (int j = 0; j < BR; ++j) load_b(j);
+        amask = amask_next;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) store_a(j, 0);
+#pragma unroll
+        for (int j = 0; j < BR; ++j) store_b(j, 0);
+        if (nchunks > 1) {
+            chunk_setup();
+#pragma unroll
+            for (int j = 0; j < AR; ++j) load_a(j);
+#pragma unroll
+            for (int j = 0; j < BR; ++j) load_b(j);
+            amask = amask_next;
+        }
+        __syncthreads();
+    }
+    for (int k = 0; k < nchunks; ++k) {
+        const int cur = k & 1;
+        const bool wr = k + 1 < nchunks;           // registers hold chunk k+1: write it to the other buffer
+        const bool ld = k + 2 < nchunks;           // then request chunk k+2 into the same registers
+        const float* Ab = &As[cur * ABUF + ((wm * TM) * 32 + lr) * BKP + lh * 4];
+        const float* Bb = &Bs[cur * BBUF + ((wn * TN) * 32 + lr) * BKP + lh * 4];
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = ry_ld4(Ab + i * 32 * BKP);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = ry_ld4(Bb + j * 32 * BKP);
+        if (ld) chunk_setup();                     // scalars of chunk k+2 (used by the load slices below)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + 1 < NS) {                      // fragments of the next step, one step ahead
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[(s + 1) & 1][i] = ry_ld4(Ab + i * 32 * BKP + (s + 1) * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[(s + 1) & 1][j] = ry_ld4(Bb + j * 32 * BKP + (s + 1) * 8);
+            }
+            // steps 0,1: LDS writes of chunk k+1 (A then B); steps 2,3: global loads of chunk k+2 (A then B)
+            if (s == 0 && wr) {
+#pragma unroll
+                for (int j = 0; j < AR; ++j) store_a(j, cur ^ 1);
+            }
+            if (s == 1 && wr) {
+#pragma unroll
+                for (int j = 0; j < BR; ++j) store_b(j, cur ^ 1);
+            }
+            if (s == 2 && ld) {
+#pragma unroll
+                for (int j = 0; j < AR; ++j) load_a(j);
+            }
+            if (s == 3 && ld) {
+#pragma unroll
+                for (int j = 0; j < BR; ++j) load_b(j);
+                amask = amask_next;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[s & 1][i][t], bf[s & 1][j][t], acc[i][j]);
+#ifndef RY_HOST_EMU
+            __builtin_amdgcn_sched_barrier(0);     // keep each step's LDS / global work where it was placed
+#endif
+        }
+        __syncthreads();                           // buf[cur^1] complete and buf[cur] free: the only barrier of the chunk
+    }
+
     float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {

@@ -457,6 +457,11 @@ static const char* tile_name(int tile) {
     }
 }
 
+static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
+static int g_pipe = 1;     // RY_PIPE=0: two-barrier ry_igemm_f32 instead of the pipelined ry_igemm_f32_p
+static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
+static unsigned long long* g_dbg = nullptr;
+static int g_bk64 = 0;     // RY_BK=64: 64-deep K chunks for the 128x128 tile when every channel count is a multiple of 64
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
 // choose tile + split-K for one stage-2 layer
@@ -505,13 +510,26 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         int bm, bn; tile_dims(lp.tile, &bm, &bn);
         dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)(l.cout / bn), (unsigned)(g.nphases * lp.splits));
         RY_TRY(Lc.begin(tile_name(lp.tile), l.name, lp.flops, lp.bytes, grid));
+        p.dbg = g_dbg;
+        const bool bk64 = g_bk64 && lp.tile == TILE_128x128 && C1 % 64 == 0 && C2 % 64 == 0;
+#define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
+    do {                                                                                                    \
+        if (g_pipe && BK_ == 32 && !g_timing) RY_LAUNCH((ry_igemm_f32_p<BM_, BN_, WM_, WN_>), grid, 256, Lc.stream, p); \
+        else if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
+        else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
+        else RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 0>), grid, 256, Lc.stream, p);               \
+    } while (0)
         switch (lp.tile) {
-            case TILE_128x128: RY_LAUNCH((ry_igemm_f32<128, 128, 2, 2>), grid, 256, Lc.stream, p); break;
-            case TILE_256x64: RY_LAUNCH((ry_igemm_f32<256, 64, 4, 1>), grid, 256, Lc.stream, p); break;
-            case TILE_64x128: RY_LAUNCH((ry_igemm_f32<64, 128, 1, 4>), grid, 256, Lc.stream, p); break;
-            case TILE_128x64: RY_LAUNCH((ry_igemm_f32<128, 64, 4, 1>), grid, 256, Lc.stream, p); break;
-            default: RY_LAUNCH((ry_igemm_f32<32, 128, 1, 4>), grid, 256, Lc.stream, p); break;
+            case TILE_128x128:
+                if (bk64) RY_IGEMM_LAUNCH(128, 128, 2, 2, 64);
+                else RY_IGEMM_LAUNCH(128, 128, 2, 2, 32);
+                break;
+            case TILE_256x64: RY_IGEMM_LAUNCH(256, 64, 4, 1, 32); break;
+            case TILE_64x128: RY_IGEMM_LAUNCH(64, 128, 1, 4, 32); break;
+            case TILE_128x64: RY_IGEMM_LAUNCH(128, 64, 4, 1, 32); break;
+            default: RY_IGEMM_LAUNCH(32, 128, 1, 4, 32); break;
         }
+#undef RY_IGEMM_LAUNCH
         RY_TRY(Lc.end());
         if (lp.splits > 1) {
             RyReduceParams r;
@@ -935,6 +953,16 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
     if (net->desc.bn_eps <= 0.f) net->desc.bn_eps = 2e-5f;
     net->layers = build_topology(*desc);
     if (const char* e = getenv("RY_GRAPH")) net->use_graph = atoi(e) != 0;
+    if (const char* e = getenv("RY_ILV")) g_ilv = atoi(e);
+    if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
+    if (const char* e = getenv("RY_PIPE")) g_pipe = atoi(e);
+#ifndef RY_HOST_EMU
+    if (g_timing && !g_dbg) {
+        RT_TRY(hipMalloc((void**)&g_dbg, 8 * sizeof(unsigned long long)));
+        RT_TRY(hipMemset(g_dbg, 0, 8 * sizeof(unsigned long long)));
+    }
+#endif
+    if (const char* e = getenv("RY_BK")) g_bk64 = atoi(e) == 64;
     if (const char* e = getenv("RY_TILE64")) g_tile64 = atoi(e) == 256 ? TILE_256x64 : TILE_128x64;
     RT_TRY(rt::stream_create(&net->stream));
     RT_TRY(rt::event_create(&net->done));
@@ -1030,6 +1058,20 @@ int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat*
         for (int k = 0; k < 3; ++k) stats[i].grid[k] = rec[i].grid[k];
     }
     *n_stats = n;
+    return RY_OK;
+}
+
+// diagnostics: read and reset the phase totals of the RY_TIMING=1 kernel variant (8 counters)
+int ry_debug_igemm_phases(ry_ctx* ctx, unsigned long long* out8) {
+    if (!ctx || !out8) return fail(RY_EINVAL, "null argument");
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+#ifndef RY_HOST_EMU
+    if (g_dbg) {
+        RT_TRY(hipDeviceSynchronize());
+        RT_TRY(hipMemcpy(out8, g_dbg, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        RT_TRY(hipMemset(g_dbg, 0, 8 * sizeof(unsigned long long)));
+    }
+#endif
     return RY_OK;
 }
 
