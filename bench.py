@@ -46,8 +46,7 @@ def main():
     args = parse()
     import torch
     from realtime_yukarin_amd import engine, synth
-    from realtime_yukarin_amd.netspec import flops as net_flops, pad_frames, param_count
-    from realtime_yukarin_amd.weights import flatten_params
+    from realtime_yukarin_amd.netspec import flops as net_flops, pad_frames
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -71,22 +70,14 @@ def main():
     T = N + pad_frames(N)
     d1, d2 = synth.model_descs(args.model)
     # ---- weights: rank 0 builds the blobs, one RCCL broadcast each over xGMI, every rank adopts the device buffer
-    blobs = []
-    for d, seed in ((d1, synth.SEED_STAGE1), (d2, synth.SEED_STAGE2)):
-        n = param_count(d)
-        if rank == 0:
-            from realtime_yukarin_amd.weights import synthetic_params
-            t = torch.from_numpy(flatten_params(d, synthetic_params(d, seed))).to(dev)
-        else:
-            t = torch.empty(n, dtype=torch.float32, device=dev)
-        if dist is not None:
-            dist.broadcast(t, src=0)
-        blobs.append(t)
-    torch.cuda.synchronize()
+    from realtime_yukarin_amd import dist as rdist
+    from realtime_yukarin_amd.weights import synthetic_params
     ctx = engine.get_context(local_rank)
-    net1 = engine.Net(ctx, d1, (blobs[0].data_ptr(), blobs[0].numel()))
-    net2 = engine.Net(ctx, d2, (blobs[1].data_ptr(), blobs[1].numel()), width=synth.FFT_BINS - 1)
-    del blobs
+    P1 = synthetic_params(d1, synth.SEED_STAGE1) if rank == 0 else None
+    P2 = synthetic_params(d2, synth.SEED_STAGE2) if rank == 0 else None
+    net1 = rdist.make_net(ctx, d1, rdist.broadcast_blob(d1, P1, dev))
+    net2 = rdist.make_net(ctx, d2, rdist.broadcast_blob(d2, P2, dev), width=synth.FFT_BINS - 1)
+    del P1, P2
 
     # ---- synthetic windows, resident in HBM before the timed region (different data per rank)
     x1 = torch.from_numpy(synth.stage1_input(N, Wn, seed=synth.SEED_INPUT + 10 * rank)).to(dev)

@@ -458,7 +458,7 @@ static const char* tile_name(int tile) {
 }
 
 static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
-static int g_pipe = 1;     // RY_PIPE=0: two-barrier ry_igemm_f32 instead of the pipelined ry_igemm_f32_p
+static int g_pipe = 0;     // RY_PIPE=1: pipelined one-barrier ry_igemm_f32_p (measured 96 TF vs 105 TF for the default; kept for A/B)
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
 static unsigned long long* g_dbg = nullptr;
 static int g_bk64 = 0;     // RY_BK=64: 64-deep K chunks for the 128x128 tile when every channel count is a multiple of 64

@@ -1,0 +1,137 @@
+"""End-to-end drop-in check of the hot-path entry on CPU (emulator build of the kernels):
+`VoiceChanger.convert_from_acoustic_feature` driven through the `yukarin` / `become_yukarin` shims, with model files
+written to disk in the Chainer save_npz key layout + config.json, compared against the oracle CNNs composed with the
+same host steps.  Runs the reference's OWN VoiceChanger class when /root/reference is mounted, and always the
+host-side mirror `realtime_yukarin_amd.voice_changer.VoiceChanger`."""
+import importlib
+import json
+import pickle
+import sys
+from pathlib import Path
+
+import numpy
+import pytest
+
+from oracle import unet
+from realtime_yukarin_amd import compat, engine, sptk
+from realtime_yukarin_amd.netspec import NetDesc
+from realtime_yukarin_amd.weights import save_npz, synthetic_params
+
+compat.install()
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path('/root/reference')
+FS, FRAME_PERIOD, N = 16000, 5, 60
+
+
+@pytest.fixture(scope='module')
+def models(tmp_path_factory):
+    d = tmp_path_factory.mktemp('models')
+    d1, d2 = NetDesc(1, 9, 9, 8, 8), NetDesc(2, 1, 1, 8, 8)
+    P1, P2 = synthetic_params(d1, 11, bias_std=0.05), synthetic_params(d2, 12, bias_std=0.02)
+    P1n = dict(P1); P1n['encoder/c1/batchnorm/N'] = numpy.array(7)          # Chainer also stores the BN sample counter
+    save_npz(d / 's1.npz', P1n)
+    save_npz(d / 's2.npz', P2)
+    (d / 's1.json').write_text(json.dumps({
+        'dataset': {'acoustic_param': {'sampling_rate': FS, 'frame_period': FRAME_PERIOD, 'order': 8, 'alpha': 0.41, 'unknown_key': 1},
+                    'in_features': ['mc'], 'out_features': ['mc'], 'input_glob': 'x'},
+        'model': {'in_channels': 9, 'out_channels': 9, 'generator_base_channels': 8, 'generator_extensive_layers': 8,
+                  'discriminator_base_channels': 1}, 'loss': {}, 'train': {}}))
+    (d / 's2.json').write_text(json.dumps({
+        'dataset': {'param': {'voice_param': {'sample_rate': FS}, 'acoustic_feature_param': {'frame_period': FRAME_PERIOD, 'order': 8}}},
+        'model': {'generator_base_channels': 8, 'generator_extensive_layers': 8}}))
+    numpy.save(str(d / 'in_stat.npy'), {'mean': numpy.log(200.0), 'var': 0.04})
+    numpy.save(str(d / 'tg_stat.npy'), {'mean': numpy.log(300.0), 'var': 0.09})
+    return d, (d1, P1), (d2, P2)
+
+
+@pytest.fixture()
+def on_emulator(emu_ctx, monkeypatch):
+    """Route the shims' lazily created context to the emulator build (tests only; the product never does this)."""
+    monkeypatch.setattr(engine, 'get_context', lambda device=0, lib=None: emu_ctx)
+    return emu_ctx
+
+
+def make_input(rng):
+    from yukarin import Wave
+    wave = (0.1 * rng.normal(size=N * FS * FRAME_PERIOD // 1000)).astype(numpy.float32)
+    wave[10 * 80:40 * 80] = 0.0                                                 # a silent stretch -> separate_effective drops frames
+    f0 = numpy.where(rng.random((N, 1)) < 0.3, 0.0, rng.lognormal(numpy.log(220.0), 0.2, (N, 1))).astype(numpy.float32)
+    feat = dict(f0=f0, ap=rng.uniform(0.001, 0.999, (N, 513)).astype(numpy.float32),
+                mc=(rng.normal(size=(N, 9)) * [4, 1, .5, .5, .3, .3, .2, .2, .2]).astype(numpy.float32), voiced=f0 > 0)
+    return Wave(wave=wave, sampling_rate=FS), feat
+
+
+def build_converters(models):
+    from become_yukarin import SuperResolution
+    from become_yukarin.config.sr_config import create_from_json as create_sr_config
+    from yukarin import AcousticConverter
+    from yukarin.config import create_from_json as create_config
+    from yukarin.f0_converter import F0Converter
+    d = models[0]
+    f0c = F0Converter(input_statistics=d / 'in_stat.npy', target_statistics=d / 'tg_stat.npy')
+    ac = AcousticConverter(create_config(d / 's1.json'), d / 's1.npz', f0_converter=f0c, out_sampling_rate=FS)
+    sr = SuperResolution(create_sr_config(d / 's2.json'), d / 's2.npz')
+    return ac, sr
+
+
+def expected(models, ac, wave, feat):
+    """Oracle CNNs + the same host glue, written out step by step (voice_changer.py:24-42)."""
+    (_, P1), (_, P2) = models[1], models[2]
+    eff = wave.get_effective_frame(threshold_db=60, fft_length=1024, frame_period=FRAME_PERIOD)[:N]
+    mc = numpy.zeros((N, 9), numpy.float32)
+    mc[eff] = unet.stage1_convert_core(feat['mc'][eff], P1)
+    f0 = numpy.zeros((N, 1), numpy.float32)
+    f0[eff] = ac.f0_converter.convert(feat['f0'][eff])
+    sp = sptk.mc2sp(mc, alpha=sptk.mcepalpha(FS), fftlen=1024) + 1e-16
+    return dict(f0=f0, mc=mc, sp=unet.stage2_convert(sp.astype(numpy.float32), P2), eff=eff)
+
+
+def check(out, exp, feat):
+    assert out.sp.shape == (N, 513) and out.sp.dtype == numpy.float32
+    assert float(numpy.abs(out.sp / exp['sp'] - 1).max()) < 1e-4
+    assert float(numpy.abs(out.mc - exp['mc']).max() / numpy.abs(exp['mc']).max()) < 1e-4
+    assert numpy.allclose(out.f0, exp['f0'], rtol=1e-6)
+    assert numpy.array_equal(out.ap[exp['eff']], feat['ap'][exp['eff']]) and not out.ap[~exp['eff']].any()
+    assert 0 < exp['eff'].sum() < N
+
+
+def test_mirror_voice_changer_end_to_end(models, on_emulator):
+    from realtime_yukarin_amd.voice_changer import VoiceChanger
+    from yukarin import AcousticFeature
+    ac, sr = build_converters(models)
+    ac = pickle.loads(pickle.dumps(ac)); sr = pickle.loads(pickle.dumps(sr))     # run.py ships them to a child Process
+    wave, feat = make_input(numpy.random.default_rng(21))
+
+    class Wrapped(AcousticFeature):                                              # AcousticFeatureWrapper equivalent
+        pass
+    f_in = Wrapped(**{k: v.copy() for k, v in feat.items()}); f_in.wave = wave
+    vc = VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60)
+    assert vc.output_sampling_rate == FS
+    out = vc.convert_from_acoustic_feature(f_in)
+    check(out, expected(models, ac, wave, feat), feat)
+    # two windows in one batched stage-2 call give the same answer
+    f_a = Wrapped(**{k: v.copy() for k, v in feat.items()}); f_a.wave = wave
+    f_b = Wrapped(**{k: v.copy() for k, v in feat.items()}); f_b.wave = wave
+    both = vc.convert_windows([f_a, f_b])
+    assert numpy.allclose(both[0].sp, out.sp, rtol=1e-6) and numpy.allclose(both[1].sp, out.sp, rtol=1e-6)
+
+
+@pytest.mark.skipif(not REF.exists(), reason='/root/reference is not mounted here')
+def test_reference_voice_changer_and_convert_stream_run_unchanged_on_the_shims(models, on_emulator, monkeypatch):
+    for p in (str(ROOT / 'tests' / 'stubs'), str(REF)):
+        monkeypatch.syspath_prepend(p)
+    vc_mod = importlib.import_module('realtime_voice_conversion.yukarin_wrapper.voice_changer')
+    cs_mod = importlib.import_module('realtime_voice_conversion.stream.convert_stream')
+    ac, sr = build_converters(models)
+    wave, feat = make_input(numpy.random.default_rng(21))
+    f_in = vc_mod.AcousticFeatureWrapper(wave=wave, **{k: v.copy() for k, v in feat.items()})
+    vc = vc_mod.VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60)
+    out = vc.convert_from_acoustic_feature(f_in)
+    check(out, expected(models, ac, wave, feat), feat)
+    # ... and the reference's ConvertStream drives it with overlap windows (time 0.3 s = 60 frames, no extra)
+    stream = cs_mod.ConvertStream(voice_changer=vc)
+    stream.add(start_time=0, data=vc_mod.AcousticFeatureWrapper(wave=wave, **{k: v.copy() for k, v in feat.items()}))
+    got = stream.process(start_time=0, time_length=0.3, extra_time=0)
+    assert numpy.allclose(got.sp, out.sp, rtol=1e-6)
+    for m in [k for k in sys.modules if k.startswith('realtime_voice_conversion')]:
+        sys.modules.pop(m)
