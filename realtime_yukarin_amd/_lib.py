@@ -18,7 +18,7 @@ DEFAULT_LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GLU = 0, 1, 2, 3
 ACTS = {None: ACT_NONE, 'none': ACT_NONE, 'lrelu': ACT_LRELU, 'relu': ACT_RELU, 'glu': ACT_GLU}
 PATH_AUTO, PATH_IGEMM, PATH_DIRECT = 0, 1, 2
-TILES = {None: 0, 'auto': 0, '128x128': 1, '256x64': 2, '64x128': 3, '32x128': 4, '128x64': 5}
+TILES = {None: 0, 'auto': 0, '128x128': 1, '256x64': 2, '64x128': 3, '32x128': 4, '128x64': 5, '96x128': 6}
 
 # every symbol include/ry355.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (

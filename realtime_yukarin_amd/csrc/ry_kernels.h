@@ -62,6 +62,7 @@ struct RyIgemmParams {
     int act;
     float slope;
     long long slab_stride;
+    int mtiles, ntiles;         // 1-D XCD-aware grid: logical id = ((split*mtiles + mt)*ntiles + nt)*nphases + phase
     unsigned long long* dbg;    // VAR bit 1 (diagnostic build of the kernel): per-phase shader-clock totals, else unused
 };
 
@@ -95,10 +96,18 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
-    const int m0 = (int)blockIdx.x * BM;
-    const int n0 = (int)blockIdx.y * BN;
-    const int phase = (int)blockIdx.z / p.splits;
-    const int split = (int)blockIdx.z % p.splits;
+    // XCD-aware 1-D grid: block b runs on XCD b % 8 (observed dispatch rule, speed only); give each XCD a contiguous
+    // range of logical ids so the phases / N-tiles / neighbouring M-tiles that re-read the same input pixels share one L2
+    const int total_tiles = p.splits * p.mtiles * p.ntiles * p.g.nphases;
+    const int per_xcd = (total_tiles + 7) >> 3;
+    int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (lid >= total_tiles) return;
+    const int phase = lid % p.g.nphases; lid /= p.g.nphases;
+    const int nt = lid % p.ntiles; lid /= p.ntiles;
+    const int mt = lid % p.mtiles;
+    const int split = lid / p.mtiles;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
     const int Ctot = g.C1 + g.C2;
     const int Mimg = g.Mh * g.Mw;
     const int M = g.B * Mimg;
@@ -306,10 +315,18 @@ RY_KERNEL(256) void ry_igemm_f32_p(RyIgemmParams p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
-    const int m0 = (int)blockIdx.x * BM;
-    const int n0 = (int)blockIdx.y * BN;
-    const int phase = (int)blockIdx.z / p.splits;
-    const int split = (int)blockIdx.z % p.splits;
+    // XCD-aware 1-D grid: block b runs on XCD b % 8 (observed dispatch rule, speed only); give each XCD a contiguous
+    // range of logical ids so the phases / N-tiles / neighbouring M-tiles that re-read the same input pixels share one L2
+    const int total_tiles = p.splits * p.mtiles * p.ntiles * p.g.nphases;
+    const int per_xcd = (total_tiles + 7) >> 3;
+    int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (lid >= total_tiles) return;
+    const int phase = lid % p.g.nphases; lid /= p.g.nphases;
+    const int nt = lid % p.ntiles; lid /= p.ntiles;
+    const int mt = lid % p.mtiles;
+    const int split = lid / p.mtiles;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
     const int Ctot = g.C1 + g.C2;
     const int Mimg = g.Mh * g.Mw;
     const int M = g.B * Mimg;

@@ -308,7 +308,7 @@ static bool igemm_eligible(const Layer& l) {
 // per-layer launch plans
 // ------------------------------------------------------------------------------------------------
 enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4 };
-enum { TILE_128x128 = 1, TILE_256x64 = 2, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5 };
+enum { TILE_128x128 = 1, TILE_256x64 = 2, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5, TILE_96x128 = 6 };
 
 struct LayerPlan {
     // geometry
@@ -443,6 +443,7 @@ static void tile_dims(int tile, int* bm, int* bn) {
         case TILE_256x64: *bm = 256; *bn = 64; break;
         case TILE_64x128: *bm = 64; *bn = 128; break;
         case TILE_128x64: *bm = 128; *bn = 64; break;
+        case TILE_96x128: *bm = 96; *bn = 128; break;
         default: *bm = 32; *bn = 128; break;
     }
 }
@@ -453,6 +454,7 @@ static const char* tile_name(int tile) {
         case TILE_256x64: return "ry_igemm_f32<256,64>";
         case TILE_64x128: return "ry_igemm_f32<64,128>";
         case TILE_128x64: return "ry_igemm_f32<128,64>";
+        case TILE_96x128: return "ry_igemm_f32<96,128>";
         default: return "ry_igemm_f32<32,128>";
     }
 }
@@ -465,35 +467,52 @@ static int g_bk64 = 0;     // RY_BK=64: 64-deep K chunks for the 128x128 tile wh
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
 // choose tile + split-K for one stage-2 layer
-static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits) {
-    int t;
-    if (l.cout % 128 != 0) t = g_tile64;
-    else if (M >= 1024) t = TILE_128x128;
-    else if (M > 32) t = TILE_64x128;
-    else t = TILE_32x128;
-    if (*tile == 0) *tile = t;
-    int bm, bn; tile_dims(*tile, &bm, &bn);
-    if (*splits == 0) {
-        // MFMA-bound: every CU should get the same number of workgroups, so pick the split count whose grid is
-        // closest to a whole number of waves over the 256 CUs (>= 2 workgroups per CU, >= 4 K-chunks per split)
-        const long blocks = (long)((M + bm - 1) / bm) * (l.cout / bn) * nphases;
-        int best = 1; double best_eff = -1.0;
-        const bool tinyM = M <= 64;                               // pure weight streaming: latency-bound per workgroup
-        const int smax = tinyM ? 128 : 32;
-        const int min_chunks = tinyM ? 2 : 4;
-        for (int s = 1; s <= smax && s <= (nk >= min_chunks ? nk / min_chunks : 1); ++s) {
-            const long g = blocks * s;
-            const long rounds = (g + 255) / 256;
-            double eff = (double)g / (double)(rounds * 256);
-            if (tinyM) eff = g >= 1024 ? 1.0 - 1e-4 * s : (double)g / 1024.0;   // fill the chip with loads in flight
-            else {
-                if (rounds < 2) eff *= 0.5 * rounds + 0.25;      // a single thin wave cannot hide its own barriers
-                eff -= 0.004 * (s - 1);                           // each extra split adds slab traffic + a reduce pass
-            }
-            if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
-        }
-        *splits = best;
+// efficiency of running `blocks` workgroups of one launch on 256 CUs with split-K `s`
+static double grid_eff(long blocks, int s, bool tinyM) {
+    const long g = blocks * s;
+    const long rounds = (g + 255) / 256;
+    double eff = (double)g / (double)(rounds * 256);
+    if (tinyM) return g >= 1024 ? 1.0 - 1e-4 * s : (double)g / 1024.0;   // weight streaming: fill the chip with loads in flight
+    if (rounds < 2) eff *= 0.5 * rounds + 0.25;                            // a single thin wave cannot hide its own barriers
+    if (s > 1) eff -= 0.10 + 0.004 * (s - 1);                              // split-K: slab writes at the tail + a reduce pass (~10 % measured)
+    return eff;
+}
+
+static int best_split(long blocks, int nk, bool tinyM, double* eff_out) {
+    const int smax = tinyM ? 128 : 32, min_chunks = tinyM ? 2 : 4;
+    int best = 1; double be = -1.0;
+    for (int s = 1; s <= smax && s <= (nk >= min_chunks ? nk / min_chunks : 1); ++s) {
+        const double e = grid_eff(blocks, s, tinyM);
+        if (e > be + 1e-9) { be = e; best = s; }
     }
+    if (eff_out) *eff_out = be;
+    return best;
+}
+
+static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits) {
+    // MFMA-bound layers: every CU should get the same number of workgroups.  Candidate M-tiles 128 / 96 / 64 (N-tile 128)
+    // are scored by (row utilisation) x (grid balance over 256 CUs, with the best split-K for that tile).
+    if (*tile == 0) {
+        if (l.cout % 128 != 0) *tile = g_tile64;
+        else if (M <= 32) *tile = TILE_32x128;
+        else if (M <= 64) *tile = TILE_64x128;
+        else {
+            const int cand[3] = {TILE_128x128, TILE_96x128, TILE_64x128};
+            const double bias[3] = {0.0, -0.02, -0.08};                   // smaller tiles re-read more B per flop
+            double be = -1.0; int bt = TILE_128x128;
+            for (int c = 0; c < 3; ++c) {
+                int bm, bn; tile_dims(cand[c], &bm, &bn);
+                const long mt = (M + bm - 1) / bm;
+                double e = 0.0;
+                best_split(mt * (l.cout / bn) * nphases, nk, false, &e);
+                e = e * ((double)M / (double)(mt * bm)) + bias[c];
+                if (e > be + 1e-9) { be = e; bt = cand[c]; }
+            }
+            *tile = bt;
+        }
+    }
+    int bm, bn; tile_dims(*tile, &bm, &bn);
+    if (*splits == 0) *splits = best_split((long)((M + bm - 1) / bm) * (l.cout / bn) * nphases, nk, M <= 64, nullptr);
     if (*splits > nk) *splits = nk;
 }
 
@@ -508,7 +527,9 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         p.slab_stride = (long long)B * lp.Ho * lp.Wo * l.cout;
         p.out = lp.splits > 1 ? lp.slabs : lp.out;
         int bm, bn; tile_dims(lp.tile, &bm, &bn);
-        dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)(l.cout / bn), (unsigned)(g.nphases * lp.splits));
+        p.mtiles = (M + bm - 1) / bm; p.ntiles = l.cout / bn;
+        const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
+        dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
         RY_TRY(Lc.begin(tile_name(lp.tile), l.name, lp.flops, lp.bytes, grid));
         p.dbg = g_dbg;
         const bool bk64 = g_bk64 && lp.tile == TILE_128x128 && C1 % 64 == 0 && C2 % 64 == 0;
@@ -527,6 +548,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             case TILE_256x64: RY_IGEMM_LAUNCH(256, 64, 4, 1, 32); break;
             case TILE_64x128: RY_IGEMM_LAUNCH(64, 128, 1, 4, 32); break;
             case TILE_128x64: RY_IGEMM_LAUNCH(128, 64, 4, 1, 32); break;
+            case TILE_96x128: RY_IGEMM_LAUNCH(96, 128, 1, 4, 32); break;
             default: RY_IGEMM_LAUNCH(32, 128, 1, 4, 32); break;
         }
 #undef RY_IGEMM_LAUNCH
@@ -1155,6 +1177,7 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
         const TapTable t = make_taps(l);
         const int M = B * (transposed ? H * Wd : lp.Ho * lp.Wo);
         lp.tile = tile; lp.splits = splits;
+        if (tile < 0 || tile > TILE_96x128) return fail(RY_EINVAL, "unknown tile");
         if ((tile == TILE_256x64 || tile == TILE_128x64) ? Cout % 64 : (tile != 0 && Cout % 128)) return fail(RY_EINVAL, "tile does not divide Cout");
         choose_igemm(l, M, t.nphases, t.ntaps * (Cin / 32), &lp.tile, &lp.splits);
         if (lp.splits > 1) RY_TRY(arena.alloc(&lp.slabs, out_elems * lp.splits));

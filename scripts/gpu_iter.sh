@@ -7,8 +7,8 @@ show() { python -c "
 import json,sys; d=json.load(open(sys.argv[1])); print({k:d[k] for k in ('value','ms_per_step','x_realtime','stage_ms')}); print(d.get('roofline')); print(d.get('roofline_stage1')); print(d['kernels'])" $1; }
 timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --layers-out gpurun_out/layers_n300.txt > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?"
 show gpurun_out/bench.json
-RY_TILE64=256 timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --layers-out gpurun_out/layers_n300_t256x64.txt > gpurun_out/bench_t256x64.json 2>> gpurun_out/bench.err
-echo "--- RY_TILE64=256"; show gpurun_out/bench_t256x64.json
+true
+true
 timeout 300 python bench.py --steps 50 --warmup 5 --frames 100 --no-cpu-baseline --layers-out gpurun_out/layers_n100.txt > gpurun_out/bench_n100.json 2>> gpurun_out/bench.err
 echo "--- N=100"; show gpurun_out/bench_n100.json
 cat gpurun_out/layers_n300.txt
