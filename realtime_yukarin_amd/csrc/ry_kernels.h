@@ -54,7 +54,7 @@ struct RyConvGeom {
 
 struct RyIgemmParams {
     RyConvGeom g;
-    const float* wt;            // [phase][N][tap][C1+C2]
+    const float* wt;            // [phase][N/64][tap][(C1+C2)/32][64][32]: every (64 couts x 32 k) chunk is one contiguous 8 KB block
     const float* scale;         // [N] folded BN scale (1 when no BN)
     const float* shift;         // [N] folded bias/BN shift
     float* out;                 // splits==1: NHWC output; else slabs [split][B*Ho*Wo][N] of raw sums
@@ -63,6 +63,8 @@ struct RyIgemmParams {
     float slope;
     long long slab_stride;
     int mtiles, ntiles;         // 1-D XCD-aware grid: logical id = ((split*mtiles + mt)*ntiles + nt)*nphases + phase
+    int tw;                     // > 0: an M-tile is a 2-D block of (BM/tw) x tw rows of the Mh x Mw grid (compact input footprint:
+                                //      overlapping taps hit L2); 0: BM consecutive rows in raster order
     unsigned long long* dbg;    // VAR bit 1 (diagnostic build of the kernel): per-phase shader-clock totals, else unused
 };
 
@@ -74,6 +76,7 @@ template <int BM, int BN, int WM, int WN, int BK, int VAR>
 RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     constexpr int ILV = VAR & 1;
     constexpr bool TIMING = (VAR & 2) != 0;
+    constexpr bool FPRE = (VAR & 4) != 0;          // MFMA fragments of step s+1 are read from LDS while step s computes
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
 #if defined(RY_HOST_EMU)
 #define RY_STAMP(i)
@@ -81,6 +84,7 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 #define RY_STAMP(i) if (TIMING) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); tph[i] += t_now - t_prev; t_prev = t_now; }
     if (TIMING) t_prev = __builtin_amdgcn_s_memtime();
 #endif
+    static_assert(BK == 32, "the filter layout is blocked in 32-deep K chunks");
     constexpr int BKP = BK + 4;                    // +4-float row pad: conflict-free ds_read_b128
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int TPR = BK / 4;                    // threads per row of a K chunk (16 bytes each)
@@ -120,9 +124,19 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
         int yb = -(1 << 20), xb = 0, pb = 0, ob = -1;
-        if (m < M) {
-            const int b = m / Mimg, rem = m - b * Mimg;
-            const int ry = rem / g.Mw, rx = rem - ry * g.Mw;
+        bool live = m < M;
+        int b = 0, ry = 0, rx = 0;
+        if (p.tw > 0) {                            // 2-D tile: mt enumerates (image, tile row, tile column)
+            const int th = BM / p.tw, tcols = g.Mw / p.tw, trows = g.Mh / th;
+            const int tx = mt % tcols, ty = (mt / tcols) % trows;
+            b = mt / (tcols * trows);
+            ry = ty * th + r / p.tw; rx = tx * p.tw + r % p.tw;
+            live = b < g.B;
+        } else if (live) {
+            b = m / Mimg; const int rem = m - b * Mimg;
+            ry = rem / g.Mw; rx = rem - ry * g.Mw;
+        }
+        if (live) {
             yb = ry * g.stride - g.pad;
             xb = rx * g.stride - g.pad;
             pb = b * g.Hi * g.Wi;
@@ -147,7 +161,10 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     }
     unsigned boff[BR];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) boff[j] = (unsigned)(((phase * g.N + n0 + rbase + RSTEP * j) * g.ntaps) * Ctot + c4);
+    for (int j = 0; j < BR; ++j) {
+        const int n = n0 + rbase + RSTEP * j;
+        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * (Ctot >> 5)) * 2048 + (n & 63) * 32 + c4);
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -165,93 +182,125 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     int cib = kc_begin - tap * cpt;
     int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
 
-    f32x4 areg[AR], breg[BR];
-    unsigned amask = 0;                            // bit j: row j of this thread's A loads is real data (not padding)
-    // chunk state of the loads in flight (workgroup-uniform)
+    // Register staging, DEPTH chunks deep.  DEPTH = 2 (VAR bit 3): the loads issued while chunk k computes are those of
+    // chunk k+2, so they have a whole extra iteration to land (L2-missing im2col rows take 2-4 us under load, more than
+    // the MFMA phase of one chunk); costs one more register set.
+    constexpr int DEPTH = (VAR & 8) ? 2 : 1;
+    f32x4 areg[DEPTH][AR], breg[DEPTH][BR];
+    unsigned amask[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) amask[d] = 0;
+    // chunk state of the loads being issued (workgroup-uniform)
     const float* src = g.src1;
     int delta = 0, dy = 0, dx = 0;
     bool first = true;
     unsigned bdelta = 0;
-    auto chunk_setup = [&](int tap_, int cib_, int ky_, int kx_) {
-        const int ci0 = cib_ * BK;
+    auto chunk_setup = [&](int set) {              // scalars of the next chunk of the walk; then advances the walk
+        const int ci0 = cib * BK;
         first = ci0 < g.C1;
         src = first ? g.src1 : g.src2;
         const int Cs = first ? g.C1 : g.C2;
         const int cil = first ? ci0 : ci0 - g.C1;
-        dy = subpix ? pdy - ky_ : ky_; dx = subpix ? pdx - kx_ : kx_;
+        dy = subpix ? pdy - ky : ky; dx = subpix ? pdx - kx : kx;
         delta = (dy * g.Wi + dx) * Cs + cil;                    // workgroup-uniform (scalar unit)
-        bdelta = (unsigned)(tap_ * Ctot + ci0);
-        amask = 0;
+        bdelta = (unsigned)((tap * cpt + cib) * 2048);
+        amask[set] = 0;
+        if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
     };
-    auto load_a = [&](int j) {
+    auto load_a = [&](int set, int j) {
         const int iy = ayb[j] + dy, ix = axb[j] + dx;
         const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
         // zero padding / ragged rows: load a valid address and discard (no divergent control flow around the load)
         const int off = ok ? (first ? aoff1[j] : aoff2[j]) + delta : c4;
-        areg[j] = ry_ld4(src + (unsigned)off);      // zeroed when it is written to LDS, so the wait sits after the MFMAs
-        amask |= ok ? (1u << j) : 0u;
+        areg[set][j] = ry_ld4(src + (unsigned)off); // zeroed when it is written to LDS, so the wait sits after the MFMAs
+        amask[set] |= ok ? (1u << j) : 0u;
     };
-    auto load_b = [&](int j) { breg[j] = ry_ld4(p.wt + (boff[j] + bdelta)); };
+    auto load_b = [&](int set, int j) { breg[set][j] = ry_ld4(p.wt + (boff[j] + bdelta)); };
 
-    if (kc_begin < kc_end) {
-        chunk_setup(tap, cib, ky, kx);
+    const int nchunks = kc_end - kc_begin;
 #pragma unroll
-        for (int j = 0; j < AR; ++j) load_a(j);
+    for (int d = 0; d < DEPTH; ++d) {              // prologue: chunks 0 .. DEPTH-1 into the register sets
+        if (d < nchunks) {
+            chunk_setup(d);
 #pragma unroll
-        for (int j = 0; j < BR; ++j) load_b(j);
+            for (int j = 0; j < AR; ++j) load_a(d, j);
+#pragma unroll
+            for (int j = 0; j < BR; ++j) load_b(d, j);
+        }
     }
     constexpr int NS = BK / 8;                     // MFMA steps per chunk (8 K values each)
     RY_STAMP(5)
-    for (int kc = kc_begin; kc < kc_end; ++kc) {
+    // one iteration: registers of `set` (chunk k) -> LDS, then `set` is re-used for the loads of chunk k + DEPTH
+    auto iteration = [&](int k, int set) {
         __syncthreads();                           // previous chunk's fragment reads are done
         RY_STAMP(0)
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
-            f32x4 v = areg[j];
-            if (!(amask & (1u << j))) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+            f32x4 v = areg[set][j];
+            if (!(amask[set] & (1u << j))) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
             ry_st4(&As[(rbase + RSTEP * j) * BKP + c4], v);
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) ry_st4(&Bs[(rbase + RSTEP * j) * BKP + c4], breg[j]);
+        for (int j = 0; j < BR; ++j) ry_st4(&Bs[(rbase + RSTEP * j) * BKP + c4], breg[set][j]);
         RY_STAMP(1)
         __syncthreads();
         RY_STAMP(2)
-        if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
-        const bool more = kc + 1 < kc_end;
+        const bool more = k + DEPTH < nchunks;
         if (more) {
-            chunk_setup(tap, cib, ky, kx);
+            chunk_setup(set);
             if (!ILV) {                            // global loads in flight under the MFMAs below
 #pragma unroll
-                for (int j = 0; j < AR; ++j) load_a(j);
+                for (int j = 0; j < AR; ++j) load_a(set, j);
 #pragma unroll
-                for (int j = 0; j < BR; ++j) load_b(j);
+                for (int j = 0; j < BR; ++j) load_b(set, j);
             }
         }
         RY_STAMP(3)
+        f32x4 af[2][TM], bf[2][TN];
+        if (FPRE) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[0][i] = ry_ld4(&As[((wm * TM + i) * 32 + lr) * BKP + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[0][j] = ry_ld4(&Bs[((wn * TN + j) * 32 + lr) * BKP + lh * 4]);
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            f32x4 af[TM], bf[TN];
+            const int cb = FPRE ? (s & 1) : 0;
+            if (!FPRE) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = ry_ld4(&As[((wm * TM + i) * 32 + lr) * BKP + s * 8 + lh * 4]);
+                for (int i = 0; i < TM; ++i) af[0][i] = ry_ld4(&As[((wm * TM + i) * 32 + lr) * BKP + s * 8 + lh * 4]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(&Bs[((wn * TN + j) * 32 + lr) * BKP + s * 8 + lh * 4]);
-            if (ILV && more) {                     // slice s of the next chunk's loads
+                for (int j = 0; j < TN; ++j) bf[0][j] = ry_ld4(&Bs[((wn * TN + j) * 32 + lr) * BKP + s * 8 + lh * 4]);
+            } else if (s + 1 < NS) {
 #pragma unroll
-                for (int j = 0; j < AR; ++j) if (j % NS == s) load_a(j);
+                for (int i = 0; i < TM; ++i) af[cb ^ 1][i] = ry_ld4(&As[((wm * TM + i) * 32 + lr) * BKP + (s + 1) * 8 + lh * 4]);
 #pragma unroll
-                for (int j = 0; j < BR; ++j) if (j % NS == s) load_b(j);
+                for (int j = 0; j < TN; ++j) bf[cb ^ 1][j] = ry_ld4(&Bs[((wn * TN + j) * 32 + lr) * BKP + (s + 1) * 8 + lh * 4]);
+            }
+            if (ILV && more) {                     // slice s of the loads being issued
+#pragma unroll
+                for (int j = 0; j < AR; ++j) if (j % NS == s) load_a(set, j);
+#pragma unroll
+                for (int j = 0; j < BR; ++j) if (j % NS == s) load_b(set, j);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[cb][i][t], bf[cb][j][t], acc[i][j]);
 #ifndef RY_HOST_EMU
             if (ILV) __builtin_amdgcn_sched_barrier(0);       // keep the load slices where they are
 #endif
         }
         RY_STAMP(4)
+    };
+    if (DEPTH == 1) {
+        for (int k = 0; k < nchunks; ++k) iteration(k, 0);
+    } else {
+        int k = 0;
+        for (; k + 1 < nchunks; k += 2) { iteration(k, 0); iteration(k + 1, 1 % DEPTH); }
+        if (k < nchunks) iteration(k, 0);
     }
 
     // epilogue: D[row=(r&3)+8*(r>>2)+4*lh][col=lr]; 32 lanes store 128 contiguous bytes of one pixel
@@ -336,9 +385,19 @@ RY_KERNEL(256) void ry_igemm_f32_p(RyIgemmParams p) {
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
         int yb = -(1 << 20), xb = 0, pb = 0, ob = -1;
-        if (m < M) {
-            const int b = m / Mimg, rem = m - b * Mimg;
-            const int ry = rem / g.Mw, rx = rem - ry * g.Mw;
+        bool live = m < M;
+        int b = 0, ry = 0, rx = 0;
+        if (p.tw > 0) {                            // 2-D tile: mt enumerates (image, tile row, tile column)
+            const int th = BM / p.tw, tcols = g.Mw / p.tw, trows = g.Mh / th;
+            const int tx = mt % tcols, ty = (mt / tcols) % trows;
+            b = mt / (tcols * trows);
+            ry = ty * th + r / p.tw; rx = tx * p.tw + r % p.tw;
+            live = b < g.B;
+        } else if (live) {
+            b = m / Mimg; const int rem = m - b * Mimg;
+            ry = rem / g.Mw; rx = rem - ry * g.Mw;
+        }
+        if (live) {
             yb = ry * g.stride - g.pad;
             xb = rx * g.stride - g.pad;
             pb = b * g.Hi * g.Wi;
@@ -360,7 +419,10 @@ RY_KERNEL(256) void ry_igemm_f32_p(RyIgemmParams p) {
     }
     unsigned boff[BR];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) boff[j] = (unsigned)(((phase * g.N + n0 + rbase + RSTEP * j) * g.ntaps) * Ctot + c4);
+    for (int j = 0; j < BR; ++j) {
+        const int n = n0 + rbase + RSTEP * j;
+        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * (Ctot >> 5)) * 2048 + (n & 63) * 32 + c4);
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -393,7 +455,7 @@ RY_KERNEL(256) void ry_igemm_f32_p(RyIgemmParams p) {
         const int cil = first ? ci0 : ci0 - g.C1;
         dy = subpix ? pdy - ky : ky; dx = subpix ? pdx - kx : kx;
         delta = (dy * g.Wi + dx) * Cs + cil;
-        bdelta = (unsigned)(tap * Ctot + ci0);
+        bdelta = (unsigned)((tap * cpt + cib) * 2048);
         amask_next = 0;
         if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
     };

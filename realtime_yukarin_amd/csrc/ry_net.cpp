@@ -11,6 +11,9 @@
 // a plan per (batch, frames) owns all activation buffers, and the whole forward -- pad/log wrapper
 // kernels, 16 fused layers, exp/crop -- is captured once into a hipGraph and replayed per buffer.
 #include "ry_kernels.h"
+#ifndef RY_HOST_EMU
+int ry_dyn_lds_bytes = 0;
+#endif
 
 #include "../../include/ry355.h"
 
@@ -278,15 +281,20 @@ static float w2d_at(const Layer& l, const float* W, int n, int c, int ky, int kx
     return l.deconv ? W[(((size_t)c * N + n) * K + ky) * K + kx] : W[(((size_t)n * C + c) * K + ky) * K + kx];
 }
 
+// implicit-GEMM filters: [phase][N/64][tap][C/32][64 couts][32 k].  Each (64 x 32) chunk a workgroup stages per K step is
+// one contiguous 8 KB block: a wave's 16-byte lane loads cover 1 KB of consecutive addresses, and the rows of a B tile are
+// not spread at a power-of-two stride of 4-16 KB (which funnels every workgroup's B traffic into the same L2 channels).
 static void relayout_igemm(const Layer& l, const float* W, std::vector<float>& out) {
     const TapTable t = make_taps(l);
-    const int C = l.cin(), N = l.cout;
+    const int C = l.cin(), N = l.cout, cpt = C / 32;
     out.resize((size_t)t.nphases * N * t.ntaps * C);
     for (int ph = 0; ph < t.nphases; ++ph)
         for (int n = 0; n < N; ++n)
             for (int tt = 0; tt < t.ntaps; ++tt)
-                for (int c = 0; c < C; ++c)
-                    out[(((size_t)ph * N + n) * t.ntaps + tt) * C + c] = w2d_at(l, W, n, c, t.ky[ph][tt], t.kx[ph][tt]);
+                for (int c = 0; c < C; ++c) {
+                    const size_t blk = (((size_t)ph * (N / 64) + n / 64) * t.ntaps + tt) * cpt + c / 32;
+                    out[(blk * 64 + n % 64) * 32 + c % 32] = w2d_at(l, W, n, c, t.ky[ph][tt], t.kx[ph][tt]);
+                }
 }
 
 static void relayout_direct(const Layer& l, const float* W, std::vector<float>& out) {
@@ -461,9 +469,11 @@ static const char* tile_name(int tile) {
 
 static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
 static int g_pipe = 0;     // RY_PIPE=1: pipelined one-barrier ry_igemm_f32_p (measured 96 TF vs 105 TF for the default; kept for A/B)
+static int g_deep = 0;     // RY_DEEP=1: two-chunk-deep register prefetch variant of ry_igemm_f32 (VAR bit 3)
+static int g_fpre = 0;     // RY_FPRE=1: fragment prefetch variant of ry_igemm_f32 (VAR bit 2)
+static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
 static unsigned long long* g_dbg = nullptr;
-static int g_bk64 = 0;     // RY_BK=64: 64-deep K chunks for the 128x128 tile when every channel count is a multiple of 64
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
 // choose tile + split-K for one stage-2 layer
@@ -528,22 +538,28 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         p.out = lp.splits > 1 ? lp.slabs : lp.out;
         int bm, bn; tile_dims(lp.tile, &bm, &bn);
         p.mtiles = (M + bm - 1) / bm; p.ntiles = l.cout / bn;
+        p.tw = 0;
+        if (g_tile2d) {                               // 2-D M-tiles when the row grid divides evenly
+            for (int tw = 16; tw >= 4; tw >>= 1) {
+                if (bm % tw == 0 && g.Mw % tw == 0 && g.Mh % (bm / tw) == 0) { p.tw = tw; break; }
+            }
+        }
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
         dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
         RY_TRY(Lc.begin(tile_name(lp.tile), l.name, lp.flops, lp.bytes, grid));
         p.dbg = g_dbg;
-        const bool bk64 = g_bk64 && lp.tile == TILE_128x128 && C1 % 64 == 0 && C2 % 64 == 0;
 #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
     do {                                                                                                    \
         if (g_pipe && BK_ == 32 && !g_timing) RY_LAUNCH((ry_igemm_f32_p<BM_, BN_, WM_, WN_>), grid, 256, Lc.stream, p); \
         else if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
+        else if (g_deep) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 9>), grid, 256, Lc.stream, p);   \
+        else if (g_fpre) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 5>), grid, 256, Lc.stream, p);   \
         else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
         else RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 0>), grid, 256, Lc.stream, p);               \
     } while (0)
         switch (lp.tile) {
             case TILE_128x128:
-                if (bk64) RY_IGEMM_LAUNCH(128, 128, 2, 2, 64);
-                else RY_IGEMM_LAUNCH(128, 128, 2, 2, 32);
+                RY_IGEMM_LAUNCH(128, 128, 2, 2, 32);
                 break;
             case TILE_256x64: RY_IGEMM_LAUNCH(256, 64, 4, 1, 32); break;
             case TILE_64x128: RY_IGEMM_LAUNCH(64, 128, 1, 4, 32); break;
@@ -978,13 +994,18 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
     if (const char* e = getenv("RY_ILV")) g_ilv = atoi(e);
     if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
     if (const char* e = getenv("RY_PIPE")) g_pipe = atoi(e);
+    if (const char* e = getenv("RY_FPRE")) g_fpre = atoi(e);
+    if (const char* e = getenv("RY_DEEP")) g_deep = atoi(e);
+#ifndef RY_HOST_EMU
+    if (const char* e = getenv("RY_LDSPAD")) ry_dyn_lds_bytes = atoi(e);
+#endif
+    if (const char* e = getenv("RY_TILE2D")) g_tile2d = atoi(e);
 #ifndef RY_HOST_EMU
     if (g_timing && !g_dbg) {
         RT_TRY(hipMalloc((void**)&g_dbg, 8 * sizeof(unsigned long long)));
         RT_TRY(hipMemset(g_dbg, 0, 8 * sizeof(unsigned long long)));
     }
 #endif
-    if (const char* e = getenv("RY_BK")) g_bk64 = atoi(e) == 64;
     if (const char* e = getenv("RY_TILE64")) g_tile64 = atoi(e) == 256 ? TILE_256x64 : TILE_128x64;
     RT_TRY(rt::stream_create(&net->stream));
     RT_TRY(rt::event_create(&net->done));

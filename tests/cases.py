@@ -41,6 +41,9 @@ CONV2D_CASES = [
     (2, 5, 32, 128, 1, 3, 1, 1, False, None, 'last', None, 0),         # rolling-window form (W % 16 == 0, 128 channels)
     (1, 3, 16, 128, 1, 3, 1, 1, False, None, 'last', None, 0),
     (1, 16, 20, 32, 64, 4, 2, 1, False, 'relu', 'igemm', '128x64', 2),
+    (1, 32, 64, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '128x128', 1),  # 16x32 outputs: 2-D 8x16 pixel tiles
+    (2, 8, 16, 32, 128, 4, 2, 1, True, 'relu', 'igemm', '64x128', 1),      # deconv, batch 2, 2-D 4x16 tiles over the input grid
+    (1, 24, 32, 32, 128, 4, 2, 1, False, 'relu', 'igemm', '96x128', 2),    # 12x16 outputs: 2-D 6x16 tiles, split-K
     (1, 20, 24, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '96x128', 1),   # 120 rows: one full 96-row tile + a ragged one
     (1, 6, 8, 64, 256, 4, 2, 1, True, 'relu', 'igemm', '96x128', 2),       # deconv, 2 N-tiles, 4 phases, split-K, XCD-ordered grid
     (1, 6, 10, 64, 64, 4, 2, 1, True, 'relu', 'igemm', '128x64', 0),
