@@ -153,6 +153,16 @@ def main():
         elapsed = float(te.item())
     assert bool(torch.isfinite(y2).all()) and bool(torch.isfinite(y1).all())
 
+    def time_only(fn, reps=20):
+        for _ in range(3):
+            fn()
+        ctx.sync(); ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        return ctx.timer_stop() / reps
+    s1_ms = time_only(lambda: net1.convert_device(x1.data_ptr(), y1.data_ptr(), Wn, N))
+    s2_ms = time_only(lambda: net2.convert_device(sp.data_ptr(), y2.data_ptr(), Wn, N))
+
     frames_total = world * Wn * N * args.steps
     value = frames_total / elapsed
     out = {
@@ -162,6 +172,7 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'x_realtime': round(value * 0.005, 1), 'x_realtime_per_gpu': round(value * 0.005 / world, 1),
         'device_ms_per_step_rank0': round(dev_ms / args.steps, 4),
+        'graph_replay_ms': {'stage1_alone': round(s1_ms, 4), 'stage2_alone': round(s2_ms, 4)},
         'config': {'workload': 'BASELINE config #3: stage-1 + stage-2 SR forward, buffer_time 0.5 s + 2x0.5 s convert_extra_time '
                                '@16 kHz / 5 ms -> %d real frames (%d padded) per window, %d window(s) per GPU per step, %s random-init weights'
                                % (N, T, Wn, args.model),

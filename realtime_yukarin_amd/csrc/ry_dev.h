@@ -28,9 +28,8 @@ RY_DEV float ry_shfl(float v, int src) { return __shfl(v, src, 64); }
 RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }
 
 typedef hipStream_t ry_stream_t;
-extern int ry_dyn_lds_bytes;      // RY_LDSPAD (diagnostics): unused dynamic LDS per workgroup, to force a lower occupancy
 #define RY_LAUNCH(kernel, grid, block, stream, ...) \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), ry_dyn_lds_bytes, stream, __VA_ARGS__)
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #endif
 
 RY_DEV f32x4 ry_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }

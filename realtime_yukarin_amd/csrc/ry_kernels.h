@@ -76,7 +76,6 @@ template <int BM, int BN, int WM, int WN, int BK, int VAR>
 RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     constexpr int ILV = VAR & 1;
     constexpr bool TIMING = (VAR & 2) != 0;
-    constexpr bool FPRE = (VAR & 4) != 0;          // MFMA fragments of step s+1 are read from LDS while step s computes
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
 #if defined(RY_HOST_EMU)
 #define RY_STAMP(i)
@@ -182,10 +181,10 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     int cib = kc_begin - tap * cpt;
     int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
 
-    // Register staging, DEPTH chunks deep.  DEPTH = 2 (VAR bit 3): the loads issued while chunk k computes are those of
-    // chunk k+2, so they have a whole extra iteration to land (L2-missing im2col rows take 2-4 us under load, more than
-    // the MFMA phase of one chunk); costs one more register set.
-    constexpr int DEPTH = (VAR & 8) ? 2 : 1;
+    // Register staging, one chunk deep: the loads issued while chunk k computes are those of chunk k+1.  (A two-chunk-deep
+    // variant, fragment prefetch, a one-barrier LDS-double-buffered loop and per-workgroup priorities were all measured
+    // as nulls or losses on MI355X -- DESIGN.md section 4.1.)
+    constexpr int DEPTH = 1;
     f32x4 areg[DEPTH][AR], breg[DEPTH][BR];
     unsigned amask[DEPTH];
 #pragma unroll
@@ -256,27 +255,13 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
             }
         }
         RY_STAMP(3)
-        f32x4 af[2][TM], bf[2][TN];
-        if (FPRE) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[0][i] = ry_ld4(&As[((wm * TM + i) * 32 + lr) * BKP + lh * 4]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = ry_ld4(&Bs[((wn * TN + j) * 32 + lr) * BKP + lh * 4]);
-        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int cb = FPRE ? (s & 1) : 0;
-            if (!FPRE) {
+            f32x4 af[TM], bf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[0][i] = ry_ld4(&As[((wm * TM + i) * 32 + lr) * BKP + s * 8 + lh * 4]);
+            for (int i = 0; i < TM; ++i) af[i] = ry_ld4(&As[((wm * TM + i) * 32 + lr) * BKP + s * 8 + lh * 4]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[0][j] = ry_ld4(&Bs[((wn * TN + j) * 32 + lr) * BKP + s * 8 + lh * 4]);
-            } else if (s + 1 < NS) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[cb ^ 1][i] = ry_ld4(&As[((wm * TM + i) * 32 + lr) * BKP + (s + 1) * 8 + lh * 4]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[cb ^ 1][j] = ry_ld4(&Bs[((wn * TN + j) * 32 + lr) * BKP + (s + 1) * 8 + lh * 4]);
-            }
+            for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(&Bs[((wn * TN + j) * 32 + lr) * BKP + s * 8 + lh * 4]);
             if (ILV && more) {                     // slice s of the loads being issued
 #pragma unroll
                 for (int j = 0; j < AR; ++j) if (j % NS == s) load_a(set, j);
@@ -288,20 +273,14 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[cb][i][t], bf[cb][j][t], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
 #ifndef RY_HOST_EMU
             if (ILV) __builtin_amdgcn_sched_barrier(0);       // keep the load slices where they are
 #endif
         }
         RY_STAMP(4)
     };
-    if (DEPTH == 1) {
-        for (int k = 0; k < nchunks; ++k) iteration(k, 0);
-    } else {
-        int k = 0;
-        for (; k + 1 < nchunks; k += 2) { iteration(k, 0); iteration(k + 1, 1 % DEPTH); }
-        if (k < nchunks) iteration(k, 0);
-    }
+    for (int k = 0; k < nchunks; ++k) iteration(k, 0);
 
     // epilogue: D[row=(r&3)+8*(r>>2)+4*lh][col=lr]; 32 lanes store 128 contiguous bytes of one pixel
     float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
@@ -333,240 +312,6 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
     }
 #endif
 #undef RY_STAMP
-}
-
-// ---------------------------------------------------------------------------------------------
-// ry_igemm_f32_p -- software-pipelined form of ry_igemm_f32 (same math, same fragment maps, same epilogue).
-// The two-barrier loop of ry_igemm_f32 loses ~30% of every wave's time at its first barrier: the four waves of a
-// workgroup sit on four SIMDs, each sharing its MFMA pipe with other workgroups' waves, so they drift apart and
-// the fastest waits for the slowest twice per chunk (s_memtime phase stamps).  Here:
-//   * LDS is double-buffered: chunk k is read from buf[k&1] while chunk k+1 is written to buf[(k+1)&1]
-//     -> ONE barrier per chunk;
-//   * one staging register set: during iteration k the registers (chunk k+1, requested one iteration ago) are
-//     written to LDS in the first MFMA steps and immediately re-used for the global loads of chunk k+2 in the
-//     later steps, so loads have a whole iteration to land and LDS writes / load issue hide under the MFMAs;
-//   * MFMA fragments of step s+1 are read from LDS while step s computes.
-// ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
-RY_KERNEL(256) void ry_igemm_f32_p(RyIgemmParams p) {
-    constexpr int BK = 32, BKP = 36, NS = BK / 8;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int RSTEP = 32;
-    constexpr int AR = BM / RSTEP, BR = BN / RSTEP;
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
-    constexpr int ABUF = BM * BKP, BBUF = BN * BKP;
-    __shared__ __attribute__((aligned(16))) float As[2 * ABUF];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BBUF];
-    __shared__ int rY[BM], rX[BM], rP[BM], rO[BM];
-
-    const RyConvGeom& g = p.g;
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 31, lh = lane >> 5;
-    // XCD-aware 1-D grid: block b runs on XCD b % 8 (observed dispatch rule, speed only); give each XCD a contiguous
-    // range of logical ids so the phases / N-tiles / neighbouring M-tiles that re-read the same input pixels share one L2
-    const int total_tiles = p.splits * p.mtiles * p.ntiles * p.g.nphases;
-    const int per_xcd = (total_tiles + 7) >> 3;
-    int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (lid >= total_tiles) return;
-    const int phase = lid % p.g.nphases; lid /= p.g.nphases;
-    const int nt = lid % p.ntiles; lid /= p.ntiles;
-    const int mt = lid % p.mtiles;
-    const int split = lid / p.mtiles;
-    const int m0 = mt * BM;
-    const int n0 = nt * BN;
-    const int Ctot = g.C1 + g.C2;
-    const int Mimg = g.Mh * g.Mw;
-    const int M = g.B * Mimg;
-    const bool subpix = g.ostride == 2;
-    const int pdy = subpix ? (phase >> 1) : 0, pdx = subpix ? (phase & 1) : 0;
-
-    for (int r = tid; r < BM; r += 256) {
-        const int m = m0 + r;
-        int yb = -(1 << 20), xb = 0, pb = 0, ob = -1;
-        bool live = m < M;
-        int b = 0, ry = 0, rx = 0;
-        if (p.tw > 0) {                            // 2-D tile: mt enumerates (image, tile row, tile column)
-            const int th = BM / p.tw, tcols = g.Mw / p.tw, trows = g.Mh / th;
-            const int tx = mt % tcols, ty = (mt / tcols) % trows;
-            b = mt / (tcols * trows);
-            ry = ty * th + r / p.tw; rx = tx * p.tw + r % p.tw;
-            live = b < g.B;
-        } else if (live) {
-            b = m / Mimg; const int rem = m - b * Mimg;
-            ry = rem / g.Mw; rx = rem - ry * g.Mw;
-        }
-        if (live) {
-            yb = ry * g.stride - g.pad;
-            xb = rx * g.stride - g.pad;
-            pb = b * g.Hi * g.Wi;
-            ob = (b * g.Ho + ry * g.ostride + pdy) * g.Wo + rx * g.ostride + pdx;
-        }
-        rY[r] = yb; rX[r] = xb; rP[r] = pb; rO[r] = ob;
-    }
-    __syncthreads();
-
-    const int c4 = (tid & 7) * 4;
-    const int rbase = tid >> 3;
-    int ayb[AR], axb[AR], aoff1[AR], aoff2[AR];
-#pragma unroll
-    for (int j = 0; j < AR; ++j) {
-        ayb[j] = rY[rbase + RSTEP * j]; axb[j] = rX[rbase + RSTEP * j];
-        const int pixb = rP[rbase + RSTEP * j] + ayb[j] * g.Wi + axb[j];
-        aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + c4 : 0;
-        aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + c4 : 0;
-    }
-    unsigned boff[BR];
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-        const int n = n0 + rbase + RSTEP * j;
-        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * (Ctot >> 5)) * 2048 + (n & 63) * 32 + c4);
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int cpt = Ctot / BK;
-    const int nk = g.ntaps * cpt;
-    const int kc_begin = (int)(((long long)nk * split) / p.splits);
-    const int kc_end = (int)(((long long)nk * (split + 1)) / p.splits);
-    // walk state of the NEXT chunk to be requested from global memory
-    int tap = kc_begin / cpt;
-    int cib = kc_begin - tap * cpt;
-    int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
-
-    f32x4 areg[AR], breg[BR];
-    unsigned amask = 0, amask_next = 0;            // validity bits of the rows held in areg (and of the loads being issued)
-    const float* src = g.src1;
-    int delta = 0, dy = 0, dx = 0;
-    bool first = true;
-    unsigned bdelta = 0;
-    auto chunk_setup = [&]() {                     // scalars of the chunk (tap, cib); then advances the walk
-        const int ci0 = cib * BK;
-        first = ci0 < g.C1;
-        src = first ? g.src1 : g.src2;
-        const int Cs = first ? g.C1 : g.C2;
-        const int cil = first ? ci0 : ci0 - g.C1;
-        dy = subpix ? pdy - ky : ky; dx = subpix ? pdx - kx : kx;
-        delta = (dy * g.Wi + dx) * Cs + cil;
-        bdelta = (unsigned)((tap * cpt + cib) * 2048);
-        amask_next = 0;
-        if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
-    };
-    auto load_a = [&](int j) {
-        const int iy = ayb[j] + dy, ix = axb[j] + dx;
-        const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-        const int off = ok ? (first ? aoff1[j] : aoff2[j]) + delta : c4;
-        areg[j] = ry_ld4(src + (unsigned)off);
-        amask_next |= ok ? (1u << j) : 0u;
-    };
-    auto load_b = [&](int j) { breg[j] = ry_ld4(p.wt + (boff[j] + bdelta)); };
-    auto store_a = [&](int j, int buf) {
-        f32x4 v = areg[j];
-        if (!(amask & (1u << j))) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
-        ry_st4(&As[buf * ABUF + (rbase + RSTEP * j) * BKP + c4], v);
-    };
-    auto store_b = [&](int j, int buf) { ry_st4(&Bs[buf * BBUF + (rbase + RSTEP * j) * BKP + c4], breg[j]); };
-
-    const int nchunks = kc_end - kc_begin;
-    if (nchunks > 0) {                             // prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers
-        chunk_setup();
-#pragma unroll
-        for (int j = 0; j < AR; ++j) load_a(j);
-#pragma unroll
-        for (int j = 0; j < BR; ++j) load_b(j);
-        amask = amask_next;
-#pragma unroll
-        for (int j = 0; j < AR; ++j) store_a(j, 0);
-#pragma unroll
-        for (int j = 0; j < BR; ++j) store_b(j, 0);
-        if (nchunks > 1) {
-            chunk_setup();
-#pragma unroll
-            for (int j = 0; j < AR; ++j) load_a(j);
-#pragma unroll
-            for (int j = 0; j < BR; ++j) load_b(j);
-            amask = amask_next;
-        }
-        __syncthreads();
-    }
-    for (int k = 0; k < nchunks; ++k) {
-        const int cur = k & 1;
-        const bool wr = k + 1 < nchunks;           // registers hold chunk k+1: write it to the other buffer
-        const bool ld = k + 2 < nchunks;           // then request chunk k+2 into the same registers
-        const float* Ab = &As[cur * ABUF + ((wm * TM) * 32 + lr) * BKP + lh * 4];
-        const float* Bb = &Bs[cur * BBUF + ((wn * TN) * 32 + lr) * BKP + lh * 4];
-        f32x4 af[2][TM], bf[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = ry_ld4(Ab + i * 32 * BKP);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = ry_ld4(Bb + j * 32 * BKP);
-        if (ld) chunk_setup();                     // scalars of chunk k+2 (used by the load slices below)
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (s + 1 < NS) {                      // fragments of the next step, one step ahead
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[(s + 1) & 1][i] = ry_ld4(Ab + i * 32 * BKP + (s + 1) * 8);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[(s + 1) & 1][j] = ry_ld4(Bb + j * 32 * BKP + (s + 1) * 8);
-            }
-            // steps 0,1: LDS writes of chunk k+1 (A then B); steps 2,3: global loads of chunk k+2 (A then B)
-            if (s == 0 && wr) {
-#pragma unroll
-                for (int j = 0; j < AR; ++j) store_a(j, cur ^ 1);
-            }
-            if (s == 1 && wr) {
-#pragma unroll
-                for (int j = 0; j < BR; ++j) store_b(j, cur ^ 1);
-            }
-            if (s == 2 && ld) {
-#pragma unroll
-                for (int j = 0; j < AR; ++j) load_a(j);
-            }
-            if (s == 3 && ld) {
-#pragma unroll
-                for (int j = 0; j < BR; ++j) load_b(j);
-                amask = amask_next;
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[s & 1][i][t], bf[s & 1][j][t], acc[i][j]);
-#ifndef RY_HOST_EMU
-            __builtin_amdgcn_sched_barrier(0);     // keep each step's LDS / global work where it was placed
-#endif
-        }
-        __syncthreads();                           // buf[cur^1] complete and buf[cur] free: the only barrier of the chunk
-    }
-
-    float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + lr;
-        float sc = 1.f, sh = 0.f;
-        if (p.splits == 1) { sc = p.scale[n]; sh = p.shift[n]; }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int ob = rO[ml];
-                if (ob >= 0) {
-                    float v = acc[i][j][r];
-                    if (p.splits == 1) v = ry_act(fmaf(v, sc, sh), p.act, p.slope);
-                    outp[(size_t)ob * g.N + n] = v;
-                }
-            }
-        }
-    }
 }
 
 struct RyReduceParams {
@@ -603,6 +348,36 @@ RY_KERNEL(256) void ry_splitk_reduce(RyReduceParams p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(s[u], sc[u], sh[u]), p.act, p.slope);
     ry_st4(p.out + i4, o);
+}
+
+// Many slabs, few outputs (the weight-streaming layers at the bottom of the U-Net): 64 float4 columns per workgroup,
+// the slabs are divided over 4 waves (wave w sums slabs w, w+4, ...), combined through LDS in a fixed order.
+RY_KERNEL(256) void ry_splitk_reduce_wide(RyReduceParams p) {
+    __shared__ __attribute__((aligned(16))) float part[4 * 64 * 4];
+    const int tid = (int)threadIdx.x, col = tid & 63, grp = tid >> 6;
+    const long long i4 = ((long long)blockIdx.x * 64 + col) * 4;
+    const bool live = i4 < p.total;
+    const size_t st = (size_t)p.slab_stride;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    if (live) {
+        int k = grp;
+        for (; k + 4 < p.splits; k += 8) {
+            a0 += ry_ld4(p.slabs + (size_t)k * st + i4);
+            a1 += ry_ld4(p.slabs + (size_t)(k + 4) * st + i4);
+        }
+        if (k < p.splits) a0 += ry_ld4(p.slabs + (size_t)k * st + i4);
+    }
+    ry_st4(&part[(grp * 64 + col) * 4], a0 + a1);
+    __syncthreads();
+    if (grp == 0 && live) {
+        const f32x4 s = (ry_ld4(&part[col * 4]) + ry_ld4(&part[(64 + col) * 4])) + (ry_ld4(&part[(128 + col) * 4]) + ry_ld4(&part[(192 + col) * 4]));
+        const int n = (int)(i4 % p.N);
+        const f32x4 sc = ry_ld4(p.scale + n), sh = ry_ld4(p.shift + n);
+        f32x4 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(s[u], sc[u], sh[u]), p.act, p.slope);
+        ry_st4(p.out + i4, o);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -977,7 +752,17 @@ RY_KERNEL(256) void ry_conv1d_ws(RyConv1dParams p) {
     const bool co_ok = co < p.N;
     const int cw = co_ok ? co : 0;
 
+    constexpr int WB = 16;                         // filters of 16 input channels (16 x 16 bytes per lane) are in flight at a time
     for (int cc = ci_begin; cc < ci_end; cc += CS) {
+        const int cn = (ci_end - cc < CS) ? (ci_end - cc) : CS;
+        // the first filter batch does not depend on the staged tile: request it before the staging loads so both
+        // latencies overlap
+        f32x4 wnext[WB];
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+            const int cl = u < cn ? u : cn - 1;
+            wnext[u] = ry_ld4(p.wd + ((size_t)(cc + cl) * p.N + cw) * 4);
+        }
         __syncthreads();
         // stage xs[cl][pos] = act(scale * sum_splits(raw) + shift) of the producer layer(s), 0 outside [0, Lin)
         for (int e = tid; e < CS * (PP / 4); e += nthr) {
@@ -1000,15 +785,6 @@ RY_KERNEL(256) void ry_conv1d_ws(RyConv1dParams p) {
             ry_st4(&xs[cl * PP + p4 * 4], v);
         }
         __syncthreads();
-        const int cn = (ci_end - cc < CS) ? (ci_end - cc) : CS;
-        // weights: 8 input channels (8 x 16 bytes per lane) are requested ahead of the FMAs that use them
-        constexpr int WB = 8;
-        f32x4 wnext[WB];
-#pragma unroll
-        for (int u = 0; u < WB; ++u) {
-            const int cl = u < cn ? u : cn - 1;
-            wnext[u] = ry_ld4(p.wd + ((size_t)(cc + cl) * p.N + cw) * 4);
-        }
         for (int cb = 0; cb < cn; cb += WB) {
             f32x4 wcur[WB];
 #pragma unroll

@@ -11,9 +11,6 @@
 // a plan per (batch, frames) owns all activation buffers, and the whole forward -- pad/log wrapper
 // kernels, 16 fused layers, exp/crop -- is captured once into a hipGraph and replayed per buffer.
 #include "ry_kernels.h"
-#ifndef RY_HOST_EMU
-int ry_dyn_lds_bytes = 0;
-#endif
 
 #include "../../include/ry355.h"
 
@@ -468,9 +465,6 @@ static const char* tile_name(int tile) {
 }
 
 static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
-static int g_pipe = 0;     // RY_PIPE=1: pipelined one-barrier ry_igemm_f32_p (measured 96 TF vs 105 TF for the default; kept for A/B)
-static int g_deep = 0;     // RY_DEEP=1: two-chunk-deep register prefetch variant of ry_igemm_f32 (VAR bit 3)
-static int g_fpre = 0;     // RY_FPRE=1: fragment prefetch variant of ry_igemm_f32 (VAR bit 2)
 static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
 static unsigned long long* g_dbg = nullptr;
@@ -550,10 +544,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         p.dbg = g_dbg;
 #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
     do {                                                                                                    \
-        if (g_pipe && BK_ == 32 && !g_timing) RY_LAUNCH((ry_igemm_f32_p<BM_, BN_, WM_, WN_>), grid, 256, Lc.stream, p); \
-        else if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
-        else if (g_deep) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 9>), grid, 256, Lc.stream, p);   \
-        else if (g_fpre) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 5>), grid, 256, Lc.stream, p);   \
+        if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
         else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
         else RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 0>), grid, 256, Lc.stream, p);               \
     } while (0)
@@ -574,9 +565,15 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             r.slabs = lp.slabs; r.splits = lp.splits; r.slab_stride = p.slab_stride;
             r.scale = l.scale; r.shift = l.shift; r.out = lp.out; r.total = p.slab_stride; r.N = l.cout;
             r.act = l.act; r.slope = slope;
-            dim3 rg((unsigned)((r.total / 4 + 255) / 256));
-            RY_TRY(Lc.begin("ry_splitk_reduce", l.name, 0, (double)r.total * 4 * (lp.splits + 1), rg));
-            RY_LAUNCH(ry_splitk_reduce, rg, 256, Lc.stream, r);
+            if (lp.splits >= 16 && r.total <= (1 << 20)) {      // many slabs, few outputs
+                dim3 rg((unsigned)((r.total / 4 + 63) / 64));
+                RY_TRY(Lc.begin("ry_splitk_reduce_wide", l.name, 0, (double)r.total * 4 * (lp.splits + 1), rg));
+                RY_LAUNCH(ry_splitk_reduce_wide, rg, 256, Lc.stream, r);
+            } else {
+                dim3 rg((unsigned)((r.total / 4 + 255) / 256));
+                RY_TRY(Lc.begin("ry_splitk_reduce", l.name, 0, (double)r.total * 4 * (lp.splits + 1), rg));
+                RY_LAUNCH(ry_splitk_reduce, rg, 256, Lc.stream, r);
+            }
             RY_TRY(Lc.end());
         }
     } else if (lp.path == PATH_FIRST) {
@@ -993,12 +990,6 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
     if (const char* e = getenv("RY_GRAPH")) net->use_graph = atoi(e) != 0;
     if (const char* e = getenv("RY_ILV")) g_ilv = atoi(e);
     if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
-    if (const char* e = getenv("RY_PIPE")) g_pipe = atoi(e);
-    if (const char* e = getenv("RY_FPRE")) g_fpre = atoi(e);
-    if (const char* e = getenv("RY_DEEP")) g_deep = atoi(e);
-#ifndef RY_HOST_EMU
-    if (const char* e = getenv("RY_LDSPAD")) ry_dyn_lds_bytes = atoi(e);
-#endif
     if (const char* e = getenv("RY_TILE2D")) g_tile2d = atoi(e);
 #ifndef RY_HOST_EMU
     if (g_timing && !g_dbg) {

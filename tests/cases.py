@@ -35,6 +35,7 @@ CONV2D_CASES = [
     (1, 5, 7, 64, 128, 3, 1, 1, False, None, 'igemm', '64x128', 0),
     (1, 5, 7, 32, 128, 1, 1, 0, False, 'relu', 'igemm', '32x128', 1),
     (1, 2, 4, 64, 128, 4, 2, 1, False, 'lrelu', 'igemm', None, 0),     # deepest encoder layer, auto tile/split
+    (1, 2, 4, 128, 128, 4, 2, 1, False, 'lrelu', 'igemm', '32x128', 21),  # 21 slabs: wide split-K reduce, ragged slab groups
     (2, 7, 10, 1, 64, 3, 1, 1, False, 'lrelu', 'first', None, 0),      # specialised SR encoder c0 (ragged width)
     (2, 5, 9, 128, 1, 3, 1, 1, False, None, 'last', None, 0),          # specialised SR decoder c7 (two-source concat)
     (1, 4, 6, 256, 1, 3, 1, 1, False, None, 'last', None, 0),
