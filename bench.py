@@ -160,6 +160,19 @@ def main():
         for _ in range(reps):
             fn()
         return ctx.timer_stop() / reps
+    # PCIe-inclusive single-window latency of the drop-in call path (host arrays in, host arrays out; never the headline value)
+    host_ms = None
+    if rank == 0:
+        from realtime_yukarin_amd import sptk
+        core = engine.VcCore(net1, net2, sptk.mc2sp_matrix(d1.out_ch - 1, sptk.mcepalpha(16000), 2 * (synth.FFT_BINS - 1)))
+        xh = synth.stage1_input(N)[0]; eff = numpy.ones(N, bool)
+        for _ in range(3):
+            core.convert(xh, eff)
+        th = time.perf_counter()
+        for _ in range(20):
+            core.convert(xh, eff)
+        host_ms = (time.perf_counter() - th) / 20 * 1e3
+        core.close()
     s1_ms = time_only(lambda: net1.convert_device(x1.data_ptr(), y1.data_ptr(), Wn, N))
     s2_ms = time_only(lambda: net2.convert_device(sp.data_ptr(), y2.data_ptr(), Wn, N))
 
@@ -173,6 +186,7 @@ def main():
         'x_realtime': round(value * 0.005, 1), 'x_realtime_per_gpu': round(value * 0.005 / world, 1),
         'device_ms_per_step_rank0': round(dev_ms / args.steps, 4),
         'graph_replay_ms': {'stage1_alone': round(s1_ms, 4), 'stage2_alone': round(s2_ms, 4)},
+        'host_call_ms_per_window': None if host_ms is None else round(host_ms, 4),
         'config': {'workload': 'BASELINE config #3: stage-1 + stage-2 SR forward, buffer_time 0.5 s + 2x0.5 s convert_extra_time '
                                '@16 kHz / 5 ms -> %d real frames (%d padded) per window, %d window(s) per GPU per step, %s random-init weights'
                                % (N, T, Wn, args.model),

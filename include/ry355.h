@@ -88,9 +88,22 @@ int ry_sr_convert(ry_net* stage2, const float* sp, float* out, int batch, int n_
 int ry_conv1d(ry_ctx* ctx, const float* x, int B, int L, int Cin, const float* W, const float* bias, const float* bn,
               int Cout, int k, int stride, int pad, int dilate, int transposed, int act, int splits, float* y);
 /* L.Convolution2D / L.Deconvolution2D.  x [B][H][W][Cin] -> y [B][Ho][Wo][Cout].  path: 0 auto, 1 implicit-GEMM (MFMA),
- * 2 direct (VALU), 3 SR first layer (1 -> N, 3x3), 4 SR last layer (C -> 1, 3x3, channels read as two sources); tile: 0 auto, 1 = 128x128, 2 = 256x64, 3 = 64x128, 4 = 32x128, 5 = 128x64, 6 = 96x128. */
+ * 2 direct (VALU), 3 SR first layer (1 -> N, 3x3), 4 SR last layer (C -> 1, 3x3, channels read as two sources); tile: 0 auto, 1 = 128x128, 2 = 256x64, 3 = 64x128, 4 = 32x128, 5 = 128x64, 6 = 96x128, 7 = 256x128. */
 int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int W, int Cin, const float* Wt, const float* bias, const float* bn,
               int Cout, int k, int stride, int pad, int transposed, int act, int path, int tile, int splits, float* y);
+
+/* ---- the whole device-resident convert: stage-1 -> combine_silent -> mc2sp -> +floor -> stage-2 (voice_changer.py:27-41) ----
+ * mc2sp(mc) = exp(mc @ mtx) with mtx [(order+1)][bins] precomputed on the host (every step of pysptk.mc2sp before the exp is
+ * linear); see realtime_yukarin_amd/sptk.py.  One H2D and one D2H per window instead of two round trips + a CPU mc2sp. */
+typedef struct ry_vc ry_vc;
+int ry_vc_create(ry_net* stage1, ry_net* stage2, const float* mtx, int order_plus_1, int bins, ry_vc** out);
+void ry_vc_destroy(ry_vc* vc);
+/* x_eff [n_eff][in_ch]: encode_feature of the effective (non-silent) frames; row_of[i] = frame index of row i;
+ * mc_out [n_frames][order+1] (zeros on silent frames), sp_out [n_frames][bins].  n_eff may be 0 (all silent). */
+int ry_vc_convert(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, int n_frames, float sp_floor,
+                  float* mc_out, float* sp_out);
+/* `AcousticConverter.decode_spectrogram` alone (host pointers): sp [n][bins] = exp(mc [n][m] @ mtx [m][bins]) + floor. */
+int ry_mc2sp(ry_ctx* ctx, const float* mc, const float* mtx, int n, int m, int bins, float floor, float* sp);
 
 /* ---- measurement ---- */
 int ry_timer_start(ry_ctx* ctx);              /* hipEventRecord on the context stream */

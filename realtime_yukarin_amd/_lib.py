@@ -18,7 +18,7 @@ DEFAULT_LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GLU = 0, 1, 2, 3
 ACTS = {None: ACT_NONE, 'none': ACT_NONE, 'lrelu': ACT_LRELU, 'relu': ACT_RELU, 'glu': ACT_GLU}
 PATH_AUTO, PATH_IGEMM, PATH_DIRECT = 0, 1, 2
-TILES = {None: 0, 'auto': 0, '128x128': 1, '256x64': 2, '64x128': 3, '32x128': 4, '128x64': 5, '96x128': 6}
+TILES = {None: 0, 'auto': 0, '128x128': 1, '256x64': 2, '64x128': 3, '32x128': 4, '128x64': 5, '96x128': 6, '256x128': 7}
 
 # every symbol include/ry355.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -26,6 +26,7 @@ ABI_SYMBOLS = (
     'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_forward',
     'ry_ac_convert', 'ry_sr_convert', 'ry_conv1d', 'ry_conv2d',
     'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_debug_igemm_phases',
+    'ry_vc_create', 'ry_vc_destroy', 'ry_vc_convert', 'ry_mc2sp',
 )
 
 
@@ -87,6 +88,11 @@ class Ry355Lib(object):
         d.ry_sr_convert.argtypes = [_VP, _FP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         d.ry_conv1d.argtypes = [_VP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP] + [ctypes.c_int] * 8 + [_FP]
         d.ry_conv2d.argtypes = [_VP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP] + [ctypes.c_int] * 9 + [_FP]
+        d.ry_vc_create.argtypes = [_VP, _VP, _FP, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_VP)]
+        d.ry_vc_destroy.argtypes = [_VP]
+        d.ry_vc_destroy.restype = None
+        d.ry_vc_convert.argtypes = [_VP, _FP, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_float, _FP, _FP]
+        d.ry_mc2sp.argtypes = [_VP, _FP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, _FP]
         d.ry_timer_start.argtypes = [_VP]
         d.ry_timer_stop.argtypes = [_VP, ctypes.POINTER(ctypes.c_float)]
         d.ry_net_profile.argtypes = [_VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RyKernelStat),

@@ -118,5 +118,16 @@ class AcousticConverter(object):
         if self._alpha_out is None:
             self._alpha_out = sptk.mcepalpha(self.out_sampling_rate)
         fftlen = cheaptrick_fft_size(self.out_sampling_rate)
-        feature.sp = sptk.mc2sp(numpy.asarray(feature.mc, dtype=numpy.float32), alpha=self._alpha_out, fftlen=fftlen)
+        # pysptk.mc2sp == exp(mc @ M): every step before the exp is linear (sptk.mc2sp_matrix); float64 on the host like SPTK
+        feature.sp = sptk.mc2sp_fast(numpy.asarray(feature.mc, dtype=numpy.float32), alpha=self._alpha_out, fftlen=fftlen)
         return feature
+
+    def mc2sp_matrix(self) -> numpy.ndarray:
+        """The (order+1, bins) matrix of `decode_spectrogram` for this converter's output rate (used by the fused device path)."""
+        if self._alpha_out is None:
+            self._alpha_out = sptk.mcepalpha(self.out_sampling_rate)
+        return sptk.mc2sp_matrix(self.desc.out_ch - 1, self._alpha_out, cheaptrick_fft_size(self.out_sampling_rate))
+
+    def fusable(self) -> bool:
+        """True when convert() is exactly mc -> mc (the canonical config), so stage-1 -> mc2sp -> stage-2 can stay on the GPU."""
+        return list(self.config.dataset.in_features) == ['mc'] and list(self.config.dataset.out_features) == ['mc']

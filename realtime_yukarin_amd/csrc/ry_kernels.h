@@ -676,7 +676,17 @@ RY_DEV f32x4 ry_src1d_load4(const RySrc1d& s, long long pix0, int c, int valid_m
     }
     float a0 = q[0][0], a1 = q[1][0], a2 = q[2][0], a3 = q[3][0];
     int k = 1;
-    for (; k + 3 < s.splits; k += 4) {             // 16 independent loads in flight; additions stay in split order
+    for (; k + 7 < s.splits; k += 8) {             // 32 independent loads in flight; additions stay in split order
+        float b0[8], b1[8], b2[8], b3[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t o = (size_t)(k + u) * (size_t)s.slab_stride;
+            b0[u] = q[0][o]; b1[u] = q[1][o]; b2[u] = q[2][o]; b3[u] = q[3][o];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a0 += b0[u]; a1 += b1[u]; a2 += b2[u]; a3 += b3[u]; }
+    }
+    for (; k + 3 < s.splits; k += 4) {
         const size_t o0 = (size_t)k * (size_t)s.slab_stride, o1 = o0 + (size_t)s.slab_stride;
         const size_t o2 = o1 + (size_t)s.slab_stride, o3 = o2 + (size_t)s.slab_stride;
         const float b00 = q[0][o0], b10 = q[1][o0], b20 = q[2][o0], b30 = q[3][o0];
@@ -920,4 +930,32 @@ RY_KERNEL(256) void ry_sr_post(RySrPostParams p) {   // out[r][f] = exp(y[r][min
     const int fi = f < p.cols_in ? f : p.cols_in - 1;
     p.out[(size_t)blockIdx.y * (size_t)p.out_bstride + idx] =
         expf(p.y[(size_t)blockIdx.y * (size_t)p.y_bstride + (size_t)r * p.cols_in + fi]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Between the two CNNs: `AcousticConverter.combine_silent` (scatter converted rows into an all-silent block) and
+// `decode_spectrogram` = pysptk.mc2sp.  mc2sp is freqt(-alpha) -> c0 *= 2 -> symmetric extension -> Re(rfft) -> exp;
+// everything before the exp is linear in the mel-cepstrum, so sp = exp(mc @ M) with an (order+1) x (fftlen/2+1)
+// matrix M computed once on the host in float64 (realtime_yukarin_amd/sptk.py).  `floor` is the 1e-16 the reference
+// adds before stage-2 (voice_changer.py:39).
+// ---------------------------------------------------------------------------------------------
+struct RyScatterParams { const float* src; const int* row_of; float* dst; int n_src, cols; };
+
+RY_KERNEL(256) void ry_scatter_rows(RyScatterParams p) {       // dst[row_of[i]][:] = src[i][:]
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.n_src * p.cols) return;
+    const int c = (int)(idx % p.cols), i = (int)(idx / p.cols);
+    p.dst[(size_t)p.row_of[i] * p.cols + c] = p.src[idx];
+}
+
+struct RyMc2spParams { const float* mc; const float* mtx; float* sp; int n, m, f; float floor; };
+
+RY_KERNEL(256) void ry_mc2sp(RyMc2spParams p) {                 // sp[n][f] = exp(sum_m mc[n][m] * mtx[m][f]) + floor
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.n * p.f) return;
+    const int f = (int)(idx % p.f), n = (int)(idx / p.f);
+    const float* row = p.mc + (size_t)n * p.m;
+    float z = 0.f;
+    for (int m = 0; m < p.m; ++m) z = fmaf(row[m], p.mtx[(size_t)m * p.f + f], z);
+    p.sp[idx] = expf(z) + p.floor;
 }

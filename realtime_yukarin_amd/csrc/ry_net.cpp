@@ -42,6 +42,7 @@ static err_t dfree(void* p) { free(p); return 0; }
 static err_t h2d(void* d, const void* h, size_t n, ry_stream_t) { memcpy(d, h, n); return 0; }
 static err_t d2h(void* h, const void* d, size_t n, ry_stream_t) { memcpy(h, d, n); return 0; }
 static err_t d2d(void* d, const void* s, size_t n, ry_stream_t) { memcpy(d, s, n); return 0; }
+static err_t dmemset(void* d, int v, size_t n, ry_stream_t) { memset(d, v, n); return 0; }
 static err_t last_error() { return 0; }
 struct Event { double t; };
 static err_t event_create(Event*) { return 0; }
@@ -63,6 +64,7 @@ static err_t dfree(void* p) { return hipFree(p); }
 static err_t h2d(void* d, const void* h, size_t n, ry_stream_t s) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s); }
 static err_t d2h(void* h, const void* d, size_t n, ry_stream_t s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s); }
 static err_t d2d(void* d, const void* s_, size_t n, ry_stream_t s) { return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s); }
+static err_t dmemset(void* d, int v, size_t n, ry_stream_t s) { return hipMemsetAsync(d, v, n, s); }
 static err_t last_error() { return hipGetLastError(); }
 typedef hipEvent_t Event;
 static err_t event_create(Event* e) { return hipEventCreate(e); }
@@ -313,7 +315,7 @@ static bool igemm_eligible(const Layer& l) {
 // per-layer launch plans
 // ------------------------------------------------------------------------------------------------
 enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4 };
-enum { TILE_128x128 = 1, TILE_256x64 = 2, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5, TILE_96x128 = 6 };
+enum { TILE_128x128 = 1, TILE_256x64 = 2, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5, TILE_96x128 = 6, TILE_256x128 = 7 };
 
 struct LayerPlan {
     // geometry
@@ -342,6 +344,7 @@ struct Plan {
     float* x_in = nullptr;                    // padded predictor input
     float* y_full = nullptr;                  // stage-1 dense predictor output [B][T][out_ch]
     size_t user_in_floats = 0, user_out_floats = 0;
+    int graph_n = -1, last_n = -1;            // convert mode: n_frames the graph was captured for / of the previous call
     const float* cur_in = nullptr;            // where the forward reads the caller's block (staging, or the caller's device buffer)
     float* cur_out = nullptr;                 // where it writes the result
 #ifndef RY_HOST_EMU
@@ -449,6 +452,7 @@ static void tile_dims(int tile, int* bm, int* bn) {
         case TILE_64x128: *bm = 64; *bn = 128; break;
         case TILE_128x64: *bm = 128; *bn = 64; break;
         case TILE_96x128: *bm = 96; *bn = 128; break;
+        case TILE_256x128: *bm = 256; *bn = 128; break;
         default: *bm = 32; *bn = 128; break;
     }
 }
@@ -460,11 +464,13 @@ static const char* tile_name(int tile) {
         case TILE_64x128: return "ry_igemm_f32<64,128>";
         case TILE_128x64: return "ry_igemm_f32<128,64>";
         case TILE_96x128: return "ry_igemm_f32<96,128>";
+        case TILE_256x128: return "ry_igemm_f32<256,128>";
         default: return "ry_igemm_f32<32,128>";
     }
 }
 
 static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
+static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
 static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
 static unsigned long long* g_dbg = nullptr;
@@ -500,6 +506,7 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
         if (l.cout % 128 != 0) *tile = g_tile64;
         else if (M <= 32) *tile = TILE_32x128;
         else if (M <= 64) *tile = TILE_64x128;
+        else if (g_bigtile && M >= 2048) *tile = TILE_256x128;
         else {
             const int cand[3] = {TILE_128x128, TILE_96x128, TILE_64x128};
             const double bias[3] = {0.0, -0.02, -0.08};                   // smaller tiles re-read more B per flop
@@ -556,6 +563,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             case TILE_64x128: RY_IGEMM_LAUNCH(64, 128, 1, 4, 32); break;
             case TILE_128x64: RY_IGEMM_LAUNCH(128, 64, 4, 1, 32); break;
             case TILE_96x128: RY_IGEMM_LAUNCH(96, 128, 1, 4, 32); break;
+            case TILE_256x128: RY_IGEMM_LAUNCH(256, 128, 2, 2, 32); break;
             default: RY_IGEMM_LAUNCH(32, 128, 1, 4, 32); break;
         }
 #undef RY_IGEMM_LAUNCH
@@ -722,7 +730,7 @@ static int build_plan(ry_net* net, Plan& P) {
                     if (l.src_a < 0 && l.cin() == 1 && l.cout % 4 == 0) lp.path = PATH_FIRST;
                     if (i == 15 && l.cout == 1 && l.cin() % 128 == 0 && l.cin_a % 4 == 0) {
                         lp.path = PATH_LAST;      // exp / edge-pad / crop of SuperResolution.convert fused into the last layer
-                        lp.last_rows = P.mode == 1 ? P.n_frames : lp.Ho;
+                        lp.last_rows = lp.Ho;             // convert mode: overwritten with n_frames at enqueue time
                         lp.last_cols = P.mode == 1 ? lp.Wo + 1 : lp.Wo;
                         lp.last_exp = P.mode == 1;
                     }
@@ -733,7 +741,7 @@ static int build_plan(ry_net* net, Plan& P) {
     // staging
     const int cin_user = nd == 1 ? d.in_ch : (P.mode == 1 ? d.width + 1 : d.width);
     const int cout_user = nd == 1 ? d.out_ch : (P.mode == 1 ? d.width + 1 : d.width);
-    const int rows_user = P.mode == 1 ? P.n_frames : P.T;
+    const int rows_user = P.T;                 // convert mode: any n_frames < T shares this plan
     P.user_in_floats = (size_t)B * rows_user * cin_user;
     P.user_out_floats = (size_t)B * rows_user * cout_user;
     RY_TRY(P.arena.alloc(&P.user_in, P.user_in_floats));
@@ -797,6 +805,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
             const float* s2 = l.src_b >= 0 ? P.lp[l.src_b].out : nullptr;
             LayerPlan lq = lp;
             if (i == 15 && (P.mode == 0 || lp.path == PATH_LAST)) lq.out = P.cur_out;   // last layer writes the caller's block
+            if (i == 15 && P.mode == 1 && lp.path == PATH_LAST) lq.last_rows = P.n_frames;
             RY_TRY(launch_conv2d(Lc, l, lq, B, s1, l.cin_a, s2, l.cin_b, slope));
         }
     }
@@ -832,7 +841,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
 
 static int get_plan(ry_net* net, int B, int T, int mode, int n_frames, Plan** out) {
     if (B < 1 || T < 1) return fail(RY_EINVAL, "batch and frames must be positive (got %d, %d)", B, T);
-    auto key = std::make_tuple(B, T, mode, n_frames);
+    auto key = std::make_tuple(B, T, mode, 0);        // convert-mode plans are shared by every n_frames with the same padded length
     auto it = net->plans.find(key);
     if (it == net->plans.end()) {
         if (net->plans.size() >= 16) net->plans.clear();       // bounded cache
@@ -841,6 +850,7 @@ static int get_plan(ry_net* net, int B, int T, int mode, int n_frames, Plan** ou
         RY_TRY(build_plan(net, *P));
         it = net->plans.emplace(key, std::move(P)).first;
     }
+    it->second->n_frames = n_frames;
     *out = it->second.get();
     return RY_OK;
 }
@@ -848,7 +858,8 @@ static int get_plan(ry_net* net, int B, int T, int mode, int n_frames, Plan** ou
 static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_device) {
     ry_ctx* ctx = net->ctx;
     RT_TRY(rt::set_device(ctx->device));
-    const size_t in_bytes = P.user_in_floats * sizeof(float), out_bytes = P.user_out_floats * sizeof(float);
+    const int rows_now = P.mode == 1 ? P.n_frames : P.T;
+    const size_t in_bytes = P.user_in_floats / P.T * rows_now * sizeof(float), out_bytes = P.user_out_floats / P.T * rows_now * sizeof(float);
     // device callers: kernels read / write the caller's buffers directly (no staging copies); the graph is
     // re-captured only when those addresses change.  host callers: pinned-size staging buffers of the plan.
     const float* want_in = on_device ? x : P.user_in;
@@ -863,8 +874,17 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
     if (!on_device) RT_TRY(rt::h2d(P.user_in, x, in_bytes, net->stream));
     Launcher Lc{net, ctx, net->stream, nullptr, nullptr};
 #ifndef RY_HOST_EMU
-    if (net->use_graph && !P.graph_tried) {
+    // the captured graph bakes n_frames into the wrapper kernels: replay only for the same n; a new n runs eagerly once and is
+    // captured when it repeats (live windows have a constant n; windows cut by the silence gate vary)
+    if (P.gexec && P.graph_n != P.n_frames) {
+        if (P.last_n == P.n_frames) { hipGraphExecDestroy(P.gexec); P.gexec = nullptr; P.graph_tried = false; }
+    }
+    const bool replay_ok = P.gexec && P.graph_n == P.n_frames;
+    const bool capture_now = net->use_graph && !P.graph_tried && (P.mode == 0 || P.last_n == P.n_frames || P.last_n < 0);
+    P.last_n = P.n_frames;
+    if (capture_now) {
         P.graph_tried = true;
+        P.graph_n = P.n_frames;
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(net->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int r = enqueue_forward(net, P, Lc);
@@ -877,7 +897,7 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
             if (r != RY_OK) return r;
         }
     }
-    if (P.gexec) {
+    if (P.gexec && (replay_ok || P.graph_n == P.n_frames)) {
         RT_TRY(hipGraphLaunch(P.gexec, net->stream));
     } else
 #endif
@@ -991,6 +1011,7 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
     if (const char* e = getenv("RY_ILV")) g_ilv = atoi(e);
     if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
     if (const char* e = getenv("RY_TILE2D")) g_tile2d = atoi(e);
+    if (const char* e = getenv("RY_BIGTILE")) g_bigtile = atoi(e);
 #ifndef RY_HOST_EMU
     if (g_timing && !g_dbg) {
         RT_TRY(hipMalloc((void**)&g_dbg, 8 * sizeof(unsigned long long)));
@@ -1095,6 +1116,131 @@ int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat*
     return RY_OK;
 }
 
+// ---- device-resident VoiceChanger core -----------------------------------------------------------
+}  // extern "C"
+
+struct ry_vc {
+    ry_net* s1 = nullptr;
+    ry_net* s2 = nullptr;
+    int M = 0, F = 0;
+    Arena arena;
+    float* d_mtx = nullptr;
+    // per-shape buffers (re-allocated when a larger window arrives)
+    Arena bufs;
+    int cap_eff = 0, cap_frames = 0;
+    float *d_x = nullptr, *d_y1 = nullptr, *d_mc = nullptr, *d_sp = nullptr, *d_out = nullptr;
+    int* d_row = nullptr;
+    rt::Event ev;
+    bool has_ev = false;
+};
+
+static int vc_reserve(ry_vc* vc, int n_eff, int n_frames) {
+    if (n_eff <= vc->cap_eff && n_frames <= vc->cap_frames) return RY_OK;
+    rt::stream_sync(vc->s1->stream); rt::stream_sync(vc->s2->stream);
+    vc->bufs.release();
+    const int ce = n_eff > vc->cap_eff ? n_eff : vc->cap_eff, cf = n_frames > vc->cap_frames ? n_frames : vc->cap_frames;
+    const int cin = vc->s1->desc.in_ch;
+    float* rowbuf = nullptr;
+    RY_TRY(vc->bufs.alloc(&vc->d_x, (size_t)(ce > 0 ? ce : 1) * cin));
+    RY_TRY(vc->bufs.alloc(&vc->d_y1, (size_t)(ce > 0 ? ce : 1) * vc->M));
+    RY_TRY(vc->bufs.alloc(&rowbuf, (size_t)(ce > 0 ? ce : 1)));
+    RY_TRY(vc->bufs.alloc(&vc->d_mc, (size_t)cf * vc->M));
+    RY_TRY(vc->bufs.alloc(&vc->d_sp, (size_t)cf * vc->F));
+    RY_TRY(vc->bufs.alloc(&vc->d_out, (size_t)cf * vc->F));
+    vc->d_row = (int*)rowbuf;
+    vc->cap_eff = ce; vc->cap_frames = cf;
+    return RY_OK;
+}
+
+extern "C" {
+
+int ry_vc_create(ry_net* s1, ry_net* s2, const float* mtx, int M, int F, ry_vc** out) {
+    if (!s1 || !s2 || !mtx || !out) return fail(RY_EINVAL, "null argument");
+    *out = nullptr;
+    if (s1->desc.ndim != 1 || s2->desc.ndim != 2) return fail(RY_EINVAL, "ry_vc_create needs (stage-1, stage-2) predictors");
+    if (s1->ctx != s2->ctx) return fail(RY_ESTATE, "both predictors must live in the same context");
+    if (s1->desc.out_ch != M) return fail(RY_EINVAL, "stage-1 returns %d channels but the mc2sp matrix has %d rows", s1->desc.out_ch, M);
+    if (s2->desc.width + 1 != F) return fail(RY_EINVAL, "stage-2 takes %d bins but the mc2sp matrix has %d columns", s2->desc.width + 1, F);
+    RT_TRY(rt::set_device(s1->ctx->device));
+    std::unique_ptr<ry_vc> vc(new ry_vc());
+    vc->s1 = s1; vc->s2 = s2; vc->M = M; vc->F = F;
+    std::vector<float> h(mtx, mtx + (size_t)M * F);
+    RY_TRY(upload(vc->arena, s1->ctx, h, &vc->d_mtx));
+    RT_TRY(rt::event_create(&vc->ev));
+    vc->has_ev = true;
+    *out = vc.release();
+    return RY_OK;
+}
+
+void ry_vc_destroy(ry_vc* vc) {
+    if (!vc) return;
+    rt::set_device(vc->s1->ctx->device);
+    rt::stream_sync(vc->s1->stream); rt::stream_sync(vc->s2->stream);
+    if (vc->has_ev) rt::event_destroy(vc->ev);
+    delete vc;
+}
+
+int ry_vc_convert(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, int n_frames, float sp_floor,
+                  float* mc_out, float* sp_out) {
+    if (!vc || !mc_out || !sp_out || (n_eff > 0 && (!x_eff || !row_of))) return fail(RY_EINVAL, "null argument");
+    if (n_frames < 1 || n_eff < 0 || n_eff > n_frames) return fail(RY_EINVAL, "bad frame counts (%d effective of %d)", n_eff, n_frames);
+    for (int i = 0; i < n_eff; ++i)
+        if (row_of[i] < 0 || row_of[i] >= n_frames) return fail(RY_EINVAL, "row_of[%d] = %d is outside the window", i, row_of[i]);
+    ry_net *s1 = vc->s1, *s2 = vc->s2;
+    ry_ctx* ctx = s1->ctx;
+    RT_TRY(rt::set_device(ctx->device));
+    RY_TRY(vc_reserve(vc, n_eff, n_frames));
+    const int cin = s1->desc.in_ch, M = vc->M, F = vc->F;
+    ry_stream_t st1 = s1->stream;
+    Launcher Lc{s1, ctx, st1, nullptr, nullptr};
+    RT_TRY(rt::dmemset(vc->d_mc, 0, (size_t)n_frames * M * sizeof(float), st1));      // silent frames: zeros (AcousticFeature.silent)
+    if (n_eff > 0) {
+        RT_TRY(rt::h2d(vc->d_x, x_eff, (size_t)n_eff * cin * sizeof(float), st1));
+        RT_TRY(rt::h2d(vc->d_row, row_of, (size_t)n_eff * sizeof(int), st1));
+        RY_TRY(ry_ac_convert(s1, vc->d_x, vc->d_y1, 1, n_eff, 1));                     // stage-1 CNN on the effective frames
+        RyScatterParams sc;
+        sc.src = vc->d_y1; sc.row_of = vc->d_row; sc.dst = vc->d_mc; sc.n_src = n_eff; sc.cols = M;
+        dim3 sg((unsigned)(((long long)n_eff * M + 255) / 256));
+        RY_TRY(Lc.begin("ry_scatter_rows", "combine_silent", 0, 0, sg));
+        RY_LAUNCH(ry_scatter_rows, sg, 256, st1, sc);
+        RY_TRY(Lc.end());
+    }
+    RyMc2spParams mp;
+    mp.mc = vc->d_mc; mp.mtx = vc->d_mtx; mp.sp = vc->d_sp; mp.n = n_frames; mp.m = M; mp.f = F; mp.floor = sp_floor;
+    dim3 mg((unsigned)(((long long)n_frames * F + 255) / 256));
+    RY_TRY(Lc.begin("ry_mc2sp", "decode_spectrogram", 0, 0, mg));
+    RY_LAUNCH(ry_mc2sp, mg, 256, st1, mp);
+    RY_TRY(Lc.end());
+    RT_TRY(rt::d2h(mc_out, vc->d_mc, (size_t)n_frames * M * sizeof(float), st1));
+    RT_TRY(rt::event_record(vc->ev, st1));
+    RT_TRY(rt::stream_wait_event(s2->stream, vc->ev));                                  // stage-2 starts when the spectrogram is ready
+    RY_TRY(ry_sr_convert(s2, vc->d_sp, vc->d_out, 1, n_frames, 1));
+    RT_TRY(rt::d2h(sp_out, vc->d_out, (size_t)n_frames * F * sizeof(float), s2->stream));
+    RT_TRY(rt::stream_sync(st1));
+    RT_TRY(rt::stream_sync(s2->stream));
+    return RY_OK;
+}
+
+int ry_mc2sp(ry_ctx* ctx, const float* mc, const float* mtx, int n, int m, int bins, float floor_, float* sp) {
+    if (!ctx || !mc || !mtx || !sp || n < 1 || m < 1 || bins < 1) return fail(RY_EINVAL, "bad argument");
+    RT_TRY(rt::set_device(ctx->device));
+    Arena a;
+    float *dmc = nullptr, *dmtx = nullptr, *dsp = nullptr;
+    RY_TRY(a.alloc(&dmc, (size_t)n * m)); RY_TRY(a.alloc(&dmtx, (size_t)m * bins)); RY_TRY(a.alloc(&dsp, (size_t)n * bins));
+    RT_TRY(rt::h2d(dmc, mc, (size_t)n * m * sizeof(float), ctx->stream));
+    RT_TRY(rt::h2d(dmtx, mtx, (size_t)m * bins * sizeof(float), ctx->stream));
+    RyMc2spParams mp;
+    mp.mc = dmc; mp.mtx = dmtx; mp.sp = dsp; mp.n = n; mp.m = m; mp.f = bins; mp.floor = floor_;
+    dim3 mg((unsigned)(((long long)n * bins + 255) / 256));
+    Launcher Lc{nullptr, ctx, ctx->stream, nullptr, nullptr};
+    RY_TRY(Lc.begin("ry_mc2sp", "decode_spectrogram", 0, 0, mg));
+    RY_LAUNCH(ry_mc2sp, mg, 256, ctx->stream, mp);
+    RY_TRY(Lc.end());
+    RT_TRY(rt::d2h(sp, dsp, (size_t)n * bins * sizeof(float), ctx->stream));
+    RT_TRY(rt::stream_sync(ctx->stream));
+    return RY_OK;
+}
+
 // diagnostics: read and reset the phase totals of the RY_TIMING=1 kernel variant (8 counters)
 int ry_debug_igemm_phases(ry_ctx* ctx, unsigned long long* out8) {
     if (!ctx || !out8) return fail(RY_EINVAL, "null argument");
@@ -1189,7 +1335,7 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
         const TapTable t = make_taps(l);
         const int M = B * (transposed ? H * Wd : lp.Ho * lp.Wo);
         lp.tile = tile; lp.splits = splits;
-        if (tile < 0 || tile > TILE_96x128) return fail(RY_EINVAL, "unknown tile");
+        if (tile < 0 || tile > TILE_256x128) return fail(RY_EINVAL, "unknown tile");
         if ((tile == TILE_256x64 || tile == TILE_128x64) ? Cout % 64 : (tile != 0 && Cout % 128)) return fail(RY_EINVAL, "tile does not divide Cout");
         choose_igemm(l, M, t.nphases, t.ntaps * (Cin / 32), &lp.tile, &lp.splits);
         if (lp.splits > 1) RY_TRY(arena.alloc(&lp.slabs, out_elems * lp.splits));

@@ -49,6 +49,15 @@ class Context(object):
             self.lib.dll.ry_shutdown(self.handle)
         self.handle = None
 
+    def mc2sp(self, mc, mtx, floor: float = 0.0):
+        """`decode_spectrogram` on the device: exp(mc (N, M) @ mtx (M, F)) + floor."""
+        mc = numpy.ascontiguousarray(mc, dtype=numpy.float32)
+        mtx = numpy.ascontiguousarray(mtx, dtype=numpy.float32)
+        sp = numpy.empty((mc.shape[0], mtx.shape[1]), dtype=numpy.float32)
+        self.lib.check(self.lib.dll.ry_mc2sp(self.handle, _lib._fptr(mc), _lib._fptr(mtx), mc.shape[0], mc.shape[1], mtx.shape[1],
+                                             float(floor), _lib._fptr(sp)))
+        return sp
+
     # ---- single operators (Chainer layouts in, channels-last activations) ----
     def conv1d(self, x, W, b=None, bn=None, stride=1, pad=0, dilate=1, transposed=False, act=None, splits=0):
         """x (B, L, Cin) -> (B, Lout, Cout).  W (Cout,Cin,k) or transposed (Cin,Cout,k); bn = (gamma,beta,mean,var)."""
@@ -83,6 +92,40 @@ class Context(object):
                                               Cout, k, stride, pad, int(bool(transposed)), _lib.ACTS[act], pth, _lib.TILES[tile],
                                               int(splits), _lib._fptr(y)))
         return y
+
+
+class VcCore(object):
+    """Device-resident core of `VoiceChanger.convert_from_acoustic_feature`: stage-1 on the effective frames ->
+    scatter into the silent block -> mc2sp (exp(mc @ M)) -> + floor -> stage-2, one H2D and one D2H per window (`ry_vc_convert`)."""
+
+    def __init__(self, stage1: 'Net', stage2: 'Net', mtx: numpy.ndarray):
+        self.stage1, self.stage2 = stage1, stage2
+        self.lib = stage1.ctx.lib
+        mtx = numpy.ascontiguousarray(mtx, dtype=numpy.float32)
+        self.M, self.F = mtx.shape
+        h = ctypes.c_void_p()
+        self.lib.check(self.lib.dll.ry_vc_create(stage1.handle, stage2.handle, _lib._fptr(mtx), self.M, self.F, ctypes.byref(h)))
+        self.handle = h
+
+    def convert(self, x_eff: numpy.ndarray, effective: numpy.ndarray, sp_floor: float = 1e-16):
+        """x_eff (n_eff, in_ch) = features of the effective frames, effective (n_frames,) bool -> (mc (n_frames, M), sp (n_frames, F))."""
+        effective = numpy.asarray(effective, dtype=bool)
+        n = int(effective.size)
+        rows = numpy.ascontiguousarray(numpy.nonzero(effective)[0], dtype=numpy.int32)
+        x_eff = numpy.ascontiguousarray(x_eff, dtype=numpy.float32)
+        if len(rows):
+            x_eff = x_eff.reshape(len(rows), -1)
+        mc = numpy.empty((n, self.M), dtype=numpy.float32)
+        sp = numpy.empty((n, self.F), dtype=numpy.float32)
+        self.lib.check(self.lib.dll.ry_vc_convert(self.handle, _lib._fptr(x_eff) if len(rows) else _lib._fptr(None),
+                                                  rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), len(rows), n, float(sp_floor),
+                                                  _lib._fptr(mc), _lib._fptr(sp)))
+        return mc, sp
+
+    def close(self):
+        if self.handle is not None and self.stage1.ctx.handle is not None and self.stage1.ctx.pid == os.getpid():
+            self.lib.dll.ry_vc_destroy(self.handle)
+        self.handle = None
 
 
 _contexts: Dict = {}

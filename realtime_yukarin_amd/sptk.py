@@ -49,3 +49,32 @@ def mc2sp(mc: numpy.ndarray, alpha: float, fftlen: int) -> numpy.ndarray:
     symc[:, 1:c.shape[1]] = c[:, 1:]
     symc[:, -1:-c.shape[1]:-1] = c[:, 1:]
     return numpy.exp(numpy.fft.rfft(symc, axis=1).real)
+
+
+_MATRIX_CACHE = {}
+
+
+def mc2sp_matrix(order: int, alpha: float, fftlen: int) -> numpy.ndarray:
+    """(order+1, fftlen/2+1) float64 matrix M with mc2sp(mc) == exp(mc @ M).
+
+    Every step of mc2sp before the exp is linear in the mel-cepstrum (freqt is a linear recursion, then c0 *= 2, the
+    symmetric extension and the real part of the rfft), so M is mc2sp's linear part applied to the identity.  This is
+    what lets `decode_spectrogram` run on the GPU between the two CNNs as one small matmul + exp (`ry_mc2sp`)."""
+    key = (int(order), float(alpha), int(fftlen))
+    m = _MATRIX_CACHE.get(key)
+    if m is None:
+        c = freqt(numpy.eye(order + 1), fftlen // 2, -alpha)
+        c[:, 0] *= 2.0
+        symc = numpy.zeros((order + 1, fftlen))
+        symc[:, 0] = c[:, 0]
+        symc[:, 1:c.shape[1]] = c[:, 1:]
+        symc[:, -1:-c.shape[1]:-1] = c[:, 1:]
+        m = numpy.fft.rfft(symc, axis=1).real
+        _MATRIX_CACHE[key] = m
+    return m
+
+
+def mc2sp_fast(mc: numpy.ndarray, alpha: float, fftlen: int) -> numpy.ndarray:
+    """Host form of the same identity (float64): exp(mc @ M); ~100x cheaper than the recursion per window."""
+    mc = numpy.asarray(mc, dtype=numpy.float64)
+    return numpy.exp(mc @ mc2sp_matrix(mc.shape[1] - 1, alpha, fftlen))

@@ -29,10 +29,44 @@ class VoiceChanger(object):
         f_out.sp += SP_FLOOR
         return f_out
 
+    def _fused_core(self):
+        """`engine.VcCore` when both converters are the MI355X shims in their canonical (mc -> mc) configuration."""
+        ac, sr = self.acoustic_converter, self.super_resolution
+        if not (hasattr(ac, 'fusable') and hasattr(sr, '_get_net') and ac.fusable()):
+            return None
+        import os
+        from . import engine
+        key = os.getpid()
+        if getattr(self, '_core_pid', None) != key:
+            mtx = ac.mc2sp_matrix()
+            self._core = engine.VcCore(ac._get_net(), sr._get_net(mtx.shape[1]), mtx)
+            self._core_pid = key
+        return self._core
+
     def convert_from_acoustic_feature(self, f_in):
-        f_out = self._stage1(f_in)
-        f_out.sp = self.super_resolution.convert(f_out.sp.astype(numpy.float32))
+        core = self._fused_core()
+        if core is None:                       # generic path: the reference's step order, one call per step
+            f_out = self._stage1(f_in)
+            f_out.sp = self.super_resolution.convert(f_out.sp.astype(numpy.float32))
+            return f_out
+        # device-resident path: silence mask on the host (it reads the raw wave), everything else in one ry_vc_convert
+        ac = self.acoustic_converter
+        f_eff, effective = ac.separate_effective(wave=f_in.wave, feature=f_in, threshold=self.threshold)
+        mc, sp = core.convert(numpy.asarray(f_eff.mc, dtype=numpy.float32), effective, SP_FLOOR)
+        f_out = ac.combine_silent(effective=effective, feature=self._passthrough(f_eff))
+        f_out.mc = mc
+        f_out.sp = sp
         return f_out
+
+    def _passthrough(self, f_eff):
+        """f0 through the F0Converter, ap / voiced untouched -- what `AcousticConverter.convert` returns besides mc."""
+        ac = self.acoustic_converter
+        from yukarin.acoustic_feature import AcousticFeature
+        n = len(f_eff.f0)
+        f0 = f_eff.f0
+        if n and ac.f0_converter is not None:
+            f0 = ac.f0_converter.convert(f_eff).f0
+        return AcousticFeature(f0=f0, ap=f_eff.ap, voiced=f_eff.voiced, mc=numpy.zeros((n, ac.desc.out_ch), numpy.float32))
 
     def convert_windows(self, f_ins: List) -> List:
         """Independent windows: stage-1 per window (its length is data dependent after the silence split),

@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
 tail -15 gpurun_out/pytest_gpu.log
 show() { python -c "
-import json,sys; d=json.load(open(sys.argv[1])); print({k:d[k] for k in ('value','ms_per_step','x_realtime','stage_ms','graph_replay_ms')}); print(d.get('roofline')); print(d.get('roofline_stage1')); print(d['kernels'])" $1; }
+import json,sys; d=json.load(open(sys.argv[1])); print({k:d[k] for k in ('value','ms_per_step','x_realtime','stage_ms','graph_replay_ms','host_call_ms_per_window')}); print(d.get('roofline')); print(d.get('roofline_stage1')); print(d['kernels'])" $1; }
 timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --layers-out gpurun_out/layers_n300.txt > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?"
 show gpurun_out/bench.json
 true

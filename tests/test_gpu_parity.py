@@ -113,6 +113,33 @@ def test_stage2_syn64_forward_400_frames(syn64):
     assert rel_max(y, r) < cases.TOL
 
 
+def test_device_resident_voice_changer_core(syn64):
+    """stage-1 -> combine_silent -> mc2sp -> +1e-16 -> stage-2 in one `ry_vc_convert` against the
+    step-by-step composition: torch oracle CNNs + the freqt/rfft restatement of pysptk.mc2sp (float64)."""
+    from realtime_yukarin_amd import sptk
+    (n1, t1), (n2, t2) = syn64
+    n = 300
+    rng = numpy.random.default_rng(99)
+    effective = rng.random(n) > 0.25
+    x = synth.stage1_input(n)[0]
+    alpha = sptk.mcepalpha(16000)
+    core = engine.VcCore(n1, n2, sptk.mc2sp_matrix(8, alpha, 1024))
+    mc, sp = core.convert(x[effective], effective)
+    mc_ref = numpy.zeros((n, synth.MC_DIMS), numpy.float32)
+    mc_ref[effective] = torch_ref.stage1_convert_core(t1, x[effective])
+    assert rel_max(mc, mc_ref) < cases.TOL and not mc[~effective].any()
+    sp_mid = (sptk.mc2sp(mc_ref, alpha, 1024) + 1e-16).astype(numpy.float32)
+    sp_ref = torch_ref.stage2_convert(t2, sp_mid)
+    assert float(numpy.abs(sp / sp_ref - 1).max()) < cases.TOL
+    # repeated calls with a varying number of effective frames (graph re-use / eager switching) stay consistent
+    for keep in (0.9, 0.5, 0.9, 0.9):
+        eff = rng.random(n) < keep
+        mc2, _ = core.convert(x[eff], eff)
+        ref2 = numpy.zeros_like(mc_ref); ref2[eff] = torch_ref.stage1_convert_core(t1, x[eff])
+        assert rel_max(mc2, ref2) < cases.TOL
+    core.close()
+
+
 def test_errors_are_reported_not_fatal(gpu_ctx):
     d = NetDesc(1, 9, 9, 8, 8)
     P = synthetic_params(d, 1)

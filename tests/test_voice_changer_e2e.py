@@ -95,6 +95,17 @@ def check(out, exp, feat):
     assert 0 < exp['eff'].sum() < N
 
 
+def test_device_mc2sp_matches_the_sptk_recursion(emu_ctx):
+    """`decode_spectrogram`: exp(mc @ M) on the device vs the freqt / rfft restatement of pysptk.mc2sp."""
+    rng = numpy.random.default_rng(3)
+    mc = (rng.normal(size=(37, 9)) * [4, 1, .5, .5, .3, .3, .2, .2, .2]).astype(numpy.float32)
+    alpha = sptk.mcepalpha(FS)
+    ref = sptk.mc2sp(mc, alpha, 1024)
+    got = emu_ctx.mc2sp(mc, sptk.mc2sp_matrix(8, alpha, 1024))
+    assert got.shape == (37, 513) and float(numpy.abs(got / ref - 1).max()) < 5e-5
+    assert float(numpy.abs(sptk.mc2sp_fast(mc, alpha, 1024) / ref - 1).max()) < 1e-12
+
+
 def test_mirror_voice_changer_end_to_end(models, on_emulator):
     from realtime_yukarin_amd.voice_changer import VoiceChanger
     from yukarin import AcousticFeature
@@ -109,6 +120,19 @@ def test_mirror_voice_changer_end_to_end(models, on_emulator):
     assert vc.output_sampling_rate == FS
     out = vc.convert_from_acoustic_feature(f_in)
     check(out, expected(models, ac, wave, feat), feat)
+    # the generic (step-by-step) path and the device-resident fused path agree
+    assert vc._fused_core() is not None
+    vc2 = VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60)
+    vc2._fused_core = lambda: None
+    f_gen = Wrapped(**{k: v.copy() for k, v in feat.items()}); f_gen.wave = wave
+    gen = vc2.convert_from_acoustic_feature(f_gen)
+    assert float(numpy.abs(gen.sp / out.sp - 1).max()) < 2e-5 and numpy.allclose(gen.mc, out.mc, rtol=1e-6, atol=1e-7)
+    assert numpy.array_equal(gen.f0, out.f0) and numpy.array_equal(gen.ap, out.ap) and numpy.array_equal(gen.voiced, out.voiced)
+    # no effective frame at all: the stage-1 CNN is skipped (voice_changer.py:32-35): mc = 0, sp = SuperResolution(exp(0) + 1e-16)
+    mc0, sp0 = vc._fused_core().convert(numpy.zeros((0, 9), numpy.float32), numpy.zeros(N, bool))
+    assert not mc0.any() and sp0.shape == (N, 513)
+    ones = numpy.ones((N, 513), numpy.float32)
+    assert float(numpy.abs(sp0 / unet.stage2_convert(ones, models[2][1]) - 1).max()) < 1e-4
     # two windows in one batched stage-2 call give the same answer
     f_a = Wrapped(**{k: v.copy() for k, v in feat.items()}); f_a.wave = wave
     f_b = Wrapped(**{k: v.copy() for k, v in feat.items()}); f_b.wave = wave
