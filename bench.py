@@ -34,6 +34,7 @@ def parse():
     ap.add_argument('--frames', type=int, default=300, help='real frames per window (N)')
     ap.add_argument('--windows', type=int, default=1, help='windows per GPU per step')
     ap.add_argument('--model', default='SYN-64')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help="stage-2 MFMA operand type ('bf16' = BASELINE config #5; accumulation and activations stay fp32)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--profile-reps', type=int, default=5)
@@ -97,6 +98,8 @@ def main():
     net1 = rdist.make_net(ctx, d1, rdist.broadcast_blob(d1, P1, dev))
     net2 = rdist.make_net(ctx, d2, rdist.broadcast_blob(d2, P2, dev), width=synth.FFT_BINS - 1)
     del P1, P2
+    if args.dtype == 'bf16':
+        net2.set_dtype('bf16')
 
     # ---- synthetic windows, resident in HBM before the timed region (different data per rank)
     x1 = torch.from_numpy(synth.stage1_input(N, Wn, seed=synth.SEED_INPUT + 10 * rank)).to(dev)
@@ -182,7 +185,7 @@ def main():
         'metric': 'acoustic frames/s (stage1+stage2 fwd) @16kHz/5ms',
         'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'x_realtime': round(value * 0.005, 1), 'x_realtime_per_gpu': round(value * 0.005 / world, 1),
         'device_ms_per_step_rank0': round(dev_ms / args.steps, 4),
         'graph_replay_ms': {'stage1_alone': round(s1_ms, 4), 'stage2_alone': round(s2_ms, 4)},
@@ -213,8 +216,9 @@ def main():
         dname, dv = dom
         ach = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(dname)
-        out['roofline'] = {'kernel': dname, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                           'frac': round(ach / F32_MFMA_PEAK_TF, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
+        peak_tf = 2500.0 if 'bf16' in dname else F32_MFMA_PEAK_TF      # dense bf16 MFMA peak / fp32-input MFMA peak
+        out['roofline'] = {'kernel': dname, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
+                           'frac': round(ach / peak_tf, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
                            'traffic_source': traffic_src,
                            'launches': dv['launches'], 'avg_launch_ms': round(dv['ms'] / dv['launches'], 4),
                            'alg_flops_per_launch': dv['flops'] / dv['launches']}

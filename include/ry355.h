@@ -68,6 +68,10 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
                   int weights_on_device, ry_net** out);
 void ry_net_destroy(ry_net* net);
 
+/* BASELINE config #5: dtype 1 runs the stage-2 implicit-GEMM layers with bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate,
+ * fp32 activations in HBM; filters converted once).  dtype 0 (default) is exact fp32.  Tolerance of the bf16 variant: DESIGN.md. */
+int ry_net_set_dtype(ry_net* net, int dtype);
+
 /* `Predictor.__call__` / `SRPredictor.__call__` on an already padded block (frames % 128 == 0 when
  * extensive_layers == 8).  stage-1: x [batch][frames][in_ch] -> y [batch][frames][out_ch];
  * stage-2: x [batch][frames][width] -> y [batch][frames][width]. */
@@ -88,7 +92,7 @@ int ry_sr_convert(ry_net* stage2, const float* sp, float* out, int batch, int n_
 int ry_conv1d(ry_ctx* ctx, const float* x, int B, int L, int Cin, const float* W, const float* bias, const float* bn,
               int Cout, int k, int stride, int pad, int dilate, int transposed, int act, int splits, float* y);
 /* L.Convolution2D / L.Deconvolution2D.  x [B][H][W][Cin] -> y [B][Ho][Wo][Cout].  path: 0 auto, 1 implicit-GEMM (MFMA),
- * 2 direct (VALU), 3 SR first layer (1 -> N, 3x3), 4 SR last layer (C -> 1, 3x3, channels read as two sources); tile: 0 auto, 1 = 128x128, 2 = 256x64, 3 = 64x128, 4 = 32x128, 5 = 128x64, 6 = 96x128, 7 = 256x128. */
+ * 2 direct (VALU), 3 SR first layer (1 -> N, 3x3), 4 SR last layer (C -> 1, 3x3, channels read as two sources), 5 implicit-GEMM with bf16 operands; tile: 0 auto, 1 = 128x128, 2 = 256x64, 3 = 64x128, 4 = 32x128, 5 = 128x64, 6 = 96x128, 7 = 256x128. */
 int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int W, int Cin, const float* Wt, const float* bias, const float* bn,
               int Cout, int k, int stride, int pad, int transposed, int act, int path, int tile, int splits, float* y);
 

@@ -23,7 +23,7 @@ TILES = {None: 0, 'auto': 0, '128x128': 1, '256x64': 2, '64x128': 3, '32x128': 4
 # every symbol include/ry355.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     'ry_init', 'ry_shutdown', 'ry_sync', 'ry_stream', 'ry_device_count', 'ry_last_error',
-    'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_forward',
+    'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_set_dtype', 'ry_net_forward',
     'ry_ac_convert', 'ry_sr_convert', 'ry_conv1d', 'ry_conv2d',
     'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_debug_igemm_phases',
     'ry_vc_create', 'ry_vc_destroy', 'ry_vc_convert', 'ry_mc2sp',
@@ -82,6 +82,7 @@ class Ry355Lib(object):
         d.ry_net_param_count.restype = ctypes.c_size_t
         d.ry_net_create.argtypes = [_VP, ctypes.POINTER(RyNetDesc), _FP, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(_VP)]
         d.ry_net_destroy.argtypes = [_VP]
+        d.ry_net_set_dtype.argtypes = [_VP, ctypes.c_int]
         d.ry_net_destroy.restype = None
         d.ry_net_forward.argtypes = [_VP, _FP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         d.ry_ac_convert.argtypes = [_VP, _FP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int]

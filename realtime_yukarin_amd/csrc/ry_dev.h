@@ -23,6 +23,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 RY_DEV f32x16 ry_mfma_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ry_bf16x8 __attribute__((ext_vector_type(8)));
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+j] and B[k=8*(l>>5)+j][n=l&31], j = 0..7 (bf16 bit
+// patterns); C/D map as the fp32 form; products accumulate in fp32.
+RY_DEV f32x16 ry_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ry_bf16x8, a), __builtin_bit_cast(ry_bf16x8, b), c, 0, 0, 0);
+}
+RY_DEV unsigned short ry_f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }   // v_cvt_pk_bf16_f32 (RNE)
 RY_DEV float ry_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 RY_DEV float ry_shfl(float v, int src) { return __shfl(v, src, 64); }
 RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }

@@ -157,6 +157,7 @@ struct Layer {
     float* w1d = nullptr;                // stage-1 [Ctot][N][4]
     float* wig = nullptr;                // stage-2 implicit-GEMM [phase][N][tap][Ctot]
     float* wdir = nullptr;               // stage-2 direct [phase][tap][Ctot][N]
+    float* wig16 = nullptr;              // stage-2 implicit-GEMM bf16 [phase][N/64][tap][Ctot/64][64][64] (ry_net_set_dtype)
     int cin() const { return cin_a + cin_b; }
 };
 
@@ -314,7 +315,7 @@ static bool igemm_eligible(const Layer& l) {
 // ------------------------------------------------------------------------------------------------
 // per-layer launch plans
 // ------------------------------------------------------------------------------------------------
-enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4 };
+enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4, PATH_IGEMM_BF16 = 5 };
 enum { TILE_128x128 = 1, TILE_256x64 = 2, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5, TILE_96x128 = 6, TILE_256x128 = 7 };
 
 struct LayerPlan {
@@ -361,6 +362,7 @@ struct KernelRec {           // filled by the launch helpers when profiling
 };
 
 struct ry_net {
+    int dtype = 0;                           // 0 = fp32 MFMA, 1 = bf16 operands (fp32 accumulate) for the stage-2 implicit-GEMM layers
     ry_ctx* ctx = nullptr;
     ry_stream_t stream = nullptr;            // each predictor enqueues on its own stream: stage-1 of one window overlaps stage-2 of another
     rt::Event done;                          // recorded after the last enqueue; ry_sync / ry_timer_stop wait on it
@@ -457,6 +459,16 @@ static void tile_dims(int tile, int* bm, int* bn) {
     }
 }
 
+static const char* tile_name16(int tile) {
+    switch (tile) {
+        case TILE_128x128: return "ry_igemm_bf16<128,128>";
+        case TILE_96x128: return "ry_igemm_bf16<96,128>";
+        case TILE_64x128: return "ry_igemm_bf16<64,128>";
+        case TILE_128x64: return "ry_igemm_bf16<128,64>";
+        default: return "ry_igemm_bf16<32,128>";
+    }
+}
+
 static const char* tile_name(int tile) {
     switch (tile) {
         case TILE_128x128: return "ry_igemm_f32<128,128>";
@@ -531,9 +543,10 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     RyConvGeom g;
     fill_geom(g, l, lp, B, s1, C1, s2, C2);
     const int M = B * g.Mh * g.Mw;
-    if (lp.path == PATH_IGEMM) {
+    if (lp.path == PATH_IGEMM || lp.path == PATH_IGEMM_BF16) {
+        const bool bf16 = lp.path == PATH_IGEMM_BF16;
         RyIgemmParams p;
-        p.g = g; p.wt = l.wig; p.scale = l.scale; p.shift = l.shift;
+        p.g = g; p.wt = bf16 ? l.wig16 : l.wig; p.scale = l.scale; p.shift = l.shift;
         p.splits = lp.splits; p.act = l.act; p.slope = slope;
         p.slab_stride = (long long)B * lp.Ho * lp.Wo * l.cout;
         p.out = lp.splits > 1 ? lp.slabs : lp.out;
@@ -547,7 +560,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         }
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
         dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
-        RY_TRY(Lc.begin(tile_name(lp.tile), l.name, lp.flops, lp.bytes, grid));
+        RY_TRY(Lc.begin(bf16 ? tile_name16(lp.tile) : tile_name(lp.tile), l.name, lp.flops, lp.bytes, grid));
         p.dbg = g_dbg;
 #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
     do {                                                                                                    \
@@ -555,6 +568,15 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
         else RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 0>), grid, 256, Lc.stream, p);               \
     } while (0)
+        if (bf16) {
+            switch (lp.tile) {
+                case TILE_128x128: RY_LAUNCH((ry_igemm_bf16<128, 128, 2, 2>), grid, 256, Lc.stream, p); break;
+                case TILE_96x128: RY_LAUNCH((ry_igemm_bf16<96, 128, 1, 4>), grid, 256, Lc.stream, p); break;
+                case TILE_64x128: RY_LAUNCH((ry_igemm_bf16<64, 128, 1, 4>), grid, 256, Lc.stream, p); break;
+                case TILE_128x64: RY_LAUNCH((ry_igemm_bf16<128, 64, 4, 1>), grid, 256, Lc.stream, p); break;
+                default: RY_LAUNCH((ry_igemm_bf16<32, 128, 1, 4>), grid, 256, Lc.stream, p); break;
+            }
+        } else
         switch (lp.tile) {
             case TILE_128x128:
                 RY_IGEMM_LAUNCH(128, 128, 2, 2, 32);
@@ -723,6 +745,10 @@ static int build_plan(ry_net* net, Plan& P) {
                 const int nk = t.ntaps * (l.cin() / 32);
                 lp.path = PATH_IGEMM; lp.tile = 0; lp.splits = 0;
                 choose_igemm(l, M, t.nphases, nk, &lp.tile, &lp.splits);
+                if (net->dtype == 1 && l.wig16 && lp.tile != TILE_256x64 && lp.tile != TILE_256x128) {
+                    lp.path = PATH_IGEMM_BF16;                         // 64-deep K chunks: half as many as the fp32 kernel
+                    if (lp.splits > nk / 2) lp.splits = nk / 2 > 0 ? nk / 2 : 1;
+                }
                 if (lp.splits > 1) RY_TRY(P.arena.alloc(&lp.slabs, out_elems * lp.splits));
             } else {
                 lp.path = PATH_DIRECT; lp.splits = 1;
@@ -1050,6 +1076,48 @@ void ry_net_destroy(ry_net* net) {
     delete net;
 }
 
+static unsigned short host_f2bf(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+int ry_net_set_dtype(ry_net* net, int dtype) {
+    if (!net) return fail(RY_EINVAL, "null argument");
+    if (dtype != 0 && dtype != 1) return fail(RY_EINVAL, "dtype must be 0 (fp32) or 1 (bf16 operands, fp32 accumulate)");
+    if (dtype == 1 && net->desc.ndim != 2) return fail(RY_EINVAL, "the bf16 variant exists for the stage-2 predictor only");
+    ry_ctx* ctx = net->ctx;
+    RT_TRY(rt::set_device(ctx->device));
+    RT_TRY(rt::stream_sync(net->stream));
+    if (dtype == 1) {
+        for (Layer& l : net->layers) {
+            if (!l.wig || l.wig16 || l.cin_a % 64 != 0 || l.cin_b % 64 != 0) continue;
+            const TapTable t = make_taps(l);
+            const int C = l.cin(), N = l.cout;
+            const size_t n = (size_t)t.nphases * N * t.ntaps * C;
+            std::vector<float> w32(n);
+            RT_TRY(rt::d2h(w32.data(), l.wig, n * sizeof(float), ctx->stream));
+            RT_TRY(rt::stream_sync(ctx->stream));
+            // fp32 blocks [..][C/32][64][32]  ->  bf16 blocks [..][C/64][64][64]
+            std::vector<unsigned short> w16(n);
+            const size_t outer = (size_t)t.nphases * (N / 64) * t.ntaps;
+            for (size_t o = 0; o < outer; ++o)
+                for (int c = 0; c < C; ++c)
+                    for (int nl = 0; nl < 64; ++nl)
+                        w16[((o * (C / 64) + c / 64) * 64 + nl) * 64 + c % 64] = host_f2bf(w32[((o * (C / 32) + c / 32) * 64 + nl) * 32 + c % 32]);
+            float* d = nullptr;
+            RY_TRY(net->weights.alloc(&d, (n + 1) / 2));
+            RT_TRY(rt::h2d(d, w16.data(), n * sizeof(unsigned short), ctx->stream));
+            RT_TRY(rt::stream_sync(ctx->stream));
+            l.wig16 = d;
+        }
+    }
+    net->dtype = dtype;
+    net->plans.clear();                              // launch plans (and captured graphs) depend on the kernel choice
+    return RY_OK;
+}
+
 int ry_net_forward(ry_net* net, const float* x, float* y, int batch, int frames, int on_device) {
     if (!net || !x || !y) return fail(RY_EINVAL, "null argument");
     Plan* P = nullptr;
@@ -1327,17 +1395,36 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
     const bool k3 = !transposed && k == 3 && stride == 1 && pad == 1;
     if (path == PATH_FIRST && !(k3 && Cin == 1 && Cout % 4 == 0)) return fail(RY_EINVAL, "'first' path is the 1 -> N (N %% 4 == 0) 3x3 layer");
     if (path == PATH_LAST && !(k3 && Cout == 1 && Cin % 128 == 0)) return fail(RY_EINVAL, "'last' path is the C -> 1 (C %% 128 == 0) 3x3 layer");
+    if (path == PATH_IGEMM_BF16 && !(l.wig && Cin % 64 == 0)) return fail(RY_EINVAL, "bf16 implicit-GEMM path needs Cin %% 64 == 0 and Cout %% 64 == 0");
     lp.path = path ? path : (l.wig ? PATH_IGEMM : PATH_DIRECT);
     const size_t out_elems = (size_t)B * lp.Ho * lp.Wo * Cout;
     lp.splits = 1;
     lp.last_rows = lp.Ho; lp.last_cols = lp.Wo; lp.last_exp = 0;
-    if (lp.path == PATH_IGEMM) {
+    if (lp.path == PATH_IGEMM || lp.path == PATH_IGEMM_BF16) {
         const TapTable t = make_taps(l);
         const int M = B * (transposed ? H * Wd : lp.Ho * lp.Wo);
         lp.tile = tile; lp.splits = splits;
         if (tile < 0 || tile > TILE_256x128) return fail(RY_EINVAL, "unknown tile");
         if ((tile == TILE_256x64 || tile == TILE_128x64) ? Cout % 64 : (tile != 0 && Cout % 128)) return fail(RY_EINVAL, "tile does not divide Cout");
         choose_igemm(l, M, t.nphases, t.ntaps * (Cin / 32), &lp.tile, &lp.splits);
+        if (lp.path == PATH_IGEMM_BF16) {
+            if (lp.tile == TILE_256x64 || lp.tile == TILE_256x128) return fail(RY_EINVAL, "no bf16 instantiation of that tile");
+            const int nk64 = t.ntaps * (Cin / 64);
+            if (lp.splits > nk64) lp.splits = nk64;
+            // bf16 filters of this single layer
+            const size_t n = (size_t)t.nphases * Cout * t.ntaps * Cin;
+            std::vector<float> w32;
+            relayout_igemm(l, Wt, w32);
+            std::vector<unsigned short> w16(n);
+            const size_t outer = (size_t)t.nphases * (Cout / 64) * t.ntaps;
+            for (size_t o = 0; o < outer; ++o)
+                for (int c = 0; c < Cin; ++c)
+                    for (int nl = 0; nl < 64; ++nl)
+                        w16[((o * (Cin / 64) + c / 64) * 64 + nl) * 64 + c % 64] = host_f2bf(w32[((o * (Cin / 32) + c / 32) * 64 + nl) * 32 + c % 32]);
+            RY_TRY(arena.alloc(&l.wig16, (n + 1) / 2));
+            RT_TRY(rt::h2d(l.wig16, w16.data(), n * sizeof(unsigned short), ctx->stream));
+            RT_TRY(rt::stream_sync(ctx->stream));
+        }
         if (lp.splits > 1) RY_TRY(arena.alloc(&lp.slabs, out_elems * lp.splits));
     }
     float* dx = nullptr;

@@ -52,6 +52,40 @@ CONV2D_CASES = [
 ]
 
 
+def bf16_round(a):
+    """float32 -> nearest-even bfloat16 -> float32 (what v_cvt_pk_bf16_f32 does to the operands of the bf16 kernel)."""
+    u = numpy.ascontiguousarray(a, dtype=numpy.float32).view(numpy.uint32).astype(numpy.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return u.astype(numpy.uint32).view(numpy.float32).reshape(numpy.shape(a))
+
+
+# B, H, W, Cin, Cout, k, stride, pad, transposed, act, tile, splits   (bf16-operand implicit GEMM, BASELINE config #5)
+CONV2D_BF16_CASES = [
+    (1, 12, 16, 64, 128, 4, 2, 1, False, 'lrelu', '32x128', 0),
+    (2, 16, 16, 64, 128, 4, 2, 1, False, 'lrelu', '128x128', 1),
+    (1, 32, 64, 64, 128, 4, 2, 1, False, 'relu', '128x128', 2),        # 2-D tiles, split-K
+    (1, 6, 10, 128, 64, 4, 2, 1, True, 'relu', '128x64', 0),           # deconv phases
+    (1, 24, 32, 64, 128, 4, 2, 1, False, None, '96x128', 1),
+    (1, 5, 7, 64, 128, 3, 1, 1, False, None, '64x128', 0),
+]
+
+
+def run_conv2d_bf16(ctx, rng, case, bn_params):
+    """-> (y, oracle on bf16-rounded operands, oracle on fp32 operands)"""
+    B, H, W_, Cin, Cout, k, s, p, tr, act, tile, splits = case
+    x = rng.normal(size=(B, H, W_, Cin)).astype('f4')
+    Wt = rng.normal(0, 0.1, size=(Cin, Cout, k, k) if tr else (Cout, Cin, k, k)).astype('f4')
+    b = rng.normal(0, 0.1, Cout).astype('f4')
+    bn = bn_params(rng, Cout)
+    y = ctx.conv2d(x, Wt, b, bn, stride=s, pad=p, transposed=tr, act=act, path='igemm_bf16', tile=tile, splits=splits)
+    outs = []
+    for xx, ww in ((bf16_round(x), bf16_round(Wt)), (x, Wt)):
+        xn = xx.transpose(0, 3, 1, 2)
+        r = ops.deconv_nd(xn, ww, b, stride=s, pad=p) if tr else ops.conv_nd(xn, ww, b, stride=s, pad=p)
+        outs.append(ops.apply_act(ops.batch_norm_inference(r, *bn), act).transpose(0, 2, 3, 1))
+    return y, outs[0], outs[1]
+
+
 def run_conv1d(ctx, rng, case, bn_params):
     B, L, Cin, Cout, k, s, p, d, tr, act, splits = case
     x = rng.normal(size=(B, L, Cin)).astype('f4')

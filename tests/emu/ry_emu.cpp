@@ -30,6 +30,7 @@ struct State {
     int bar_arrived = 0, bar_gen = 0;
     int wave_arrived[kMaxWaves] = {0}, wave_gen[kMaxWaves] = {0};
     float wa[kMaxWaves][64], wb[kMaxWaves][64];
+    unsigned short wa16[kMaxWaves][64][8], wb16[kMaxWaves][64][8];
     const std::function<void()>* body = nullptr;
 };
 thread_local State* S = nullptr;
@@ -126,6 +127,37 @@ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
         float acc = d[r];
         acc = fmaf(S->wa[w][row], S->wb[w][col], acc);
         acc = fmaf(S->wa[w][row + 32], S->wb[w][col + 32], acc);
+        d[r] = acc;
+    }
+    sync_wave();
+    return d;
+}
+
+unsigned short f2bf(float f) {                      // round to nearest even, like v_cvt_pk_bf16_f32
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+static float bf2f(unsigned short h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// Emulated v_mfma_f32_32x32x16_bf16: lane l supplies A[i = l & 31][k = 8 * (l >> 5) + j], B[k = 8 * (l >> 5) + j][n = l & 31];
+// same C/D map as the fp32 form; fp32 accumulation in k order (the hardware's internal order is not specified; tests of
+// this path use a bf16-sized tolerance).
+f32x16 mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
+    const int me = S->cur, w = me >> 6, l = me & 63;
+    for (int j = 0; j < 8; ++j) { S->wa16[w][l][j] = a[j]; S->wb16[w][l][j] = b[j]; }
+    sync_wave();
+    f32x16 d = c;
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = d[r];
+        for (int k = 0; k < 16; ++k) {
+            const int src_a = row + 32 * (k >> 3), src_b = col + 32 * (k >> 3);
+            acc = fmaf(bf2f(S->wa16[w][src_a][k & 7]), bf2f(S->wb16[w][src_b][k & 7]), acc);
+        }
         d[r] = acc;
     }
     sync_wave();

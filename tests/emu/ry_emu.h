@@ -16,6 +16,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 struct dim3 {
     unsigned x, y, z;
@@ -26,6 +28,8 @@ namespace ry_emu {
 extern thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 void sync_block();
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
+f32x16 mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c);
+unsigned short f2bf(float f);
 float shfl_xor(float v, int mask);
 float shfl(float v, int src);
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
@@ -42,6 +46,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 #define RY_KERNEL(...)
 
 RY_DEV f32x16 ry_mfma_32x32x2(float a, float b, f32x16 c) { return ry_emu::mfma_32x32x2(a, b, c); }
+RY_DEV f32x16 ry_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) { return ry_emu::mfma_32x32x16_bf16(a, b, c); }
+RY_DEV unsigned short ry_f2bf(float f) { return ry_emu::f2bf(f); }
 RY_DEV float ry_shfl_xor(float v, int mask) { return ry_emu::shfl_xor(v, mask); }
 RY_DEV float ry_shfl(float v, int src) { return ry_emu::shfl(v, src); }
 RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }

@@ -30,6 +30,15 @@ def test_conv2d_gpu(gpu_ctx, case):
     assert rel_max(y, r) < cases.TOL
 
 
+@pytest.mark.parametrize('case', cases.CONV2D_BF16_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_bf16_gpu(gpu_ctx, case):
+    """bf16-operand MFMA (BASELINE config #5): exact up to fp32 accumulation order against the oracle run on bf16-rounded
+    operands; within 2e-2 of the fp32 oracle."""
+    y, r16, r32 = cases.run_conv2d_bf16(gpu_ctx, numpy.random.default_rng(16), case, bn_params)
+    assert rel_max(y, r16) < 1e-4
+    assert rel_max(y, r32) < 2e-2
+
+
 def test_mfma_fragment_map_is_transpose_detecting(gpu_ctx):
     """Asymmetric 1x1 'conv' = plain GEMM with A = identity rows: catches a swapped C/D row/col map."""
     Cin, Cout = 32, 128
@@ -111,6 +120,29 @@ def test_stage2_syn64_forward_400_frames(syn64):
     y = n2.forward(x)
     r = t2.forward_np(x[:, numpy.newaxis])[:, 0]
     assert rel_max(y, r) < cases.TOL
+
+
+BF16_TOL = 3e-2     # stated tolerance of the bf16 stage-2 variant against the fp32 oracle, on the log-spectrum (max / max)
+
+
+def test_stage2_syn64_bf16_variant(gpu_ctx):
+    """BASELINE config #5 (buffer_time 1.0 s -> N = 200 core / 400 with extra): bf16 operands, fp32 accumulate."""
+    (_, _), (d2, P2) = synth.model_params('SYN-64')
+    net = engine.Net(gpu_ctx, d2, flatten_params(d2, P2), width=synth.FFT_BINS - 1)
+    t2 = torch_ref.TorchUNet(P2)
+    sp = synth.stage2_input(200)[0]
+    y32 = net.convert(sp)
+    net.set_dtype('bf16')
+    y16 = net.convert(sp)
+    net.set_dtype('f32')
+    assert numpy.array_equal(net.convert(sp), y32), 'switching back restores the exact fp32 path'
+    r = torch_ref.stage2_convert(t2, sp)
+    e32 = rel_max(numpy.log(y32), numpy.log(r))
+    e16 = rel_max(numpy.log(y16), numpy.log(r))
+    print('stage-2 log-spectrum error vs fp32 oracle: fp32 path %.2e, bf16 path %.2e' % (e32, e16))
+    assert e32 < cases.TOL
+    assert 1e-5 < e16 < BF16_TOL, e16
+    net.close()
 
 
 def test_device_resident_voice_changer_core(syn64):

@@ -26,6 +26,13 @@ def test_conv2d_emu(emu_ctx, case):
     assert rel_max(y, r) < cases.TOL
 
 
+@pytest.mark.parametrize('case', cases.CONV2D_BF16_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_bf16_emu(emu_ctx, case):
+    y, r16, r32 = cases.run_conv2d_bf16(emu_ctx, numpy.random.default_rng(16), case, bn_params)
+    assert rel_max(y, r16) < 1e-5          # exact model of the kernel: bf16-rounded operands, fp32 accumulation
+    assert rel_max(y, r32) < 2e-2          # and the price of bf16 operands against the fp32 oracle
+
+
 NETS = [
     # ndim, in, out, base, e, T, width, batch
     (1, 9, 9, 8, 8, 128, 1, 1),
