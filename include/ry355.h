@@ -9,6 +9,8 @@
  * the calling thread.  All tensors are float32, channels-last:
  *   stage-1  [batch][frames][channels]      (= the (N, C) feature matrix of encode_feature, untransposed)
  *   stage-2  [batch][frames][bins]
+ * Threading: a context and its predictors are used by one thread at a time (the reference converts from a single-threaded worker
+ * loop, convert_worker.py:45-59); different contexts / processes are independent.
  * `on_device` = 0: x / y are host pointers, the call returns after the result is in y.
  * `on_device` = 1: x / y are device pointers on the context's GPU; the call only enqueues work on the
  *                  context stream (ry_stream); use ry_sync or your own event to wait.

@@ -870,7 +870,10 @@ static int get_plan(ry_net* net, int B, int T, int mode, int n_frames, Plan** ou
     auto key = std::make_tuple(B, T, mode, 0);        // convert-mode plans are shared by every n_frames with the same padded length
     auto it = net->plans.find(key);
     if (it == net->plans.end()) {
-        if (net->plans.size() >= 16) net->plans.clear();       // bounded cache
+        if (net->plans.size() >= 16) {                         // bounded cache; queued work may still use the old plans' buffers
+            RT_TRY(rt::stream_sync(net->stream));
+            net->plans.clear();
+        }
         std::unique_ptr<Plan> P(new Plan());
         P->B = B; P->T = T; P->mode = mode; P->n_frames = n_frames;
         RY_TRY(build_plan(net, *P));
