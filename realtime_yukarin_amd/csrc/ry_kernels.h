@@ -315,6 +315,199 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// ry_igemm_f32_pc -- producer / consumer form of ry_igemm_f32 (same math, fragment maps, epilogue, filter layout).
+// 512 threads: waves 0-3 are CONSUMERS (per chunk: 16 ds_read_b128 + 64 MFMAs, nothing else -- the instruction mix the
+// tools/mfma_peak probe runs at 145 TF), waves 4-7 are PRODUCERS (global -> registers -> LDS with the im2col address
+// walk, padding masks and filter loads).  LDS is double-buffered and there is ONE barrier per chunk: during iteration k
+// the consumers read buf[k&1] while the producers write chunk k+1 (requested one iteration earlier) into buf[(k+1)&1] and
+// request chunk k+2.  Consumer waves never execute a vmcnt wait, an address computation or an LDS store.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+RY_KERNEL(512) void ry_igemm_f32_pc(RyIgemmParams p) {
+    constexpr int BK = 32, BKP = 36, NS = BK / 8;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AR = BM / 32, BR = BN / 32;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 consumer waves per workgroup");
+    constexpr int ABUF = BM * BKP, BBUF = BN * BKP;
+    __shared__ __attribute__((aligned(16))) float As[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BBUF];
+    __shared__ int rY[BM], rX[BM], rP[BM], rO[BM];
+
+    const RyConvGeom& g = p.g;
+    const int tid = (int)threadIdx.x;
+    const int total_tiles = p.splits * p.mtiles * p.ntiles * p.g.nphases;
+    const int per_xcd = (total_tiles + 7) >> 3;
+    int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (lid >= total_tiles) return;
+    const int phase = lid % p.g.nphases; lid /= p.g.nphases;
+    const int nt = lid % p.ntiles; lid /= p.ntiles;
+    const int mt = lid % p.mtiles;
+    const int split = lid / p.mtiles;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+    const int Ctot = g.C1 + g.C2;
+    const int Mimg = g.Mh * g.Mw;
+    const int M = g.B * Mimg;
+    const bool subpix = g.ostride == 2;
+    const int pdy = subpix ? (phase >> 1) : 0, pdx = subpix ? (phase & 1) : 0;
+
+    for (int r = tid; r < BM; r += 512) {
+        const int m = m0 + r;
+        int yb = -(1 << 20), xb = 0, pb = 0, ob = -1;
+        bool live = m < M;
+        int b = 0, ry = 0, rx = 0;
+        if (p.tw > 0) {
+            const int th = BM / p.tw, tcols = g.Mw / p.tw, trows = g.Mh / th;
+            const int tx = mt % tcols, ty = (mt / tcols) % trows;
+            b = mt / (tcols * trows);
+            ry = ty * th + r / p.tw; rx = tx * p.tw + r % p.tw;
+            live = b < g.B;
+        } else if (live) {
+            b = m / Mimg; const int rem = m - b * Mimg;
+            ry = rem / g.Mw; rx = rem - ry * g.Mw;
+        }
+        if (live) {
+            yb = ry * g.stride - g.pad;
+            xb = rx * g.stride - g.pad;
+            pb = b * g.Hi * g.Wi;
+            ob = (b * g.Ho + ry * g.ostride + pdy) * g.Wo + rx * g.ostride + pdx;
+        }
+        rY[r] = yb; rX[r] = xb; rP[r] = pb; rO[r] = ob;
+    }
+    __syncthreads();
+
+    const int cpt = Ctot / BK;
+    const int nk = g.ntaps * cpt;
+    const int kc_begin = (int)(((long long)nk * split) / p.splits);
+    const int kc_end = (int)(((long long)nk * (split + 1)) / p.splits);
+    const int nchunks = kc_end - kc_begin;
+
+    if (tid >= 256) {
+        // ------------------------------- producer waves -------------------------------
+        const int pt = tid - 256;
+        const int c4 = (pt & 7) * 4, rbase = pt >> 3;
+        int ayb[AR], axb[AR], aoff1[AR], aoff2[AR];
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            ayb[j] = rY[rbase + 32 * j]; axb[j] = rX[rbase + 32 * j];
+            const int pixb = rP[rbase + 32 * j] + ayb[j] * g.Wi + axb[j];
+            aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + c4 : 0;
+            aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + c4 : 0;
+        }
+        unsigned boff[BR];
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int n = n0 + rbase + 32 * j;
+            boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * cpt) * 2048 + (n & 63) * 32 + c4);
+        }
+        int tap = kc_begin / cpt;
+        int cib = kc_begin - tap * cpt;
+        int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
+        f32x4 areg[AR], breg[BR];
+        unsigned amask = 0, amask_next = 0;
+        auto load_chunk = [&]() {                  // request the next chunk of the walk into the registers
+            const int ci0 = cib * BK;
+            const bool first = ci0 < g.C1;
+            const float* src = first ? g.src1 : g.src2;
+            const int Cs = first ? g.C1 : g.C2;
+            const int cil = first ? ci0 : ci0 - g.C1;
+            const int dy = subpix ? pdy - ky : ky, dx = subpix ? pdx - kx : kx;
+            const int delta = (dy * g.Wi + dx) * Cs + cil;
+            const unsigned bdelta = (unsigned)((tap * cpt + cib) * 2048);
+            amask_next = 0;
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                const int iy = ayb[j] + dy, ix = axb[j] + dx;
+                const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                const int off = ok ? (first ? aoff1[j] : aoff2[j]) + delta : c4;
+                areg[j] = ry_ld4(src + (unsigned)off);
+                amask_next |= ok ? (1u << j) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < BR; ++j) breg[j] = ry_ld4(p.wt + (boff[j] + bdelta));
+            if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
+        };
+        auto store_chunk = [&](int buf) {          // registers -> LDS buffer `buf` (padding rows zeroed)
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                f32x4 v = areg[j];
+                if (!(amask & (1u << j))) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+                ry_st4(&As[buf * ABUF + (rbase + 32 * j) * BKP + c4], v);
+            }
+#pragma unroll
+            for (int j = 0; j < BR; ++j) ry_st4(&Bs[buf * BBUF + (rbase + 32 * j) * BKP + c4], breg[j]);
+        };
+        if (nchunks > 0) {
+            load_chunk(); amask = amask_next;
+            store_chunk(0);
+            if (nchunks > 1) { load_chunk(); amask = amask_next; }
+        }
+        __syncthreads();                           // buffer 0 holds chunk 0
+        for (int k = 0; k < nchunks; ++k) {
+            if (k + 1 < nchunks) {
+                store_chunk((k + 1) & 1);          // chunk k+1 was requested one iteration ago
+                if (k + 2 < nchunks) { load_chunk(); amask = amask_next; }
+            }
+            __syncthreads();                       // consumers are done with buf[k&1]; buf[(k+1)&1] is complete
+        }
+        return;
+    }
+
+    // ------------------------------- consumer waves -------------------------------
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __syncthreads();                               // buffer 0 holds chunk 0
+    for (int k = 0; k < nchunks; ++k) {
+        const float* Ab = &As[(k & 1) * ABUF + ((wm * TM) * 32 + lr) * BKP + lh * 4];
+        const float* Bb = &Bs[(k & 1) * BBUF + ((wn * TN) * 32 + lr) * BKP + lh * 4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = ry_ld4(Ab + i * 32 * BKP + s * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(Bb + j * 32 * BKP + s * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + lr;
+        float sc = 1.f, sh = 0.f;
+        if (p.splits == 1) { sc = p.scale[n]; sh = p.shift[n]; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ob = rO[ml];
+                if (ob >= 0) {
+                    float v = acc[i][j][r];
+                    if (p.splits == 1) v = ry_act(fmaf(v, sc, sh), p.act, p.slope);
+                    outp[(size_t)ob * g.N + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ry_igemm_bf16 -- the same implicit GEMM with bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), BASELINE
 // config #5.  Activations stay fp32 in HBM and are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when the A tile is written to
 // LDS; filters are converted once at `ry_net_set_dtype` and stored as [phase][N/64][tap][C/64][64][64] bf16 (8 KB blocks).

@@ -484,6 +484,7 @@ static const char* tile_name(int tile) {
 static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
 static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
+static int g_pc = 0;       // RY_PC=1: producer/consumer kernel ry_igemm_f32_pc instead of ry_igemm_f32
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
 static unsigned long long* g_dbg = nullptr;
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
@@ -564,7 +565,8 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         p.dbg = g_dbg;
 #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
     do {                                                                                                    \
-        if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
+        if (g_pc && !g_timing && BM_ <= 128) RY_LAUNCH((ry_igemm_f32_pc<BM_, BN_, WM_, WN_>), grid, 512, Lc.stream, p); \
+        else if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
         else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
         else RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 0>), grid, 256, Lc.stream, p);               \
     } while (0)
@@ -1039,6 +1041,7 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
     if (const char* e = getenv("RY_GRAPH")) net->use_graph = atoi(e) != 0;
     if (const char* e = getenv("RY_ILV")) g_ilv = atoi(e);
     if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
+    if (const char* e = getenv("RY_PC")) g_pc = atoi(e);
     if (const char* e = getenv("RY_TILE2D")) g_tile2d = atoi(e);
     if (const char* e = getenv("RY_BIGTILE")) g_bigtile = atoi(e);
 #ifndef RY_HOST_EMU
