@@ -114,11 +114,16 @@ def main():
             net2.forward_device(xin.data_ptr(), yout.data_ptr(), Wn, T)
         ctx.sync()
         st = net2.profile(Wn, T, args.profile_reps)
+        if args.layers_out:
+            with open(args.layers_out, 'w') as f:
+                for q in st:
+                    f.write('%-12s %-26s grid=%-10s %9.2f us %8.2f TFLOP/s\n' % (
+                        q['layer'], q['name'], 'x'.join(map(str, q['grid'])), q['ms'] * 1e3, q['flops'] / max(q['ms'], 1e-9) / 1e9))
         fam = {}
         for q in st:
             f = fam.setdefault(q['name'], [0.0, 0.0])
             f[0] += q['ms']; f[1] += q['flops']
-        print(' | '.join('%s %.1fus %.1fTF' % (k, v[0] * 1e3, v[1] / max(v[0], 1e-9) / 1e9) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:5]), flush=True)
+        print('total %.1fus | ' % (sum(q['ms'] for q in st) * 1e3) + ' | '.join('%s %.1fus %.1fTF' % (k, v[0] * 1e3, v[1] / max(v[0], 1e-9) / 1e9) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:5]), flush=True)
         if os.environ.get('RY_TIMING'):
             import ctypes
             buf = (ctypes.c_ulonglong * 8)()

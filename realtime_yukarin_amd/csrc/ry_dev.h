@@ -32,6 +32,13 @@ RY_DEV f32x16 ry_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ry_bf16x8, a), __builtin_bit_cast(ry_bf16x8, b), c, 0, 0, 0);
 }
 RY_DEV unsigned short ry_f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }   // v_cvt_pk_bf16_f32 (RNE)
+// Direct global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): lane i's data lands at lds_wave_base + 16*i bytes;
+// the LDS base must be wave-uniform, the global address is per lane.  Completion is tracked by vmcnt.
+RY_DEV void ry_glds16(const float* gsrc_lane, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+RY_DEV int ry_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 RY_DEV float ry_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 RY_DEV float ry_shfl(float v, int src) { return __shfl(v, src, 64); }
 RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }

@@ -66,6 +66,8 @@ struct RyIgemmParams {
     int tw;                     // > 0: an M-tile is a 2-D block of (BM/tw) x tw rows of the Mh x Mw grid (compact input footprint:
                                 //      overlapping taps hit L2); 0: BM consecutive rows in raster order
     unsigned long long* dbg;    // VAR bit 1 (diagnostic build of the kernel): per-phase shader-clock totals, else unused
+    int dbg_flags;              // diagnostics of ry_igemm_f32_ldsdma (wrong results): 4 = skip the output stores, 8 = skip the K loop
+    const float* zeros;         // >= 16 bytes of zeros in device memory (source of padded rows for the direct-to-LDS kernel)
 };
 
 // VAR bit 1 (RY_TIMING=1, diagnostics only): every wave accumulates s_memtime deltas per loop phase into p.dbg.
@@ -315,22 +317,31 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// ry_igemm_f32_pc -- producer / consumer form of ry_igemm_f32 (same math, fragment maps, epilogue, filter layout).
-// 512 threads: waves 0-3 are CONSUMERS (per chunk: 16 ds_read_b128 + 64 MFMAs, nothing else -- the instruction mix the
-// tools/mfma_peak probe runs at 145 TF), waves 4-7 are PRODUCERS (global -> registers -> LDS with the im2col address
-// walk, padding masks and filter loads).  LDS is double-buffered and there is ONE barrier per chunk: during iteration k
-// the consumers read buf[k&1] while the producers write chunk k+1 (requested one iteration earlier) into buf[(k+1)&1] and
-// request chunk k+2.  Consumer waves never execute a vmcnt wait, an address computation or an LDS store.
+// ry_igemm_f32_ldsdma -- implicit GEMM whose operand tiles go global -> LDS by DMA (global_load_lds_dwordx4), issued by
+// the same four waves that run the MFMAs (no staging registers, no ds_write, one barrier per K chunk).
+// LDS rows are BK floats (unpadded: the DMA destination is lane-linear); the 16-byte slot c of row r is stored at
+// position c ^ ((r / (64 / BK)) & (BK / 4 - 1)), which makes the ds_read_b128 fragment reads conflict-free (bank =
+// (addr / 4) mod 64 inside the instruction's 16-lane groups).  The swizzle is applied on the SOURCE side: the lane that
+// fills position q of row r fetches slot q ^ f(r).  Padding is fetched from a zero page.
+// Two buffers held in DISTINCT __shared__ arrays and a loop unrolled by two, so that the compiler's LDS-DMA alias
+// tracking does not order the reads of buffer k & 1 behind the DMA into the other buffer.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
-RY_KERNEL(512) void ry_igemm_f32_pc(RyIgemmParams p) {
-    constexpr int BK = 32, BKP = 36, NS = BK / 8;
+template <int V> struct RyConst { static constexpr int value = V; };
+
+template <int BM, int BN, int WM, int WN, int BK>
+RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
+    constexpr int NS = BK / 8;
+    constexpr int S = BK / 4;              // 16-byte slots per LDS row
+    constexpr int RPI = 64 / S;            // rows filled by one DMA wave-instruction (1 KiB)
+    constexpr int WRAP = 64 / BK;          // rows per 64-bank wrap
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int AR = BM / 32, BR = BN / 32;
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 consumer waves per workgroup");
-    constexpr int ABUF = BM * BKP, BBUF = BN * BKP;
-    __shared__ __attribute__((aligned(16))) float As[2 * ABUF];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BBUF];
+    constexpr int AG = BM / RPI, BG = BN / RPI;
+    constexpr int AI = (AG + 3) / 4, BI = (BG + 3) / 4, NI = AI + BI;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BM % RPI == 0 && BN % RPI == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) float As0[BM * BK];
+    __shared__ __attribute__((aligned(16))) float As1[BM * BK];
+    __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
+    __shared__ __attribute__((aligned(16))) float Bs1[BN * BK];
     __shared__ int rY[BM], rX[BM], rP[BM], rO[BM];
 
     const RyConvGeom& g = p.g;
@@ -351,7 +362,7 @@ RY_KERNEL(512) void ry_igemm_f32_pc(RyIgemmParams p) {
     const bool subpix = g.ostride == 2;
     const int pdy = subpix ? (phase >> 1) : 0, pdx = subpix ? (phase & 1) : 0;
 
-    for (int r = tid; r < BM; r += 512) {
+    for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
         int yb = -(1 << 20), xb = 0, pb = 0, ob = -1;
         bool live = m < M;
@@ -376,87 +387,71 @@ RY_KERNEL(512) void ry_igemm_f32_pc(RyIgemmParams p) {
     }
     __syncthreads();
 
+    const int lane = tid & 63, wave = ry_uniform(tid >> 6);
+    // ---- DMA role of this lane: row drow / position dpos inside each 1-KiB row group this wave fills ----
+    const int drow = lane / S, dpos = lane % S;
+    int ayb[AI], axb[AI], aoff1[AI], aoff2[AI];
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int gi = 4 * j + wave;
+        const int row = (gi < AG ? gi : 0) * RPI + drow;
+        const int c4 = (dpos ^ ((row / WRAP) & (S - 1))) * 4;
+        ayb[j] = rY[row]; axb[j] = rX[row];
+        const int pixb = rP[row] + ayb[j] * g.Wi + axb[j];
+        aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + c4 : 0;
+        aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + c4 : 0;
+    }
+    const int c32 = Ctot >> 5;               // 32-channel blocks of the weight layout
+    unsigned boff[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int gi = 4 * j + wave;
+        const int row = (gi < BG ? gi : 0) * RPI + drow;
+        const int c4 = (dpos ^ ((row / WRAP) & (S - 1))) * 4;
+        const int n = n0 + row;
+        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * c32) * 2048 + (n & 63) * 32 + c4);
+    }
+
     const int cpt = Ctot / BK;
     const int nk = g.ntaps * cpt;
     const int kc_begin = (int)(((long long)nk * split) / p.splits);
     const int kc_end = (int)(((long long)nk * (split + 1)) / p.splits);
-    const int nchunks = kc_end - kc_begin;
+    const int nchunks = (p.dbg_flags & 8) ? 0 : kc_end - kc_begin;
+    int tap = kc_begin / cpt;
+    int cib = kc_begin - tap * cpt;
+    int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
 
-    if (tid >= 256) {
-        // ------------------------------- producer waves -------------------------------
-        const int pt = tid - 256;
-        const int c4 = (pt & 7) * 4, rbase = pt >> 3;
-        int ayb[AR], axb[AR], aoff1[AR], aoff2[AR];
-#pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            ayb[j] = rY[rbase + 32 * j]; axb[j] = rX[rbase + 32 * j];
-            const int pixb = rP[rbase + 32 * j] + ayb[j] * g.Wi + axb[j];
-            aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + c4 : 0;
-            aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + c4 : 0;
-        }
-        unsigned boff[BR];
-#pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            const int n = n0 + rbase + 32 * j;
-            boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * cpt) * 2048 + (n & 63) * 32 + c4);
-        }
-        int tap = kc_begin / cpt;
-        int cib = kc_begin - tap * cpt;
-        int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
-        f32x4 areg[AR], breg[BR];
-        unsigned amask = 0, amask_next = 0;
-        auto load_chunk = [&]() {                  // request the next chunk of the walk into the registers
-            const int ci0 = cib * BK;
-            const bool first = ci0 < g.C1;
-            const float* src = first ? g.src1 : g.src2;
-            const int Cs = first ? g.C1 : g.C2;
-            const int cil = first ? ci0 : ci0 - g.C1;
-            const int dy = subpix ? pdy - ky : ky, dx = subpix ? pdx - kx : kx;
-            const int delta = (dy * g.Wi + dx) * Cs + cil;
-            const unsigned bdelta = (unsigned)((tap * cpt + cib) * 2048);
-            amask_next = 0;
-#pragma unroll
-            for (int j = 0; j < AR; ++j) {
-                const int iy = ayb[j] + dy, ix = axb[j] + dx;
+    // state of the chunk being fetched (wave-uniform)
+    const float* c_src = nullptr; bool c_first = true; int c_delta = 0, c_dy = 0, c_dx = 0; unsigned c_bdelta = 0;
+    auto next_chunk = [&]() {
+        const int ci0 = cib * BK;
+        c_first = ci0 < g.C1;
+        c_src = c_first ? g.src1 : g.src2;
+        const int Cs = c_first ? g.C1 : g.C2;
+        const int cil = c_first ? ci0 : ci0 - g.C1;
+        c_dy = subpix ? pdy - ky : ky; c_dx = subpix ? pdx - kx : kx;
+        c_delta = (c_dy * g.Wi + c_dx) * Cs + cil;
+        c_bdelta = (unsigned)((tap * c32 + (ci0 >> 5)) * 2048 + (ci0 & 31));
+        if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
+    };
+    auto dma_item = [&](int q, float* Ad, float* Bd) {     // q-th DMA instruction of this wave for the current fetch
+        if (q < AI) {
+            const int j = q, gi = 4 * j + wave;
+            if (AG % 4 == 0 || gi < AG) {
+                const int iy = ayb[j] + c_dy, ix = axb[j] + c_dx;
                 const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-                const int off = ok ? (first ? aoff1[j] : aoff2[j]) + delta : c4;
-                areg[j] = ry_ld4(src + (unsigned)off);
-                amask_next |= ok ? (1u << j) : 0u;
+                const float* gp = ok ? c_src + (unsigned)((c_first ? aoff1[j] : aoff2[j]) + c_delta) : p.zeros;
+                ry_glds16(gp, Ad + gi * (RPI * BK));
             }
-#pragma unroll
-            for (int j = 0; j < BR; ++j) breg[j] = ry_ld4(p.wt + (boff[j] + bdelta));
-            if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
-        };
-        auto store_chunk = [&](int buf) {          // registers -> LDS buffer `buf` (padding rows zeroed)
-#pragma unroll
-            for (int j = 0; j < AR; ++j) {
-                f32x4 v = areg[j];
-                if (!(amask & (1u << j))) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
-                ry_st4(&As[buf * ABUF + (rbase + 32 * j) * BKP + c4], v);
-            }
-#pragma unroll
-            for (int j = 0; j < BR; ++j) ry_st4(&Bs[buf * BBUF + (rbase + 32 * j) * BKP + c4], breg[j]);
-        };
-        if (nchunks > 0) {
-            load_chunk(); amask = amask_next;
-            store_chunk(0);
-            if (nchunks > 1) { load_chunk(); amask = amask_next; }
+        } else {
+            const int j = q - AI, gi = 4 * j + wave;
+            if (BG % 4 == 0 || gi < BG) ry_glds16(p.wt + (boff[j] + c_bdelta), Bd + gi * (RPI * BK));
         }
-        __syncthreads();                           // buffer 0 holds chunk 0
-        for (int k = 0; k < nchunks; ++k) {
-            if (k + 1 < nchunks) {
-                store_chunk((k + 1) & 1);          // chunk k+1 was requested one iteration ago
-                if (k + 2 < nchunks) { load_chunk(); amask = amask_next; }
-            }
-            __syncthreads();                       // consumers are done with buf[k&1]; buf[(k+1)&1] is complete
-        }
-        return;
-    }
+    };
 
-    // ------------------------------- consumer waves -------------------------------
-    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
+    const int sw = (lr / WRAP) & (S - 1);        // swizzle key of every fragment row this lane reads (tile rows are multiples of 32)
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -464,17 +459,36 @@ RY_KERNEL(512) void ry_igemm_f32_pc(RyIgemmParams p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    __syncthreads();                               // buffer 0 holds chunk 0
-    for (int k = 0; k < nchunks; ++k) {
-        const float* Ab = &As[(k & 1) * ABUF + ((wm * TM) * 32 + lr) * BKP + lh * 4];
-        const float* Bb = &Bs[(k & 1) * BBUF + ((wn * TN) * 32 + lr) * BKP + lh * 4];
+
+    if (nchunks > 0) {
+        next_chunk();
+#pragma unroll
+        for (int q = 0; q < NI; ++q) dma_item(q, As0, Bs0);
+    }
+    __syncthreads();
+
+    auto run_chunk = [&](auto bufc, int k) {
+        constexpr int BUF = decltype(bufc)::value;
+        const float* Ac = BUF ? As1 : As0;
+        const float* Bc = BUF ? Bs1 : Bs0;
+        float* An = BUF ? As0 : As1;
+        float* Bn = BUF ? Bs0 : Bs1;
+        const bool more = k + 1 < nchunks;
+        if (more) next_chunk();
+        const float* Ab = Ac + ((wm * TM) * 32 + lr) * BK;
+        const float* Bb = Bc + ((wn * TN) * 32 + lr) * BK;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
+            const int pos = ((2 * s + lh) ^ sw) * 4;
             f32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = ry_ld4(Ab + i * 32 * BKP + s * 8);
+            for (int i = 0; i < TM; ++i) af[i] = ry_ld4(Ab + i * 32 * BK + pos);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(Bb + j * 32 * BKP + s * 8);
+            for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(Bb + j * 32 * BK + pos);
+            if (more) {
+#pragma unroll
+                for (int q = (s * NI) / NS; q < ((s + 1) * NI) / NS; ++q) dma_item(q, An, Bn);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -482,9 +496,14 @@ RY_KERNEL(512) void ry_igemm_f32_pc(RyIgemmParams p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
         }
-        __syncthreads();
+        __syncthreads();                       // DMA of chunk k + 1 landed (vmcnt) and buffer BUF is free again
+    };
+    for (int k = 0; k < nchunks; k += 2) {
+        run_chunk(RyConst<0>(), k);
+        if (k + 1 < nchunks) run_chunk(RyConst<1>(), k + 1);
     }
 
+    if (p.dbg_flags & 4) return;
     float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {

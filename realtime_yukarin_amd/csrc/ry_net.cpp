@@ -469,43 +469,64 @@ static const char* tile_name16(int tile) {
     }
 }
 
-static const char* tile_name(int tile) {
-    switch (tile) {
-        case TILE_128x128: return "ry_igemm_f32<128,128>";
-        case TILE_256x64: return "ry_igemm_f32<256,64>";
-        case TILE_64x128: return "ry_igemm_f32<64,128>";
-        case TILE_128x64: return "ry_igemm_f32<128,64>";
-        case TILE_96x128: return "ry_igemm_f32<96,128>";
-        case TILE_256x128: return "ry_igemm_f32<256,128>";
-        default: return "ry_igemm_f32<32,128>";
-    }
-}
-
 static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
 static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
-static int g_pc = 0;       // RY_PC=1: producer/consumer kernel ry_igemm_f32_pc instead of ry_igemm_f32
+static int g_igemm_dbg = 0; // RY_IGEMM_DBG: ablation bits of ry_igemm_f32_ldsdma (diagnostics; wrong results)
+static float* g_zero_page = nullptr;   // 256 bytes of zeros in device memory (padding source of ry_igemm_f32_dma)
+static int g_ldsdma = 1;    // RY_LDSDMA=0: register-staged ry_igemm_f32 instead of the LDS-DMA kernel (A/B; ~5 % slower end to end)
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
 static unsigned long long* g_dbg = nullptr;
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
+static const char* tile_name(int tile) {
+    const bool dma = g_ldsdma && !g_timing;
+    switch (tile) {
+        case TILE_128x128: return dma ? "ry_igemm_f32_ldsdma<128,128>" : "ry_igemm_f32<128,128>";
+        case TILE_256x64: return "ry_igemm_f32<256,64>";
+        case TILE_64x128: return dma ? "ry_igemm_f32_ldsdma<64,128>" : "ry_igemm_f32<64,128>";
+        case TILE_128x64: return dma ? "ry_igemm_f32_ldsdma<128,64>" : "ry_igemm_f32<128,64>";
+        case TILE_96x128: return dma ? "ry_igemm_f32_ldsdma<96,128>" : "ry_igemm_f32<96,128>";
+        case TILE_256x128: return "ry_igemm_f32<256,128>";
+        default: return dma ? "ry_igemm_f32_ldsdma<32,128>" : "ry_igemm_f32<32,128>";
+    }
+}
+
 // choose tile + split-K for one stage-2 layer
 // efficiency of running `blocks` workgroups of one launch on 256 CUs with split-K `s`
-static double grid_eff(long blocks, int s, bool tinyM) {
+// Workgroups of one tile that fit a CU.  LDS-DMA kernel: two unpadded BK = 32 buffers; register-staged kernel: one padded
+// buffer, limited to 3 by its VGPR budget.
+static int tile_occ(int tile) {
+    int bm, bn; tile_dims(tile, &bm, &bn);
+    const int lds = g_ldsdma ? (bm + bn) * 32 * 4 * 2 + bm * 16 : (bm + bn) * 36 * 4 + bm * 16;
+    int occ = (160 * 1024) / lds;
+    const int cap = g_ldsdma ? 4 : 3;
+    return occ > cap ? cap : (occ < 1 ? 1 : occ);
+}
+
+// Fraction of the MFMA peak a CU sustains with r co-resident workgroups of the main loop (measured on gfx950: a lone
+// 4-wave workgroup cannot cover its own barriers and LDS latency).
+static double cu_rate(int r) {
+    static const double f[5] = {0.0, 0.36, 0.70, 0.72, 0.72};
+    return f[r > 4 ? 4 : r];
+}
+
+static double grid_eff(long blocks, int s, bool tinyM, int occ) {
     const long g = blocks * s;
-    const long rounds = (g + 255) / 256;
-    double eff = (double)g / (double)(rounds * 256);
     if (tinyM) return g >= 1024 ? 1.0 - 1e-4 * s : (double)g / 1024.0;   // weight streaming: fill the chip with loads in flight
-    if (rounds < 2) eff *= 0.5 * rounds + 0.25;                            // a single thin wave cannot hide its own barriers
+    const long per_cu = (g + 255) / 256;                                   // the busiest CU sets the time
+    const long full = per_cu / occ, rem = per_cu % occ;
+    const double t = (double)full * occ / cu_rate(occ) + (rem ? (double)rem / cu_rate((int)rem) : 0.0);
+    double eff = ((double)g / 256.0) / t / cu_rate(4);
     if (s > 1) eff -= 0.10 + 0.004 * (s - 1);                              // split-K: slab writes at the tail + a reduce pass (~10 % measured)
     return eff;
 }
 
-static int best_split(long blocks, int nk, bool tinyM, double* eff_out) {
+static int best_split(long blocks, int nk, bool tinyM, int occ, double* eff_out) {
     const int smax = tinyM ? 128 : 32, min_chunks = tinyM ? 2 : 4;
     int best = 1; double be = -1.0;
     for (int s = 1; s <= smax && s <= (nk >= min_chunks ? nk / min_chunks : 1); ++s) {
-        const double e = grid_eff(blocks, s, tinyM);
+        const double e = grid_eff(blocks, s, tinyM, occ);
         if (e > be + 1e-9) { be = e; best = s; }
     }
     if (eff_out) *eff_out = be;
@@ -513,8 +534,8 @@ static int best_split(long blocks, int nk, bool tinyM, double* eff_out) {
 }
 
 static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits) {
-    // MFMA-bound layers: every CU should get the same number of workgroups.  Candidate M-tiles 128 / 96 / 64 (N-tile 128)
-    // are scored by (row utilisation) x (grid balance over 256 CUs, with the best split-K for that tile).
+    // MFMA-bound layers: every CU should hold a full set of co-resident workgroups for the whole launch.  Candidate
+    // M-tiles 128 / 96 / 64 (N-tile 128) are scored by (row utilisation) x (grid efficiency with the best split-K).
     if (*tile == 0) {
         if (l.cout % 128 != 0) *tile = g_tile64;
         else if (M <= 32) *tile = TILE_32x128;
@@ -528,7 +549,7 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
                 int bm, bn; tile_dims(cand[c], &bm, &bn);
                 const long mt = (M + bm - 1) / bm;
                 double e = 0.0;
-                best_split(mt * (l.cout / bn) * nphases, nk, false, &e);
+                best_split(mt * (l.cout / bn) * nphases, nk, false, tile_occ(cand[c]), &e);
                 e = e * ((double)M / (double)(mt * bm)) + bias[c];
                 if (e > be + 1e-9) { be = e; bt = cand[c]; }
             }
@@ -536,7 +557,7 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
         }
     }
     int bm, bn; tile_dims(*tile, &bm, &bn);
-    if (*splits == 0) *splits = best_split((long)((M + bm - 1) / bm) * (l.cout / bn) * nphases, nk, M <= 64, nullptr);
+    if (*splits == 0) *splits = best_split((long)((M + bm - 1) / bm) * (l.cout / bn) * nphases, nk, M <= 64, tile_occ(*tile), nullptr);
     if (*splits > nk) *splits = nk;
 }
 
@@ -562,10 +583,10 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
         dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
         RY_TRY(Lc.begin(bf16 ? tile_name16(lp.tile) : tile_name(lp.tile), l.name, lp.flops, lp.bytes, grid));
-        p.dbg = g_dbg;
+        p.dbg = g_dbg; p.dbg_flags = g_igemm_dbg; p.zeros = g_zero_page;
 #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
     do {                                                                                                    \
-        if (g_pc && !g_timing && BM_ <= 128) RY_LAUNCH((ry_igemm_f32_pc<BM_, BN_, WM_, WN_>), grid, 512, Lc.stream, p); \
+        if (g_ldsdma && !g_timing && BM_ <= 128) RY_LAUNCH((ry_igemm_f32_ldsdma<BM_, BN_, WM_, WN_, 32>), grid, 256, Lc.stream, p); \
         else if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
         else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
         else RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 0>), grid, 256, Lc.stream, p);               \
@@ -1041,7 +1062,13 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
     if (const char* e = getenv("RY_GRAPH")) net->use_graph = atoi(e) != 0;
     if (const char* e = getenv("RY_ILV")) g_ilv = atoi(e);
     if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
-    if (const char* e = getenv("RY_PC")) g_pc = atoi(e);
+    if (const char* e = getenv("RY_LDSDMA")) g_ldsdma = atoi(e);
+    if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);
+    if (!g_zero_page) {
+        std::vector<float> z(64, 0.f);
+        Arena* keep = new Arena();                                  // process lifetime
+        RY_TRY(upload(*keep, ctx, z, &g_zero_page));
+    }
     if (const char* e = getenv("RY_TILE2D")) g_tile2d = atoi(e);
     if (const char* e = getenv("RY_BIGTILE")) g_bigtile = atoi(e);
 #ifndef RY_HOST_EMU

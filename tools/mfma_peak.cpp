@@ -9,6 +9,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // MODE 0: one operand pair, 4 accumulators.  MODE 1: 2x2 tiles, operands from registers (8 k-steps).
 // MODE 2: as MODE 1 but operands re-read from LDS (ds_read_b128) every 32 MFMAs, like the igemm inner loop.
+// MODE 3: MODE 2 + one __syncthreads() per 64 MFMAs; MODE 4: MODE 2 + two per 64 MFMAs (the igemm's barrier cadence).
 template <int MODE>
 __global__ __launch_bounds__(256) void mfma_loop(const float* in, float* out, int iters) {
     __shared__ __attribute__((aligned(16))) float As[128 * 36];
@@ -33,7 +34,8 @@ __global__ __launch_bounds__(256) void mfma_loop(const float* in, float* out, in
             bf[s][i] = *(const f32x4*)&Bs[((wn * 2 + i) * 32 + lr) * 36 + s * 8 + lh * 4];
         }
         for (int it = 0; it < iters / 8; ++it) {          // 32 MFMAs per iteration
-            if (MODE == 2) {
+            if (MODE >= 3 && (it & 1) == 0) { __syncthreads(); if (MODE == 4) __syncthreads(); }
+            if (MODE >= 2) {
                 int o = (it & 1) * 16;
                 asm volatile("" : "+v"(o));                 // opaque: the fragment reads cannot be hoisted out of the loop
 #pragma unroll
@@ -83,10 +85,12 @@ int main() {
     float *din, *dout;
     (void)hipMalloc(&din, 512 * 4); (void)hipMalloc(&dout, 1024 * 256 * 4);
     (void)hipMemcpy(din, h.data(), 512 * 4, hipMemcpyHostToDevice);
-    for (int blocks : {256, 512, 768, 1024}) {
+    for (int blocks : {256, 512, 768}) {
         run<0>("mfma only, 1 operand pair", blocks, din, dout);
         run<1>("mfma 2x2 tiles, register operands", blocks, din, dout);
         run<2>("mfma 2x2 tiles, ds_read_b128 operands", blocks, din, dout);
+        run<3>("  + 1 barrier per 64 MFMAs", blocks, din, dout);
+        run<4>("  + 2 barriers per 64 MFMAs", blocks, din, dout);
     }
     return 0;
 }
