@@ -66,7 +66,7 @@ struct RyIgemmParams {
     int tw;                     // > 0: an M-tile is a 2-D block of (BM/tw) x tw rows of the Mh x Mw grid (compact input footprint:
                                 //      overlapping taps hit L2); 0: BM consecutive rows in raster order
     unsigned long long* dbg;    // VAR bit 1 (diagnostic build of the kernel): per-phase shader-clock totals, else unused
-    int dbg_flags;              // diagnostics of ry_igemm_f32_ldsdma (wrong results): 4 = skip the output stores, 8 = skip the K loop
+    int dbg_flags;              // diagnostics of ry_igemm_f32_ldsdma (wrong results): 4 skip the output stores, 8 skip the K loop, 128 skip the loads in the K loop
     const float* zeros;         // >= 16 bytes of zeros in device memory (source of padded rows for the direct-to-LDS kernel)
 };
 
@@ -164,7 +164,8 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
         const int n = n0 + rbase + RSTEP * j;
-        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * (Ctot >> 5)) * 2048 + (n & 63) * 32 + c4);
+        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * (Ctot >> 5)) * 2048 +
+                             ((n >> 5) & 1) * 1024 + (c4 >> 3) * 256 + (((c4 >> 2) & 1) * 32 + (n & 31)) * 4);   // fragment-ordered block
     }
 
     f32x16 acc[TM][TN];
@@ -317,27 +318,31 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// ry_igemm_f32_ldsdma -- implicit GEMM whose operand tiles go global -> LDS by DMA (global_load_lds_dwordx4), issued by
-// the same four waves that run the MFMAs (no staging registers, no ds_write, one barrier per K chunk).
-// LDS rows are BK floats (unpadded: the DMA destination is lane-linear); the 16-byte slot c of row r is stored at
-// position c ^ ((r / (64 / BK)) & (BK / 4 - 1)), which makes the ds_read_b128 fragment reads conflict-free (bank =
-// (addr / 4) mod 64 inside the instruction's 16-lane groups).  The swizzle is applied on the SOURCE side: the lane that
-// fills position q of row r fetches slot q ^ f(r).  Padding is fetched from a zero page.
-// Two buffers held in DISTINCT __shared__ arrays and a loop unrolled by two, so that the compiler's LDS-DMA alias
-// tracking does not order the reads of buffer k & 1 behind the DMA into the other buffer.
+// ry_igemm_f32_ldsdma -- the default stage-2 implicit GEMM.  Operand tiles go global -> LDS by DMA
+// (global_load_lds_dwordx4), issued by the same four waves that run the MFMAs: no staging registers, no ds_write, one
+// barrier per 32-wide K chunk.
+//   A (gathered pixels x channels): LDS rows of 32 floats, unpadded (the DMA destination is lane-linear); the 16-byte slot
+//     c of row r is stored at position c ^ ((r >> 1) & 7), which makes the ds_read_b128 fragment reads conflict-free
+//     (bank = (addr / 4) mod 64 inside the instruction's 16-lane groups).  The swizzle is applied on the SOURCE side: the
+//     lane that fills position q of row r fetches slot q ^ f(r).  Padding is fetched from a zero page.
+//   B (filters) is stored in fragment order by the host (ry_net.cpp: wig_inblock), one 1-KiB piece per (32 columns, K step):
+//     the pieces are DMA-copied into the LDS as they are and read back lane-linearly (conflict-free, no swizzle).
+//     (Loading them global -> registers in the 1 x 4 wave layouts, bypassing the LDS, measured 2 % slower: DESIGN.md 4.1.)
+// Two buffers held in DISTINCT __shared__ arrays and a loop unrolled by two, so that the compiler's LDS-DMA alias tracking
+// does not order the reads of buffer k & 1 behind the DMA into the other buffer.
+// dbg_flags (RY_IGEMM_DBG, diagnostics with wrong results): 4 skip the output stores, 8 skip the K loop, 128 skip the
+// loads inside the K loop.
 // ---------------------------------------------------------------------------------------------
 template <int V> struct RyConst { static constexpr int value = V; };
 
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN>
 RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
-    constexpr int NS = BK / 8;
-    constexpr int S = BK / 4;              // 16-byte slots per LDS row
-    constexpr int RPI = 64 / S;            // rows filled by one DMA wave-instruction (1 KiB)
-    constexpr int WRAP = 64 / BK;          // rows per 64-bank wrap
+    constexpr int BK = 32, NS = 4;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int AG = BM / RPI, BG = BN / RPI;
+    constexpr int AG = BM / 8;                // 1-KiB DMA pieces of the A tile (8 rows each)
+    constexpr int BG = BN / 8;                // 1-KiB DMA pieces of the B tile ((32 columns, K step) each)
     constexpr int AI = (AG + 3) / 4, BI = (BG + 3) / 4, NI = AI + BI;
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BM % RPI == 0 && BN % RPI == 0, "tile shape");
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
     __shared__ __attribute__((aligned(16))) float As0[BM * BK];
     __shared__ __attribute__((aligned(16))) float As1[BM * BK];
     __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
@@ -388,28 +393,29 @@ RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
     __syncthreads();
 
     const int lane = tid & 63, wave = ry_uniform(tid >> 6);
-    // ---- DMA role of this lane: row drow / position dpos inside each 1-KiB row group this wave fills ----
-    const int drow = lane / S, dpos = lane % S;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    // ---- A: DMA role of this lane = row drow / position dpos inside each 8-row piece this wave fills ----
+    const int drow = lane >> 3, dpos = lane & 7;
     int ayb[AI], axb[AI], aoff1[AI], aoff2[AI];
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
         const int gi = 4 * j + wave;
-        const int row = (gi < AG ? gi : 0) * RPI + drow;
-        const int c4 = (dpos ^ ((row / WRAP) & (S - 1))) * 4;
+        const int row = (gi < AG ? gi : 0) * 8 + drow;
+        const int c4 = (dpos ^ ((row >> 1) & 7)) * 4;
         ayb[j] = rY[row]; axb[j] = rX[row];
         const int pixb = rP[row] + ayb[j] * g.Wi + axb[j];
         aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + c4 : 0;
         aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + c4 : 0;
     }
-    const int c32 = Ctot >> 5;               // 32-channel blocks of the weight layout
+    // ---- B: element offset of this lane's 16 bytes in the (tap 0, chunk 0) block of each (32 columns, K step) piece ----
+    const int c32 = Ctot >> 5;
     unsigned boff[BI];
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
-        const int gi = 4 * j + wave;
-        const int row = (gi < BG ? gi : 0) * RPI + drow;
-        const int c4 = (dpos ^ ((row / WRAP) & (S - 1))) * 4;
-        const int n = n0 + row;
-        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * c32) * 2048 + (n & 63) * 32 + c4);
+        const int gi = 4 * j + wave, gq = gi < BG ? gi : 0;
+        const int n = n0 + (gq >> 2) * 32;
+        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * c32) * 2048 + ((n >> 5) & 1) * 1024 + (gq & 3) * 256 + lane * 4);
     }
 
     const int cpt = Ctot / BK;
@@ -431,27 +437,25 @@ RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
         const int cil = c_first ? ci0 : ci0 - g.C1;
         c_dy = subpix ? pdy - ky : ky; c_dx = subpix ? pdx - kx : kx;
         c_delta = (c_dy * g.Wi + c_dx) * Cs + cil;
-        c_bdelta = (unsigned)((tap * c32 + (ci0 >> 5)) * 2048 + (ci0 & 31));
+        c_bdelta = (unsigned)((tap * c32 + cib) * 2048);
         if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
     };
-    auto dma_item = [&](int q, float* Ad, float* Bd) {     // q-th DMA instruction of this wave for the current fetch
+    auto dma_item = [&](int q, float* Ad, float* Bd) {     // q-th DMA instruction of this wave for the chunk being fetched
         if (q < AI) {
             const int j = q, gi = 4 * j + wave;
             if (AG % 4 == 0 || gi < AG) {
                 const int iy = ayb[j] + c_dy, ix = axb[j] + c_dx;
                 const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
                 const float* gp = ok ? c_src + (unsigned)((c_first ? aoff1[j] : aoff2[j]) + c_delta) : p.zeros;
-                ry_glds16(gp, Ad + gi * (RPI * BK));
+                ry_glds16(gp, Ad + gi * 256);
             }
         } else {
             const int j = q - AI, gi = 4 * j + wave;
-            if (BG % 4 == 0 || gi < BG) ry_glds16(p.wt + (boff[j] + c_bdelta), Bd + gi * (RPI * BK));
+            if (BG % 4 == 0 || gi < BG) ry_glds16(p.wt + (boff[j] + c_bdelta), Bd + gi * 256);
         }
     };
 
-    const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int sw = (lr / WRAP) & (S - 1);        // swizzle key of every fragment row this lane reads (tile rows are multiples of 32)
+    const int sw = (lr >> 1) & 7;                // swizzle key of every A fragment row this lane reads (tile rows are multiples of 32)
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -473,10 +477,9 @@ RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
         const float* Bc = BUF ? Bs1 : Bs0;
         float* An = BUF ? As0 : As1;
         float* Bn = BUF ? Bs0 : Bs1;
-        const bool more = k + 1 < nchunks;
+        const bool more = (k + 1 < nchunks) && !(p.dbg_flags & 128);
         if (more) next_chunk();
         const float* Ab = Ac + ((wm * TM) * 32 + lr) * BK;
-        const float* Bb = Bc + ((wn * TN) * 32 + lr) * BK;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int pos = ((2 * s + lh) ^ sw) * 4;
@@ -484,7 +487,7 @@ RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = ry_ld4(Ab + i * 32 * BK + pos);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(Bb + j * 32 * BK + pos);
+            for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(Bc + ((wn * TN + j) * 4 + s) * 256 + lane * 4);
             if (more) {
 #pragma unroll
                 for (int q = (s * NI) / NS; q < ((s + 1) * NI) / NS; ++q) dma_item(q, An, Bn);

@@ -108,6 +108,7 @@ struct ry_ctx {
     rt::Event t0, t1;
     bool timers = false;
     std::vector<void*> owned;            // context-lifetime device allocations
+    float* zero_page = nullptr;          // 256 bytes of zeros: source of padded rows for the LDS-DMA implicit GEMM
 
     int alloc(float** p, size_t nfloats) {
         void* q = nullptr;
@@ -155,7 +156,7 @@ struct Layer {
     float* scale = nullptr;
     float* shift = nullptr;
     float* w1d = nullptr;                // stage-1 [Ctot][N][4]
-    float* wig = nullptr;                // stage-2 implicit-GEMM [phase][N][tap][Ctot]
+    float* wig = nullptr;                // stage-2 implicit-GEMM blocks [phase][N/64][tap][Ctot/32][fragment order], see wig_inblock()
     float* wdir = nullptr;               // stage-2 direct [phase][tap][Ctot][N]
     float* wig16 = nullptr;              // stage-2 implicit-GEMM bf16 [phase][N/64][tap][Ctot/64][64][64] (ry_net_set_dtype)
     int cin() const { return cin_a + cin_b; }
@@ -284,6 +285,14 @@ static float w2d_at(const Layer& l, const float* W, int n, int c, int ky, int kx
 // implicit-GEMM filters: [phase][N/64][tap][C/32][64 couts][32 k].  Each (64 x 32) chunk a workgroup stages per K step is
 // one contiguous 8 KB block: a wave's 16-byte lane loads cover 1 KB of consecutive addresses, and the rows of a B tile are
 // not spread at a power-of-two stride of 4-16 KB (which funnels every workgroup's B traffic into the same L2 channels).
+// Stage-2 implicit-GEMM weights: blocks [phase][N/64][tap][Ctot/32] of 64 output channels x 32 input channels, each block
+// stored in MFMA FRAGMENT ORDER [n/32 : 2][s : 4][lane : 64][t : 4] with lane = 32 * lh + (n % 32) and k = 8 s + 4 lh + t:
+// the 16 bytes lane `lane` feeds to the four v_mfma_f32_32x32x2_f32 of K step s are contiguous, one (n/32, s) piece is
+// 1 KiB in lane order -- a wave loads its B fragments straight into registers (or a piece into LDS) fully coalesced.
+static inline size_t wig_inblock(int nl, int k) {
+    return (size_t)(nl >> 5) * 1024 + (size_t)(k >> 3) * 256 + (size_t)((((k >> 2) & 1) * 32 + (nl & 31)) * 4) + (size_t)(k & 3);
+}
+
 static void relayout_igemm(const Layer& l, const float* W, std::vector<float>& out) {
     const TapTable t = make_taps(l);
     const int C = l.cin(), N = l.cout, cpt = C / 32;
@@ -293,7 +302,7 @@ static void relayout_igemm(const Layer& l, const float* W, std::vector<float>& o
             for (int tt = 0; tt < t.ntaps; ++tt)
                 for (int c = 0; c < C; ++c) {
                     const size_t blk = (((size_t)ph * (N / 64) + n / 64) * t.ntaps + tt) * cpt + c / 32;
-                    out[(blk * 64 + n % 64) * 32 + c % 32] = w2d_at(l, W, n, c, t.ky[ph][tt], t.kx[ph][tt]);
+                    out[blk * 2048 + wig_inblock(n % 64, c % 32)] = w2d_at(l, W, n, c, t.ky[ph][tt], t.kx[ph][tt]);
                 }
 }
 
@@ -473,7 +482,6 @@ static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in o
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
 static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
 static int g_igemm_dbg = 0; // RY_IGEMM_DBG: ablation bits of ry_igemm_f32_ldsdma (diagnostics; wrong results)
-static float* g_zero_page = nullptr;   // 256 bytes of zeros in device memory (padding source of ry_igemm_f32_dma)
 static int g_ldsdma = 1;    // RY_LDSDMA=0: register-staged ry_igemm_f32 instead of the LDS-DMA kernel (A/B; ~5 % slower end to end)
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
 static unsigned long long* g_dbg = nullptr;
@@ -498,10 +506,12 @@ static const char* tile_name(int tile) {
 // buffer, limited to 3 by its VGPR budget.
 static int tile_occ(int tile) {
     int bm, bn; tile_dims(tile, &bm, &bn);
-    const int lds = g_ldsdma ? (bm + bn) * 32 * 4 * 2 + bm * 16 : (bm + bn) * 36 * 4 + bm * 16;
-    int occ = (160 * 1024) / lds;
-    const int cap = g_ldsdma ? 4 : 3;
-    return occ > cap ? cap : (occ < 1 ? 1 : occ);
+    if (g_ldsdma && bm <= 128) {
+        const int occ = (160 * 1024) / ((bm + bn) * 32 * 4 * 2 + bm * 16);
+        return occ > 4 ? 4 : occ;                                        // <= 128 VGPRs: four waves per SIMD
+    }
+    const int occ = (160 * 1024) / ((bm + bn) * 36 * 4 + bm * 16);
+    return occ > 3 ? 3 : (occ < 1 ? 1 : occ);
 }
 
 // Fraction of the MFMA peak a CU sustains with r co-resident workgroups of the main loop (measured on gfx950: a lone
@@ -583,10 +593,10 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
         dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
         RY_TRY(Lc.begin(bf16 ? tile_name16(lp.tile) : tile_name(lp.tile), l.name, lp.flops, lp.bytes, grid));
-        p.dbg = g_dbg; p.dbg_flags = g_igemm_dbg; p.zeros = g_zero_page;
+        p.dbg = g_dbg; p.dbg_flags = g_igemm_dbg; p.zeros = Lc.ctx->zero_page;
 #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
     do {                                                                                                    \
-        if (g_ldsdma && !g_timing && BM_ <= 128) RY_LAUNCH((ry_igemm_f32_ldsdma<BM_, BN_, WM_, WN_, 32>), grid, 256, Lc.stream, p); \
+        if (g_ldsdma && !g_timing && BM_ <= 128) RY_LAUNCH((ry_igemm_f32_ldsdma<BM_, BN_, WM_, WN_>), grid, 256, Lc.stream, p); \
         else if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
         else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
         else RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 0>), grid, 256, Lc.stream, p);               \
@@ -978,6 +988,24 @@ int ry_device_count(void) {
     return n;
 }
 
+// process-wide A/B and diagnostic switches, read when a context is created
+static int read_env_switches() {
+    if (const char* e = getenv("RY_ILV")) g_ilv = atoi(e);
+    if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
+    if (const char* e = getenv("RY_LDSDMA")) g_ldsdma = atoi(e);
+    if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);
+    if (const char* e = getenv("RY_TILE2D")) g_tile2d = atoi(e);
+    if (const char* e = getenv("RY_BIGTILE")) g_bigtile = atoi(e);
+#ifndef RY_HOST_EMU
+    if (g_timing && !g_dbg) {
+        RT_TRY(hipMalloc((void**)&g_dbg, 8 * sizeof(unsigned long long)));
+        RT_TRY(hipMemset(g_dbg, 0, 8 * sizeof(unsigned long long)));
+    }
+#endif
+    if (const char* e = getenv("RY_TILE64")) g_tile64 = atoi(e) == 256 ? TILE_256x64 : TILE_128x64;
+    return RY_OK;
+}
+
 int ry_init(int device, ry_ctx** out) {
     if (!out) return fail(RY_EINVAL, "null out pointer");
     *out = nullptr;
@@ -991,6 +1019,11 @@ int ry_init(int device, ry_ctx** out) {
     RT_TRY(rt::event_create(&c->t0));
     RT_TRY(rt::event_create(&c->t1));
     c->timers = true;
+    RY_TRY(c->alloc(&c->zero_page, 64));
+    c->owned.push_back(c->zero_page);
+    RT_TRY(rt::dmemset(c->zero_page, 0, 64 * sizeof(float), c->stream));
+    RT_TRY(rt::stream_sync(c->stream));
+    RY_TRY(read_env_switches());
     *out = c.release();
     return RY_OK;
 }
@@ -1001,6 +1034,7 @@ void ry_shutdown(ry_ctx* ctx) {
     rt::stream_sync(ctx->stream);
     if (ctx->timers) { rt::event_destroy(ctx->t0); rt::event_destroy(ctx->t1); }
     rt::stream_destroy(ctx->stream);
+    for (void* q : ctx->owned) rt::dfree(q);
     delete ctx;
 }
 
@@ -1060,24 +1094,6 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
     if (net->desc.bn_eps <= 0.f) net->desc.bn_eps = 2e-5f;
     net->layers = build_topology(*desc);
     if (const char* e = getenv("RY_GRAPH")) net->use_graph = atoi(e) != 0;
-    if (const char* e = getenv("RY_ILV")) g_ilv = atoi(e);
-    if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
-    if (const char* e = getenv("RY_LDSDMA")) g_ldsdma = atoi(e);
-    if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);
-    if (!g_zero_page) {
-        std::vector<float> z(64, 0.f);
-        Arena* keep = new Arena();                                  // process lifetime
-        RY_TRY(upload(*keep, ctx, z, &g_zero_page));
-    }
-    if (const char* e = getenv("RY_TILE2D")) g_tile2d = atoi(e);
-    if (const char* e = getenv("RY_BIGTILE")) g_bigtile = atoi(e);
-#ifndef RY_HOST_EMU
-    if (g_timing && !g_dbg) {
-        RT_TRY(hipMalloc((void**)&g_dbg, 8 * sizeof(unsigned long long)));
-        RT_TRY(hipMemset(g_dbg, 0, 8 * sizeof(unsigned long long)));
-    }
-#endif
-    if (const char* e = getenv("RY_TILE64")) g_tile64 = atoi(e) == 256 ? TILE_256x64 : TILE_128x64;
     RT_TRY(rt::stream_create(&net->stream));
     RT_TRY(rt::event_create(&net->done));
     net->has_done = true;
@@ -1138,7 +1154,7 @@ int ry_net_set_dtype(ry_net* net, int dtype) {
             for (size_t o = 0; o < outer; ++o)
                 for (int c = 0; c < C; ++c)
                     for (int nl = 0; nl < 64; ++nl)
-                        w16[((o * (C / 64) + c / 64) * 64 + nl) * 64 + c % 64] = host_f2bf(w32[((o * (C / 32) + c / 32) * 64 + nl) * 32 + c % 32]);
+                        w16[((o * (C / 64) + c / 64) * 64 + nl) * 64 + c % 64] = host_f2bf(w32[(o * (C / 32) + c / 32) * 2048 + wig_inblock(nl, c % 32)]);
             float* d = nullptr;
             RY_TRY(net->weights.alloc(&d, (n + 1) / 2));
             RT_TRY(rt::h2d(d, w16.data(), n * sizeof(unsigned short), ctx->stream));
@@ -1453,7 +1469,7 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
             for (size_t o = 0; o < outer; ++o)
                 for (int c = 0; c < Cin; ++c)
                     for (int nl = 0; nl < 64; ++nl)
-                        w16[((o * (Cin / 64) + c / 64) * 64 + nl) * 64 + c % 64] = host_f2bf(w32[((o * (Cin / 32) + c / 32) * 64 + nl) * 32 + c % 32]);
+                        w16[((o * (Cin / 64) + c / 64) * 64 + nl) * 64 + c % 64] = host_f2bf(w32[(o * (Cin / 32) + c / 32) * 2048 + wig_inblock(nl, c % 32)]);
             RY_TRY(arena.alloc(&l.wig16, (n + 1) / 2));
             RT_TRY(rt::h2d(l.wig16, w16.data(), n * sizeof(unsigned short), ctx->stream));
             RT_TRY(rt::stream_sync(ctx->stream));
