@@ -129,6 +129,11 @@ int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat*
 /* diagnostics (RY_TIMING=1 only): per-phase shader-clock totals of ry_igemm_f32, summed over waves; reads and resets */
 int ry_debug_igemm_phases(ry_ctx* ctx, unsigned long long* out8);
 
+/* diagnostics: the launch configuration the stage-2 planner picks for an implicit-GEMM layer with M output rows (pixels of
+ * one sub-pixel phase), Cout output channels, `nphases` phases (4 for the k4s2 deconvolution, else 1) and K = 32 * nk:
+ * tile code (see ry_conv2d), external split-K count, K groups per workgroup, estimated microseconds.  No device work. */
+int ry_debug_plan_igemm(int M, int Cout, int nphases, int nk, int* tile, int* splits, int* kgroups, double* est_us);
+
 #ifdef __cplusplus
 }
 #endif

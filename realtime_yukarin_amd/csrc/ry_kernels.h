@@ -330,23 +330,27 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 //     (Loading them global -> registers in the 1 x 4 wave layouts, bypassing the LDS, measured 2 % slower: DESIGN.md 4.1.)
 // Two buffers held in DISTINCT __shared__ arrays and a loop unrolled by two, so that the compiler's LDS-DMA alias tracking
 // does not order the reads of buffer k & 1 behind the DMA into the other buffer.
+// KG = 2 (512 threads): two groups of four waves each take half of the workgroup's K range with their own buffers and are
+// summed through the LDS at the end -- split-K without slabs in HBM or a reduce kernel, for layers whose tile count only
+// fills the chip once (the co-resident second workgroup of a CU becomes the second K group of the same tile).
 // dbg_flags (RY_IGEMM_DBG, diagnostics with wrong results): 4 skip the output stores, 8 skip the K loop, 128 skip the
 // loads inside the K loop.
 // ---------------------------------------------------------------------------------------------
 template <int V> struct RyConst { static constexpr int value = V; };
 
-template <int BM, int BN, int WM, int WN>
-RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
+template <int BM, int BN, int WM, int WN, int KG>
+RY_KERNEL(256 * KG, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
     constexpr int BK = 32, NS = 4;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AG = BM / 8;                // 1-KiB DMA pieces of the A tile (8 rows each)
     constexpr int BG = BN / 8;                // 1-KiB DMA pieces of the B tile ((32 columns, K step) each)
     constexpr int AI = (AG + 3) / 4, BI = (BG + 3) / 4, NI = AI + BI;
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) float As0[BM * BK];
-    __shared__ __attribute__((aligned(16))) float As1[BM * BK];
-    __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
-    __shared__ __attribute__((aligned(16))) float Bs1[BN * BK];
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BM % 32 == 0 && BN % 32 == 0 && BM <= 128, "tile shape");
+    static_assert(KG == 1 || KG == 2, "one or two K groups of four waves");
+    __shared__ __attribute__((aligned(16))) float As0[KG * BM * BK];
+    __shared__ __attribute__((aligned(16))) float As1[KG * BM * BK];
+    __shared__ __attribute__((aligned(16))) float Bs0[KG * BN * BK];
+    __shared__ __attribute__((aligned(16))) float Bs1[KG * BN * BK];
     __shared__ int rY[BM], rX[BM], rP[BM], rO[BM];
 
     const RyConvGeom& g = p.g;
@@ -367,7 +371,7 @@ RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
     const bool subpix = g.ostride == 2;
     const int pdy = subpix ? (phase >> 1) : 0, pdx = subpix ? (phase & 1) : 0;
 
-    for (int r = tid; r < BM; r += 256) {
+    for (int r = tid; r < BM; r += 256 * KG) {
         const int m = m0 + r;
         int yb = -(1 << 20), xb = 0, pb = 0, ob = -1;
         bool live = m < M;
@@ -392,7 +396,8 @@ RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
     }
     __syncthreads();
 
-    const int lane = tid & 63, wave = ry_uniform(tid >> 6);
+    const int lane = tid & 63, wave = ry_uniform((tid >> 6) & 3);
+    const int grp = KG > 1 ? ry_uniform(tid >> 8) : 0;      // K group of this wave: the groups split the K range of the workgroup
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
     // ---- A: DMA role of this lane = row drow / position dpos inside each 8-row piece this wave fills ----
@@ -422,9 +427,12 @@ RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
     const int nk = g.ntaps * cpt;
     const int kc_begin = (int)(((long long)nk * split) / p.splits);
     const int kc_end = (int)(((long long)nk * (split + 1)) / p.splits);
-    const int nchunks = (p.dbg_flags & 8) ? 0 : kc_end - kc_begin;
-    int tap = kc_begin / cpt;
-    int cib = kc_begin - tap * cpt;
+    const int wg_chunks = (p.dbg_flags & 8) ? 0 : kc_end - kc_begin;
+    const int g_begin = kc_begin + (wg_chunks * grp) / KG;                 // this K group's share of the workgroup's range
+    const int nchunks = (wg_chunks * (grp + 1)) / KG - (wg_chunks * grp) / KG;
+    const int max_chunks = (wg_chunks + KG - 1) / KG;                      // barrier count is the same for both groups
+    int tap = g_begin / cpt;
+    int cib = g_begin - tap * cpt;
     int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
 
     // state of the chunk being fetched (wave-uniform)
@@ -464,22 +472,25 @@ RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    float* const A0 = As0 + grp * (BM * BK); float* const A1 = As1 + grp * (BM * BK);
+    float* const B0 = Bs0 + grp * (BN * BK); float* const B1 = Bs1 + grp * (BN * BK);
     if (nchunks > 0) {
         next_chunk();
 #pragma unroll
-        for (int q = 0; q < NI; ++q) dma_item(q, As0, Bs0);
+        for (int q = 0; q < NI; ++q) dma_item(q, A0, B0);
     }
     __syncthreads();
 
     auto run_chunk = [&](auto bufc, int k) {
         constexpr int BUF = decltype(bufc)::value;
-        const float* Ac = BUF ? As1 : As0;
-        const float* Bc = BUF ? Bs1 : Bs0;
-        float* An = BUF ? As0 : As1;
-        float* Bn = BUF ? Bs0 : Bs1;
+        const float* Ac = BUF ? A1 : A0;
+        const float* Bc = BUF ? B1 : B0;
+        float* An = BUF ? A0 : A1;
+        float* Bn = BUF ? B0 : B1;
         const bool more = (k + 1 < nchunks) && !(p.dbg_flags & 128);
         if (more) next_chunk();
         const float* Ab = Ac + ((wm * TM) * 32 + lr) * BK;
+        if (KG == 1 || k < nchunks) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int pos = ((2 * s + lh) ^ sw) * 4;
@@ -499,11 +510,35 @@ RY_KERNEL(256, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
         }
+        }
         __syncthreads();                       // DMA of chunk k + 1 landed (vmcnt) and buffer BUF is free again
     };
-    for (int k = 0; k < nchunks; k += 2) {
+    for (int k = 0; k < max_chunks; k += 2) {
         run_chunk(RyConst<0>(), k);
-        if (k + 1 < nchunks) run_chunk(RyConst<1>(), k + 1);
+        if (k + 1 < max_chunks) run_chunk(RyConst<1>(), k + 1);
+    }
+
+    if (KG > 1) {
+        // Sum the two K groups inside the workgroup: group 1 parks its accumulators in the (now idle) B buffers, lane-linear,
+        // group 0 adds them in a fixed order (group 0 + group 1) and runs the epilogue.  No slabs, no second kernel.
+        float* scr = (wave < 2 ? Bs0 : Bs1) + (wave & 1) * (TM * TN * 16 * 64) + lane;
+        static_assert(KG == 1 || 2 * TM * TN * 16 * 64 <= KG * BN * BK, "accumulators of two waves fit one B buffer");
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) scr[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += scr[((i * TN + j) * 16 + r) * 64];
     }
 
     if (p.dbg_flags & 4) return;

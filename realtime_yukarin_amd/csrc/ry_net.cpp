@@ -336,6 +336,7 @@ struct LayerPlan {
     float* raw = nullptr;                     // [splits][B*Lo][N] raw sums
     // stage-2
     int path = 0, tile = 0;
+    int kg = 1;                               // K groups inside a workgroup (LDS-DMA implicit GEMM): 2 = split-K summed through the LDS
     float* out = nullptr;                     // NHWC activation
     float* slabs = nullptr;
     int last_rows = 0, last_cols = 0, last_exp = 0;   // PATH_LAST: fused exp / edge-pad / crop
@@ -482,93 +483,119 @@ static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in o
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
 static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
 static int g_igemm_dbg = 0; // RY_IGEMM_DBG: ablation bits of ry_igemm_f32_ldsdma (diagnostics; wrong results)
+static int g_kgroups = 1;   // RY_KGROUPS=0: never split K inside a workgroup (external split-K + reduce kernel only)
 static int g_ldsdma = 1;    // RY_LDSDMA=0: register-staged ry_igemm_f32 instead of the LDS-DMA kernel (A/B; ~5 % slower end to end)
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
 static unsigned long long* g_dbg = nullptr;
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
-static const char* tile_name(int tile) {
+static const char* tile_name(int tile, int kg) {
     const bool dma = g_ldsdma && !g_timing;
+    const bool k2 = dma && kg == 2;
     switch (tile) {
-        case TILE_128x128: return dma ? "ry_igemm_f32_ldsdma<128,128>" : "ry_igemm_f32<128,128>";
+        case TILE_128x128: return k2 ? "ry_igemm_f32_ldsdma<128,128,k2>" : dma ? "ry_igemm_f32_ldsdma<128,128>" : "ry_igemm_f32<128,128>";
         case TILE_256x64: return "ry_igemm_f32<256,64>";
-        case TILE_64x128: return dma ? "ry_igemm_f32_ldsdma<64,128>" : "ry_igemm_f32<64,128>";
-        case TILE_128x64: return dma ? "ry_igemm_f32_ldsdma<128,64>" : "ry_igemm_f32<128,64>";
-        case TILE_96x128: return dma ? "ry_igemm_f32_ldsdma<96,128>" : "ry_igemm_f32<96,128>";
+        case TILE_64x128: return k2 ? "ry_igemm_f32_ldsdma<64,128,k2>" : dma ? "ry_igemm_f32_ldsdma<64,128>" : "ry_igemm_f32<64,128>";
+        case TILE_128x64: return k2 ? "ry_igemm_f32_ldsdma<128,64,k2>" : dma ? "ry_igemm_f32_ldsdma<128,64>" : "ry_igemm_f32<128,64>";
+        case TILE_96x128: return k2 ? "ry_igemm_f32_ldsdma<96,128,k2>" : dma ? "ry_igemm_f32_ldsdma<96,128>" : "ry_igemm_f32<96,128>";
         case TILE_256x128: return "ry_igemm_f32<256,128>";
-        default: return dma ? "ry_igemm_f32_ldsdma<32,128>" : "ry_igemm_f32<32,128>";
+        default: return k2 ? "ry_igemm_f32_ldsdma<32,128,k2>" : dma ? "ry_igemm_f32_ldsdma<32,128>" : "ry_igemm_f32<32,128>";
     }
 }
 
-// choose tile + split-K for one stage-2 layer
-// efficiency of running `blocks` workgroups of one launch on 256 CUs with split-K `s`
+// ---- choice of tile, split-K and K groups for one stage-2 layer ----
 // Workgroups of one tile that fit a CU.  LDS-DMA kernel: two unpadded BK = 32 buffers; register-staged kernel: one padded
 // buffer, limited to 3 by its VGPR budget.
-static int tile_occ(int tile) {
+static int tile_occ(int tile, int kg) {
     int bm, bn; tile_dims(tile, &bm, &bn);
     if (g_ldsdma && bm <= 128) {
-        const int occ = (160 * 1024) / ((bm + bn) * 32 * 4 * 2 + bm * 16);
-        return occ > 4 ? 4 : occ;                                        // <= 128 VGPRs: four waves per SIMD
+        const int occ = (160 * 1024) / (kg * (bm + bn) * 32 * 4 * 2 + bm * 16);
+        const int cap = 4 / kg;                                          // <= 128 VGPRs: four waves per SIMD
+        return occ > cap ? cap : occ;
     }
     const int occ = (160 * 1024) / ((bm + bn) * 36 * 4 + bm * 16);
     return occ > 3 ? 3 : (occ < 1 ? 1 : occ);
 }
 
-// Fraction of the MFMA peak a CU sustains with r co-resident workgroups of the main loop (measured on gfx950: a lone
-// 4-wave workgroup cannot cover its own barriers and LDS latency).
+// Fraction of the MFMA peak a CU sustains with r co-resident four-wave groups running the main loop (measured on gfx950:
+// a lone group cannot cover its own barriers and LDS latency).
 static double cu_rate(int r) {
     static const double f[5] = {0.0, 0.36, 0.70, 0.72, 0.72};
     return f[r > 4 ? 4 : r];
 }
 
-static double grid_eff(long blocks, int s, bool tinyM, int occ) {
+// Estimated time (microseconds) of one layer: `blocks` output tiles of bm rows, each split over s workgroups of kg
+// four-wave K groups, on 256 CUs that hold occ workgroups at a time.  The busiest CU sets the main-loop time (a partial
+// last round runs at the rate of its fewer resident groups); external split-K adds the slab traffic and a reduce launch.
+static double est_time(long blocks, int bm, int bn, int s, int occ, int kg, int M, int N, int nk) {
     const long g = blocks * s;
-    if (tinyM) return g >= 1024 ? 1.0 - 1e-4 * s : (double)g / 1024.0;   // weight streaming: fill the chip with loads in flight
-    const long per_cu = (g + 255) / 256;                                   // the busiest CU sets the time
+    const long per_cu = (g + 255) / 256;
     const long full = per_cu / occ, rem = per_cu % occ;
-    const double t = (double)full * occ / cu_rate(occ) + (rem ? (double)rem / cu_rate((int)rem) : 0.0);
-    double eff = ((double)g / 256.0) / t / cu_rate(4);
-    if (s > 1) eff -= 0.10 + 0.004 * (s - 1);                              // split-K: slab writes at the tail + a reduce pass (~10 % measured)
-    return eff;
+    const double tile_us = 2.0 * bm * bn * (32.0 * nk) / (157.3e6 / 256.0);   // one tile on one CU at the MFMA peak
+    const double w = tile_us / (double)(s * kg);                              // work of one four-wave group
+    double t = (double)full * occ * kg * w / cu_rate(occ * kg) + (rem ? (double)rem * kg * w / cu_rate((int)rem * kg) : 0.0);
+    t += 4.0 + (double)M * N * 4.0 / 5.0e6;                                     // launch + ramp, output stores at ~5 TB/s (exposed: one round)
+    if (s > 1) t += 5.0 + (2.0 * s) * M * N * 4.0 / 4.0e6;                     // s slab writes + s slab reads at ~4 TB/s, reduce launch
+    if (kg > 1) t += 1.0;                                                       // in-LDS sum, half of the waves idle in the epilogue
+    return t;
 }
 
-static int best_split(long blocks, int nk, bool tinyM, int occ, double* eff_out) {
-    const int smax = tinyM ? 128 : 32, min_chunks = tinyM ? 2 : 4;
-    int best = 1; double be = -1.0;
+static int best_split(long blocks, int bm, int bn, int nk, bool tinyM, int occ, int kg, int M, int N, double* t_out) {
+    const int smax = tinyM ? 128 : 32, min_chunks = (tinyM ? 2 : 4) * kg;
+    int best = 1; double bt = 1e30;
     for (int s = 1; s <= smax && s <= (nk >= min_chunks ? nk / min_chunks : 1); ++s) {
-        const double e = grid_eff(blocks, s, tinyM, occ);
-        if (e > be + 1e-9) { be = e; best = s; }
+        double t;
+        if (tinyM) { const long g = blocks * s; t = g >= 1024 ? 1.0 + 1e-4 * s : 1024.0 / (double)g; }   // weight streaming: fill the chip with loads in flight
+        else t = est_time(blocks, bm, bn, s, occ, kg, M, N, nk);
+        if (t < bt - 1e-9) { bt = t; best = s; }
     }
-    if (eff_out) *eff_out = be;
+    if (t_out) *t_out = bt;
     return best;
 }
 
-static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits) {
-    // MFMA-bound layers: every CU should hold a full set of co-resident workgroups for the whole launch.  Candidate
-    // M-tiles 128 / 96 / 64 (N-tile 128) are scored by (row utilisation) x (grid efficiency with the best split-K).
+static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits, int* kg) {
+    // MFMA-bound layers: every CU should hold a full set of co-resident wave groups for the whole launch.  Candidate
+    // M-tiles 128 / 96 / 64 (N-tile 128), with one or two K groups per workgroup and the best external split-K, are
+    // compared by estimated time.
+    const bool kg_ok = g_ldsdma && g_kgroups && M > 64 && nk >= 16;
+    const int N = l.cout;
     if (*tile == 0) {
-        if (l.cout % 128 != 0) *tile = g_tile64;
+        if (N % 128 != 0) *tile = g_tile64;
         else if (M <= 32) *tile = TILE_32x128;
         else if (M <= 64) *tile = TILE_64x128;
         else if (g_bigtile && M >= 2048) *tile = TILE_256x128;
         else {
             const int cand[3] = {TILE_128x128, TILE_96x128, TILE_64x128};
-            const double bias[3] = {0.0, -0.02, -0.08};                   // smaller tiles re-read more B per flop
-            double be = -1.0; int bt = TILE_128x128;
-            for (int c = 0; c < 3; ++c) {
-                int bm, bn; tile_dims(cand[c], &bm, &bn);
-                const long mt = (M + bm - 1) / bm;
-                double e = 0.0;
-                best_split(mt * (l.cout / bn) * nphases, nk, false, tile_occ(cand[c]), &e);
-                e = e * ((double)M / (double)(mt * bm)) + bias[c];
-                if (e > be + 1e-9) { be = e; bt = cand[c]; }
-            }
-            *tile = bt;
+            const double bias[3] = {1.0, 1.02, 1.08};                     // smaller tiles re-read more B per flop
+            double bt = 1e30; int btile = TILE_128x128, bk = 1;
+            for (int c = 0; c < 3; ++c)
+                for (int k = 1; k <= ((kg_ok && *kg == 0) ? 2 : 1); ++k) {
+                    const int kk = *kg > 0 ? *kg : k;
+                    int bm, bn; tile_dims(cand[c], &bm, &bn);
+                    const long mt = (M + bm - 1) / bm;
+                    double t = 0.0;
+                    best_split(mt * (N / bn) * nphases, bm, bn, nk, false, tile_occ(cand[c], kk), kk, M, N, &t);
+                    t *= bias[c];
+                    if (t < bt - 1e-9) { bt = t; btile = cand[c]; bk = kk; }
+                }
+            *tile = btile;
+            if (*kg == 0) *kg = bk;
         }
     }
     int bm, bn; tile_dims(*tile, &bm, &bn);
-    if (*splits == 0) *splits = best_split((long)((M + bm - 1) / bm) * (l.cout / bn) * nphases, nk, M <= 64, tile_occ(*tile), nullptr);
-    if (*splits > nk) *splits = nk;
+    const long blocks = (long)((M + bm - 1) / bm) * (N / bn) * nphases;
+    if (*kg == 0) {
+        *kg = 1;
+        if (kg_ok && bm <= 128 && *splits == 0) {
+            double t1 = 0.0, t2 = 0.0;
+            best_split(blocks, bm, bn, nk, false, tile_occ(*tile, 1), 1, M, N, &t1);
+            best_split(blocks, bm, bn, nk, false, tile_occ(*tile, 2), 2, M, N, &t2);
+            if (t2 < t1 - 1e-9) *kg = 2;
+        }
+    }
+    if (bm > 128 || !g_ldsdma) *kg = 1;
+    if (*splits == 0) *splits = best_split(blocks, bm, bn, nk, M <= 64, tile_occ(*tile, *kg), *kg, M, N, nullptr);
+    if (*splits * *kg > nk) { *kg = 1; if (*splits > nk) *splits = nk; }
 }
 
 static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int B, const float* s1, int C1, const float* s2, int C2, float slope) {
@@ -592,11 +619,14 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         }
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
         dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
-        RY_TRY(Lc.begin(bf16 ? tile_name16(lp.tile) : tile_name(lp.tile), l.name, lp.flops, lp.bytes, grid));
+        RY_TRY(Lc.begin(bf16 ? tile_name16(lp.tile) : tile_name(lp.tile, lp.kg), l.name, lp.flops, lp.bytes, grid));
         p.dbg = g_dbg; p.dbg_flags = g_igemm_dbg; p.zeros = Lc.ctx->zero_page;
 #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
     do {                                                                                                    \
-        if (g_ldsdma && !g_timing && BM_ <= 128) RY_LAUNCH((ry_igemm_f32_ldsdma<BM_, BN_, WM_, WN_>), grid, 256, Lc.stream, p); \
+        if (g_ldsdma && !g_timing && BM_ <= 128) {                                                            \
+            if (lp.kg == 2) RY_LAUNCH((ry_igemm_f32_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 2>), grid, 512, Lc.stream, p); \
+            else RY_LAUNCH((ry_igemm_f32_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 1>), grid, 256, Lc.stream, p);          \
+        }                                                                                                   \
         else if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
         else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
         else RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 0>), grid, 256, Lc.stream, p);               \
@@ -777,8 +807,10 @@ static int build_plan(ry_net* net, Plan& P) {
                 const int M = B * (l.deconv ? lp.Hi * lp.Wi : lp.Ho * lp.Wo);
                 const int nk = t.ntaps * (l.cin() / 32);
                 lp.path = PATH_IGEMM; lp.tile = 0; lp.splits = 0;
-                choose_igemm(l, M, t.nphases, nk, &lp.tile, &lp.splits);
-                if (net->dtype == 1 && l.wig16 && lp.tile != TILE_256x64 && lp.tile != TILE_256x128) {
+                const bool want16 = net->dtype == 1 && l.wig16;
+                lp.kg = want16 ? 1 : 0;                                // the bf16 kernel has no K groups
+                choose_igemm(l, M, t.nphases, nk, &lp.tile, &lp.splits, &lp.kg);
+                if (want16 && lp.tile != TILE_256x64 && lp.tile != TILE_256x128) {
                     lp.path = PATH_IGEMM_BF16;                         // 64-deep K chunks: half as many as the fp32 kernel
                     if (lp.splits > nk / 2) lp.splits = nk / 2 > 0 ? nk / 2 : 1;
                 }
@@ -993,6 +1025,7 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_ILV")) g_ilv = atoi(e);
     if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
     if (const char* e = getenv("RY_LDSDMA")) g_ldsdma = atoi(e);
+    if (const char* e = getenv("RY_KGROUPS")) g_kgroups = atoi(e);
     if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);
     if (const char* e = getenv("RY_TILE2D")) g_tile2d = atoi(e);
     if (const char* e = getenv("RY_BIGTILE")) g_bigtile = atoi(e);
@@ -1359,6 +1392,20 @@ int ry_mc2sp(ry_ctx* ctx, const float* mc, const float* mtx, int n, int m, int b
 }
 
 // diagnostics: read and reset the phase totals of the RY_TIMING=1 kernel variant (8 counters)
+int ry_debug_plan_igemm(int M, int Cout, int nphases, int nk, int* tile, int* splits, int* kgroups, double* est_us) {
+    if (!tile || !splits || !kgroups) return fail(RY_EINVAL, "null argument");
+    if (M < 1 || Cout < 64 || Cout % 64 != 0 || nphases < 1 || nk < 1) return fail(RY_EINVAL, "not an implicit-GEMM layer shape");
+    RY_TRY(read_env_switches());
+    Layer l; l.cout = Cout;
+    *tile = 0; *splits = 0; *kgroups = 0;
+    choose_igemm(l, M, nphases, nk, tile, splits, kgroups);
+    if (est_us) {
+        int bm, bn; tile_dims(*tile, &bm, &bn);
+        *est_us = est_time((long)((M + bm - 1) / bm) * (Cout / bn) * nphases, bm, bn, *splits, tile_occ(*tile, *kgroups), *kgroups, M, Cout, nk);
+    }
+    return RY_OK;
+}
+
 int ry_debug_igemm_phases(ry_ctx* ctx, unsigned long long* out8) {
     if (!ctx || !out8) return fail(RY_EINVAL, "null argument");
     for (int i = 0; i < 8; ++i) out8[i] = 0;
@@ -1452,10 +1499,13 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
     if (lp.path == PATH_IGEMM || lp.path == PATH_IGEMM_BF16) {
         const TapTable t = make_taps(l);
         const int M = B * (transposed ? H * Wd : lp.Ho * lp.Wo);
+        lp.kg = (tile & 16) ? 2 : ((tile & 32) ? 1 : 0);                    // +16: two K groups per workgroup, +32: one, else automatic
+        tile &= 15;
+        if (lp.path == PATH_IGEMM_BF16) lp.kg = 1;
         lp.tile = tile; lp.splits = splits;
         if (tile < 0 || tile > TILE_256x128) return fail(RY_EINVAL, "unknown tile");
         if ((tile == TILE_256x64 || tile == TILE_128x64) ? Cout % 64 : (tile != 0 && Cout % 128)) return fail(RY_EINVAL, "tile does not divide Cout");
-        choose_igemm(l, M, t.nphases, t.ntaps * (Cin / 32), &lp.tile, &lp.splits);
+        choose_igemm(l, M, t.nphases, t.ntaps * (Cin / 32), &lp.tile, &lp.splits, &lp.kg);
         if (lp.path == PATH_IGEMM_BF16) {
             if (lp.tile == TILE_256x64 || lp.tile == TILE_256x128) return fail(RY_EINVAL, "no bf16 instantiation of that tile");
             const int nk64 = t.ntaps * (Cin / 64);

@@ -49,6 +49,15 @@ CONV2D_CASES = [
     (1, 20, 24, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '96x128', 1),   # 120 rows: one full 96-row tile + a ragged one
     (1, 6, 8, 64, 256, 4, 2, 1, True, 'relu', 'igemm', '96x128', 2),       # deconv, 2 N-tiles, 4 phases, split-K, XCD-ordered grid
     (1, 6, 10, 64, 64, 4, 2, 1, True, 'relu', 'igemm', '128x64', 0),
+    # two K groups per workgroup (split-K summed through the LDS), alone and combined with external split-K
+    (1, 24, 32, 64, 128, 4, 2, 1, False, 'relu', 'igemm', '96x128k2', 1),  # 32 chunks: 16 + 16
+    (1, 20, 24, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '96x128k2', 1), # ragged last tile, 16 chunks
+    (1, 16, 16, 96, 128, 3, 1, 1, False, 'lrelu', 'igemm', '128x128k2', 1),# 27 chunks: 13 + 14 (unequal groups)
+    (1, 6, 8, 64, 256, 4, 2, 1, True, 'relu', 'igemm', '96x128k2', 2),     # deconv phases, external split 2 x 2 groups (8 chunks -> 2 + 2 | 2 + 2)
+    (1, 16, 20, 64, 64, 4, 2, 1, False, 'relu', 'igemm', '128x64k2', 1),
+    (2, 8, 16, 32, 128, 4, 2, 1, True, 'relu', 'igemm', '64x128k2', 1),    # 4 chunks per phase: 2 + 2
+    (1, 12, 16, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '32x128k2', 3), # 16 chunks, 3 external splits of 5/5/6 -> groups of 2+3 / 2+3 / 3+3
+    (1, 24, 32, 64, 128, 4, 2, 1, False, 'relu', 'igemm', '96x128k1', 2),  # forced single group
 ]
 
 
