@@ -474,10 +474,18 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
 
     float* const A0 = As0 + grp * (BM * BK); float* const A1 = As1 + grp * (BM * BK);
     float* const B0 = Bs0 + grp * (BN * BK); float* const B1 = Bs1 + grp * (BN * BK);
+    // A workgroup with at most two chunks per K group (the weight-streaming layers with M <= 64 rows and split-K in the
+    // hundreds) fetches both up front: its time is a chain of memory latencies, not MFMA work.
+    const bool pre2 = max_chunks <= 2;
     if (nchunks > 0) {
         next_chunk();
 #pragma unroll
         for (int q = 0; q < NI; ++q) dma_item(q, A0, B0);
+        if (pre2 && nchunks > 1) {
+            next_chunk();
+#pragma unroll
+            for (int q = 0; q < NI; ++q) dma_item(q, A1, B1);
+        }
     }
     __syncthreads();
 
@@ -487,7 +495,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
         const float* Bc = BUF ? B1 : B0;
         float* An = BUF ? A0 : A1;
         float* Bn = BUF ? B0 : B1;
-        const bool more = (k + 1 < nchunks) && !(p.dbg_flags & 128);
+        const bool more = (k + 1 < nchunks) && !pre2 && !(p.dbg_flags & 128);
         if (more) next_chunk();
         const float* Ab = Ac + ((wm * TM) * 32 + lr) * BK;
         if (KG == 1 || k < nchunks) {
@@ -800,16 +808,20 @@ RY_KERNEL(256) void ry_splitk_reduce_wide(RyReduceParams p) {
     const long long i4 = ((long long)blockIdx.x * 64 + col) * 4;
     const bool live = i4 < p.total;
     const size_t st = (size_t)p.slab_stride;
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f};
     if (live) {
-        int k = grp;
-        for (; k + 4 < p.splits; k += 8) {
-            a0 += ry_ld4(p.slabs + (size_t)k * st + i4);
-            a1 += ry_ld4(p.slabs + (size_t)(k + 4) * st + i4);
+        // group grp sums slabs grp, grp + 4, ... in that order; eight loads are in flight per round trip (the kernel is a
+        // chain of memory latencies: 24..384 workgroups, up to 32 slabs per group)
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (int k = grp; k < p.splits; k += 32) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (k + 4 * u < p.splits) ? ry_ld4(p.slabs + (size_t)(k + 4 * u) * st + i4) : zero;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a0 += v[u];
         }
-        if (k < p.splits) a0 += ry_ld4(p.slabs + (size_t)k * st + i4);
     }
-    ry_st4(&part[(grp * 64 + col) * 4], a0 + a1);
+    ry_st4(&part[(grp * 64 + col) * 4], a0);
     __syncthreads();
     if (grp == 0 && live) {
         const f32x4 s = (ry_ld4(&part[col * 4]) + ry_ld4(&part[(64 + col) * 4])) + (ry_ld4(&part[(128 + col) * 4]) + ry_ld4(&part[(192 + col) * 4]));

@@ -57,3 +57,37 @@ def test_missing_library_is_a_loud_failure(tmp_path):
     with pytest.raises(_lib.Ry355Error) as ei:
         _lib.Ry355Lib(tmp_path / 'libry355.so')
     assert 'no CPU fallback' in str(ei.value)
+
+
+TILE_DIMS = {1: (128, 128), 2: (256, 64), 3: (64, 128), 4: (32, 128), 5: (128, 64), 6: (96, 128), 7: (256, 128)}
+
+
+@pytest.mark.parametrize('frames', [128, 384, 1024])
+@pytest.mark.parametrize('batch', [1, 4])
+def test_stage2_planner_picks_legal_launches(lib, frames, batch):
+    """Host logic of the stage-2 planner (no device work): for every implicit-GEMM layer shape of the base-64 predictor the
+    chosen tile divides Cout, split-K x K groups never exceeds the K chunks, K groups only with the 4-wave tiles."""
+    ch = [64, 128, 256, 512, 512, 512, 512, 512]
+    shapes = []
+    h, w = frames, 512
+    for i in range(1, 8):                                  # encoder c1..c7: k4 s2 convolutions
+        h, w = h // 2, w // 2
+        shapes.append((batch * h * w, ch[i], 1, 16 * ch[i - 1] // 32))
+    dec_in, dec_out = [512, 1024, 1024, 1024, 1024, 512, 256], [512, 512, 512, 512, 256, 128, 64]
+    for j in range(7):                                     # decoder c0..c6: k4 s2 deconvolutions = 4 phases of 2x2 taps
+        shapes.append((batch * h * w, dec_out[j], 4, 4 * dec_in[j] // 32))
+        h, w = h * 2, w * 2
+    for M, N, nph, nk in shapes:
+        t, s, k, e = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        lib.check(lib.dll.ry_debug_plan_igemm(M, N, nph, nk, ctypes.byref(t), ctypes.byref(s), ctypes.byref(k), ctypes.byref(e)))
+        bm, bn = TILE_DIMS[t.value]
+        assert N % bn == 0
+        assert 1 <= s.value and k.value in (1, 2) and s.value * k.value <= nk
+        assert k.value == 1 or bm <= 128
+        assert e.value > 0.0
+
+
+def test_stage2_planner_rejects_non_igemm_shapes(lib):
+    t, s, k = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.dll.ry_debug_plan_igemm(100, 48, 1, 8, ctypes.byref(t), ctypes.byref(s), ctypes.byref(k), None) != 0
+    assert b'implicit-GEMM' in lib.dll.ry_last_error()
