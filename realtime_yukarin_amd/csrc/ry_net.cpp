@@ -707,6 +707,8 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     return RY_OK;
 }
 
+static int g_s1_wgs = 256, g_s1_maxs = 32;   // stage-1 split heuristic (RY_S1_WGS / RY_S1_MAXS: tuning aids; 128 / 16 measured 0.275 ms, 256 / 32 0.231 ms, 512 / 64 0.238 ms per forward)
+
 static int c1d_mode(const Layer& l) {
     if (l.deconv) return RY_C1D_DECONV;
     if (l.k == 4 && l.stride == 2 && l.pad == 1 && l.dil == 1) return RY_C1D_S2;
@@ -746,14 +748,14 @@ static int launch_conv1d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
 
 static int choose_splits_1d(const Layer& l, int B, int rows, int mode) {
     // weight streaming wants many workgroups, but every split is re-summed by each consumer tile: aim for
-    // ~128 workgroups, at most 16 splits, at least 16 input channels per split
+    // ~256 workgroups, at most 32 splits, at least 16 input channels per split
     const int TL = c1d_tile_len(mode);
     const int cogroups = (l.cout + 63) / 64;
     const long wgs = (long)((cogroups + 3) / 4) * ((rows + TL - 1) / TL) * B;
-    int s = (int)((128 + wgs - 1) / wgs);
+    int s = (int)((g_s1_wgs + wgs - 1) / wgs);
     const int maxs = l.cin() / 16 > 0 ? l.cin() / 16 : 1;
     if (s > maxs) s = maxs;
-    if (s > 16) s = 16;
+    if (s > g_s1_maxs) s = g_s1_maxs;
     if (s < 1) s = 1;
     return s;
 }
@@ -1026,6 +1028,8 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
     if (const char* e = getenv("RY_LDSDMA")) g_ldsdma = atoi(e);
     if (const char* e = getenv("RY_KGROUPS")) g_kgroups = atoi(e);
+    if (const char* e = getenv("RY_S1_WGS")) g_s1_wgs = atoi(e);
+    if (const char* e = getenv("RY_S1_MAXS")) g_s1_maxs = atoi(e);
     if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);
     if (const char* e = getenv("RY_TILE2D")) g_tile2d = atoi(e);
     if (const char* e = getenv("RY_BIGTILE")) g_bigtile = atoi(e);
