@@ -489,17 +489,18 @@ static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memt
 static unsigned long long* g_dbg = nullptr;
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
+// Kernel names as rocprofv3 prints them (template arguments, no spaces): bench.py matches them against profiles/*.
 static const char* tile_name(int tile, int kg) {
     const bool dma = g_ldsdma && !g_timing;
     const bool k2 = dma && kg == 2;
     switch (tile) {
-        case TILE_128x128: return k2 ? "ry_igemm_f32_ldsdma<128,128,k2>" : dma ? "ry_igemm_f32_ldsdma<128,128>" : "ry_igemm_f32<128,128>";
+        case TILE_128x128: return k2 ? "ry_igemm_f32_ldsdma<128,128,2,2,2>" : dma ? "ry_igemm_f32_ldsdma<128,128,2,2,1>" : "ry_igemm_f32<128,128>";
         case TILE_256x64: return "ry_igemm_f32<256,64>";
-        case TILE_64x128: return k2 ? "ry_igemm_f32_ldsdma<64,128,k2>" : dma ? "ry_igemm_f32_ldsdma<64,128>" : "ry_igemm_f32<64,128>";
-        case TILE_128x64: return k2 ? "ry_igemm_f32_ldsdma<128,64,k2>" : dma ? "ry_igemm_f32_ldsdma<128,64>" : "ry_igemm_f32<128,64>";
-        case TILE_96x128: return k2 ? "ry_igemm_f32_ldsdma<96,128,k2>" : dma ? "ry_igemm_f32_ldsdma<96,128>" : "ry_igemm_f32<96,128>";
+        case TILE_64x128: return k2 ? "ry_igemm_f32_ldsdma<64,128,1,4,2>" : dma ? "ry_igemm_f32_ldsdma<64,128,1,4,1>" : "ry_igemm_f32<64,128>";
+        case TILE_128x64: return k2 ? "ry_igemm_f32_ldsdma<128,64,4,1,2>" : dma ? "ry_igemm_f32_ldsdma<128,64,4,1,1>" : "ry_igemm_f32<128,64>";
+        case TILE_96x128: return k2 ? "ry_igemm_f32_ldsdma<96,128,1,4,2>" : dma ? "ry_igemm_f32_ldsdma<96,128,1,4,1>" : "ry_igemm_f32<96,128>";
         case TILE_256x128: return "ry_igemm_f32<256,128>";
-        default: return k2 ? "ry_igemm_f32_ldsdma<32,128,k2>" : dma ? "ry_igemm_f32_ldsdma<32,128>" : "ry_igemm_f32<32,128>";
+        default: return k2 ? "ry_igemm_f32_ldsdma<32,128,1,4,2>" : dma ? "ry_igemm_f32_ldsdma<32,128,1,4,1>" : "ry_igemm_f32<32,128>";
     }
 }
 
