@@ -18,7 +18,7 @@
 //                       PRODUCER's split-sum + folded BN + activation (deferred epilogue; skip
 //                       connections read through two source descriptors, no materialised concat)
 //   ry_materialize      split-sum + folded BN + activation (+GLU) into a dense tensor
-//   ry_colmin / ry_pad_rows / ry_sr_post   the numpy.pad('minimum') / log / exp / edge-pad wrappers
+//   ry_pad_min_rows / ry_pad_rows / ry_sr_post   the numpy.pad('minimum') / log / exp / edge-pad wrappers
 #pragma once
 #include "ry_dev.h"
 
@@ -1336,23 +1336,6 @@ RY_KERNEL(256) void ry_materialize(RyMaterializeParams p) {
 // ---------------------------------------------------------------------------------------------
 // Wrapper arithmetic: numpy.pad(mode='minimum') along time, log / drop-last-bin, exp / edge-pad / crop.
 // ---------------------------------------------------------------------------------------------
-struct RyColminParams { const float* in; int rows, cols; float* minv; long long in_bstride; int minv_bstride; };
-
-RY_KERNEL(256) void ry_colmin(RyColminParams p) {     // blockIdx.y = window of the batch
-    __shared__ float red[256];
-    const int tid = (int)threadIdx.x;
-    const int c = (int)blockIdx.x * 64 + (tid & 63);
-    const float* in = p.in + (size_t)blockIdx.y * (size_t)p.in_bstride;
-    float m = INFINITY;
-    if (c < p.cols)
-        for (int r = tid >> 6; r < p.rows; r += 4) m = fminf(m, in[(size_t)r * p.cols + c]);
-    red[tid] = m;
-    __syncthreads();
-    if (tid < 64 && c < p.cols)
-        p.minv[(size_t)blockIdx.y * p.minv_bstride + c] =
-            fminf(fminf(red[tid], red[tid + 64]), fminf(red[tid + 128], red[tid + 192]));
-}
-
 struct RyPadRowsParams {
     const float* in;            // [batch][rows_in][cols_in]
     const float* minv;          // [batch][cols_in] column minima (may be null when rows_out <= rows_in)
@@ -1362,6 +1345,40 @@ struct RyPadRowsParams {
     long long in_bstride, out_bstride;
     int minv_bstride;
 };
+
+// ry_pad_min_rows -- ry_colmin + ry_pad_rows in one launch (one graph node less on the convert path): a workgroup owns 16
+// columns (16 row groups x 16 columns), takes their minimum over the real rows, then writes the padded / logged block.
+RY_KERNEL(256) void ry_pad_min_rows(RyPadRowsParams p) {      // blockIdx.y = window of the batch
+    __shared__ float red[256];
+    const int tid = (int)threadIdx.x, cl = tid & 15, grp = tid >> 4;
+    const int c = (int)blockIdx.x * 16 + cl;
+    const float* in = p.in + (size_t)blockIdx.y * (size_t)p.in_bstride;
+    float* out = p.out + (size_t)blockIdx.y * (size_t)p.out_bstride;
+    const bool cin_ok = c < p.cols_in, cout_ok = c < p.cols_out;
+    float m = INFINITY;
+    const bool need_min = p.rows_out > p.rows_in;
+    // pass 1: rows grp, grp + 16, ...: copy (log) the real rows and track the column minimum; 8 loads in flight per lane
+    for (int r0 = grp; r0 < p.rows_in; r0 += 128) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int r = r0 + 16 * u; v[u] = (cin_ok && r < p.rows_in) ? in[(size_t)r * p.cols_in + c] : INFINITY; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 16 * u;
+            m = fminf(m, v[u]);
+            if (cout_ok && r < p.rows_in && r < p.rows_out) out[(size_t)r * p.cols_out + c] = p.take_log ? logf(v[u]) : v[u];
+        }
+    }
+    if (!need_min) return;
+    red[tid] = m;
+    __syncthreads();
+    float mm = red[cl];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) mm = fminf(mm, red[g * 16 + cl]);
+    if (!cout_ok) return;
+    const float fill = p.take_log ? logf(mm) : mm;
+    for (int r = p.rows_in + grp; r < p.rows_out; r += 16) out[(size_t)r * p.cols_out + c] = fill;
+}
 
 RY_KERNEL(256) void ry_pad_rows(RyPadRowsParams p) {  // blockIdx.y = window of the batch
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;

@@ -351,7 +351,6 @@ struct Plan {
     std::vector<LayerPlan> lp;
     float* user_in = nullptr;                 // staging of the caller's input
     float* user_out = nullptr;
-    float* minv = nullptr;
     float* x_in = nullptr;                    // padded predictor input
     float* y_full = nullptr;                  // stage-1 dense predictor output [B][T][out_ch]
     size_t user_in_floats = 0, user_out_floats = 0;
@@ -841,7 +840,6 @@ static int build_plan(ry_net* net, Plan& P) {
     RY_TRY(P.arena.alloc(&P.user_in, P.user_in_floats));
     RY_TRY(P.arena.alloc(&P.user_out, P.user_out_floats));
     if (P.mode == 1) {
-        RY_TRY(P.arena.alloc(&P.minv, (size_t)B * cin_user));
         RY_TRY(P.arena.alloc(&P.x_in, (size_t)B * P.T * (nd == 1 ? d.in_ch : d.width)));
     } else {
         P.x_in = nullptr;                      // raw forward reads the caller's block directly (cur_in)
@@ -873,20 +871,15 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
     if (P.mode == 1) {
         const int cols_in = nd == 1 ? d.in_ch : d.width + 1;
         const int cols_out = nd == 1 ? d.in_ch : d.width;
-        RyColminParams c;
-        c.in = P.cur_in; c.rows = P.n_frames; c.cols = cols_in; c.minv = P.minv;
-        c.in_bstride = (long long)P.n_frames * cols_in; c.minv_bstride = cols_in;
-        dim3 cg((unsigned)((cols_in + 63) / 64), (unsigned)B);
-        RY_TRY(Lc.begin("ry_colmin", "pad", 0, 4.0 * B * P.n_frames * cols_in, cg));
-        RY_LAUNCH(ry_colmin, cg, 256, Lc.stream, c);
-        RY_TRY(Lc.end());
+        // numpy.pad(mode='minimum') over time (+ log and the dropped last bin for stage 2): column minima and the padded
+        // block in one launch
         RyPadRowsParams q;
-        q.in = P.cur_in; q.minv = P.minv; q.out = P.x_in;
+        q.in = P.cur_in; q.minv = nullptr; q.out = P.x_in;
         q.rows_in = P.n_frames; q.cols_in = cols_in; q.rows_out = P.T; q.cols_out = cols_out; q.take_log = nd == 2;
-        q.in_bstride = c.in_bstride; q.out_bstride = (long long)P.T * cols_out; q.minv_bstride = cols_in;
-        dim3 pg((unsigned)(((long long)P.T * cols_out + 255) / 256), (unsigned)B);
-        RY_TRY(Lc.begin("ry_pad_rows", "pad", 0, 4.0 * B * (P.n_frames * cols_in + P.T * cols_out), pg));
-        RY_LAUNCH(ry_pad_rows, pg, 256, Lc.stream, q);
+        q.in_bstride = (long long)P.n_frames * cols_in; q.out_bstride = (long long)P.T * cols_out; q.minv_bstride = cols_in;
+        dim3 pg((unsigned)((cols_in + 15) / 16), (unsigned)B);
+        RY_TRY(Lc.begin("ry_pad_min_rows", "pad", 0, 4.0 * B * (P.n_frames * cols_in + P.T * cols_out), pg));
+        RY_LAUNCH(ry_pad_min_rows, pg, 256, Lc.stream, q);
         RY_TRY(Lc.end());
     }
     for (int i = 0; i < 16; ++i) {
