@@ -1320,8 +1320,9 @@ RY_KERNEL(256) void ry_conv1d_ws(RyConv1dParams p) {
 
 struct RyMaterializeParams {
     RySrc1d s;
-    long long npix;             // B*L
-    float* out;                 // [npix][s.C]
+    long long npix;             // B*keep: rows written
+    int L, keep;                // rows per window in the source / rows kept per window (the crop of the convert wrapper)
+    float* out;                 // [B][keep][s.C]
     float slope;
 };
 
@@ -1329,7 +1330,8 @@ RY_KERNEL(256) void ry_materialize(RyMaterializeParams p) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.npix * p.s.C) return;
     const int c = (int)(idx % p.s.C);
-    const size_t pix = (size_t)(idx / p.s.C);
+    const long long row = idx / p.s.C;
+    const size_t pix = (size_t)((row / p.keep) * p.L + row % p.keep);
     p.out[idx] = ry_src1d_load(p.s, pix, c, p.slope);
 }
 

@@ -352,7 +352,6 @@ struct Plan {
     float* user_in = nullptr;                 // staging of the caller's input
     float* user_out = nullptr;
     float* x_in = nullptr;                    // padded predictor input
-    float* y_full = nullptr;                  // stage-1 dense predictor output [B][T][out_ch]
     size_t user_in_floats = 0, user_out_floats = 0;
     int graph_n = -1, last_n = -1;            // convert mode: n_frames the graph was captured for / of the previous call
     const float* cur_in = nullptr;            // where the forward reads the caller's block (staging, or the caller's device buffer)
@@ -844,7 +843,6 @@ static int build_plan(ry_net* net, Plan& P) {
     } else {
         P.x_in = nullptr;                      // raw forward reads the caller's block directly (cur_in)
     }
-    if (nd == 1) RY_TRY(P.arena.alloc(&P.y_full, (size_t)B * P.T * d.out_ch));
     return RY_OK;
 }
 
@@ -897,23 +895,15 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
         }
     }
     if (nd == 1) {
+        // decoder c7 keeps raw slabs like every stage-1 layer: sum them here, cropping to the real frames in convert mode
         RyMaterializeParams m;
-        m.s = src1d_of(net, P, 15); m.npix = (long long)B * P.T; m.slope = slope;
-        m.out = P.mode == 1 ? P.y_full : P.cur_out;
+        m.s = src1d_of(net, P, 15); m.L = P.T; m.keep = P.mode == 1 ? P.n_frames : P.T;
+        m.npix = (long long)B * m.keep; m.slope = slope;
+        m.out = P.cur_out;
         dim3 mg((unsigned)((m.npix * d.out_ch + 255) / 256));
         RY_TRY(Lc.begin("ry_materialize", "decoder/c7", 0, 4.0 * m.npix * d.out_ch * 2, mg));
         RY_LAUNCH(ry_materialize, mg, 256, Lc.stream, m);
         RY_TRY(Lc.end());
-        if (P.mode == 1) {   // crop: first n_frames rows of every window
-            RyPadRowsParams q;
-            q.in = P.y_full; q.minv = nullptr; q.out = P.cur_out;
-            q.rows_in = P.T; q.cols_in = d.out_ch; q.rows_out = P.n_frames; q.cols_out = d.out_ch; q.take_log = 0;
-            q.in_bstride = (long long)P.T * d.out_ch; q.out_bstride = (long long)P.n_frames * d.out_ch; q.minv_bstride = 0;
-            dim3 pg((unsigned)(((long long)P.n_frames * d.out_ch + 255) / 256), (unsigned)B);
-            RY_TRY(Lc.begin("ry_pad_rows", "crop", 0, 8.0 * B * P.n_frames * d.out_ch, pg));
-            RY_LAUNCH(ry_pad_rows, pg, 256, Lc.stream, q);
-            RY_TRY(Lc.end());
-        }
     } else if (P.mode == 1 && P.lp[15].path != PATH_LAST) {
         RySrPostParams q;
         q.y = P.lp[15].out; q.out = P.cur_out; q.rows = P.n_frames; q.cols_in = d.width; q.cols_out = d.width + 1;
@@ -1457,7 +1447,7 @@ int ry_conv1d(ry_ctx* ctx, const float* x, int B, int L, int Cin, const float* W
     memset(&m, 0, sizeof m);
     m.s.raw = lp.raw; m.s.scale = l.scale; m.s.shift = l.shift; m.s.slab_stride = lp.slab_stride;
     m.s.C = Cy; m.s.Craw = Cout; m.s.splits = lp.splits; m.s.act = act;
-    m.npix = (long long)B * lp.Wo; m.out = dy; m.slope = 0.2f;
+    m.npix = (long long)B * lp.Wo; m.L = lp.Wo; m.keep = lp.Wo; m.out = dy; m.slope = 0.2f;
     dim3 mg((unsigned)((m.npix * Cy + 255) / 256));
     RY_TRY(Lc.begin("ry_materialize", "conv1d", 0, 0, mg));
     RY_LAUNCH(ry_materialize, mg, 256, Lc.stream, m);
