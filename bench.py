@@ -34,7 +34,7 @@ def parse():
     ap.add_argument('--frames', type=int, default=300, help='real frames per window (N)')
     ap.add_argument('--windows', type=int, default=1, help='windows per GPU per step')
     ap.add_argument('--model', default='SYN-64')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help="stage-2 MFMA operand type ('bf16' = BASELINE config #5; accumulation and activations stay fp32)")
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help="stage-2 MFMA operand type ('bf16' = BASELINE config #5: bf16 filters and activations between the implicit-GEMM layers, fp32 accumulation and end layers)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--profile-reps', type=int, default=5)
@@ -221,7 +221,7 @@ def main():
         dname, dv = dom
         ach = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(dname)
-        peak_tf = 2500.0 if 'bf16' in dname else F32_MFMA_PEAK_TF      # dense bf16 MFMA peak / fp32-input MFMA peak
+        peak_tf = 2500.0 if dname.endswith(',true>') else F32_MFMA_PEAK_TF      # ry_igemm_ldsdma<..., BF16 = true>: dense bf16 MFMA peak, else fp32-input MFMA peak
         out['roofline'] = {'kernel': dname, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                            'frac': round(ach / peak_tf, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
                            'traffic_source': traffic_src,

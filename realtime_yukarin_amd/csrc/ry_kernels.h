@@ -57,7 +57,8 @@ struct RyIgemmParams {
     const float* wt;            // [phase][N/64][tap][(C1+C2)/32][64][32]: every (64 couts x 32 k) chunk is one contiguous 8 KB block
     const float* scale;         // [N] folded BN scale (1 when no BN)
     const float* shift;         // [N] folded bias/BN shift
-    float* out;                 // splits==1: NHWC output; else slabs [split][B*Ho*Wo][N] of raw sums
+    float* out;                 // splits==1: NHWC output (may be null when only out16 is wanted); else slabs [split][B*Ho*Wo][N] of raw sums
+    unsigned short* out16;      // splits==1: optional bf16 copy of the activated output (consumers on the bf16 path), else unused
     int splits;
     int act;
     float slope;
@@ -66,7 +67,7 @@ struct RyIgemmParams {
     int tw;                     // > 0: an M-tile is a 2-D block of (BM/tw) x tw rows of the Mh x Mw grid (compact input footprint:
                                 //      overlapping taps hit L2); 0: BM consecutive rows in raster order
     unsigned long long* dbg;    // VAR bit 1 (diagnostic build of the kernel): per-phase shader-clock totals, else unused
-    int dbg_flags;              // diagnostics of ry_igemm_f32_ldsdma (wrong results): 4 skip the output stores, 8 skip the K loop, 128 skip the loads in the K loop
+    int dbg_flags;              // diagnostics of ry_igemm_ldsdma (wrong results): 4 skip the output stores, 8 skip the K loop, 128 skip the loads in the K loop
     const float* zeros;         // >= 16 bytes of zeros in device memory (source of padded rows for the direct-to-LDS kernel)
 };
 
@@ -318,7 +319,8 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// ry_igemm_f32_ldsdma -- the default stage-2 implicit GEMM.  Operand tiles go global -> LDS by DMA
+// ry_igemm_ldsdma<.., BF16 = false> -- the default stage-2 implicit GEMM (fp32 operands, v_mfma_f32_32x32x2_f32);
+// BF16 = true: the same kernel on bf16 activations and filters (v_mfma_f32_32x32x16_bf16, 64 channels per K chunk).  Operand tiles go global -> LDS by DMA
 // (global_load_lds_dwordx4), issued by the same four waves that run the MFMAs: no staging registers, no ds_write, one
 // barrier per 32-wide K chunk.
 //   A (gathered pixels x channels): LDS rows of 32 floats, unpadded (the DMA destination is lane-linear); the 16-byte slot
@@ -338,9 +340,11 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 // ---------------------------------------------------------------------------------------------
 template <int V> struct RyConst { static constexpr int value = V; };
 
-template <int BM, int BN, int WM, int WN, int KG>
-RY_KERNEL(256 * KG, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
-    constexpr int BK = 32, NS = 4;
+template <int BM, int BN, int WM, int WN, int KG, bool BF16>
+RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
+    constexpr int BK = 32, NS = 4;            // LDS rows of 128 bytes: 32 floats or 64 bf16
+    constexpr int CK = BF16 ? 64 : 32;        // input channels per K chunk
+    constexpr int ES = BF16 ? 8 : 4;          // elements per 16-byte slot
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AG = BM / 8;                // 1-KiB DMA pieces of the A tile (8 rows each)
     constexpr int BG = BN / 8;                // 1-KiB DMA pieces of the B tile ((32 columns, K step) each)
@@ -407,14 +411,14 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
     for (int j = 0; j < AI; ++j) {
         const int gi = 4 * j + wave;
         const int row = (gi < AG ? gi : 0) * 8 + drow;
-        const int c4 = (dpos ^ ((row >> 1) & 7)) * 4;
+        const int ce = (dpos ^ ((row >> 1) & 7)) * ES;       // element offset of the slot this lane fetches
         ayb[j] = rY[row]; axb[j] = rX[row];
         const int pixb = rP[row] + ayb[j] * g.Wi + axb[j];
-        aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + c4 : 0;
-        aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + c4 : 0;
+        aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + ce : 0;
+        aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + ce : 0;
     }
     // ---- B: element offset of this lane's 16 bytes in the (tap 0, chunk 0) block of each (32 columns, K step) piece ----
-    const int c32 = Ctot >> 5;
+    const int c32 = Ctot / CK;                 // K blocks of the filter layout (8 KiB each: 64 x 32 floats or 64 x 64 bf16)
     unsigned boff[BI];
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
@@ -423,7 +427,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
         boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * c32) * 2048 + ((n >> 5) & 1) * 1024 + (gq & 3) * 256 + lane * 4);
     }
 
-    const int cpt = Ctot / BK;
+    const int cpt = Ctot / CK;
     const int nk = g.ntaps * cpt;
     const int kc_begin = (int)(((long long)nk * split) / p.splits);
     const int kc_end = (int)(((long long)nk * (split + 1)) / p.splits);
@@ -438,7 +442,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
     // state of the chunk being fetched (wave-uniform)
     const float* c_src = nullptr; bool c_first = true; int c_delta = 0, c_dy = 0, c_dx = 0; unsigned c_bdelta = 0;
     auto next_chunk = [&]() {
-        const int ci0 = cib * BK;
+        const int ci0 = cib * CK;
         c_first = ci0 < g.C1;
         c_src = c_first ? g.src1 : g.src2;
         const int Cs = c_first ? g.C1 : g.C2;
@@ -454,7 +458,8 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
             if (AG % 4 == 0 || gi < AG) {
                 const int iy = ayb[j] + c_dy, ix = axb[j] + c_dx;
                 const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-                const float* gp = ok ? c_src + (unsigned)((c_first ? aoff1[j] : aoff2[j]) + c_delta) : p.zeros;
+                const unsigned eo = (unsigned)((c_first ? aoff1[j] : aoff2[j]) + c_delta);     // elements (fp32 or bf16)
+                const float* gp = !ok ? p.zeros : BF16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(c_src) + eo) : c_src + eo;
                 ry_glds16(gp, Ad + gi * 256);
             }
         } else {
@@ -511,12 +516,20 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
 #pragma unroll
                 for (int q = (s * NI) / NS; q < ((s + 1) * NI) / NS; ++q) dma_item(q, An, Bn);
             }
+            if (BF16) {                        // one v_mfma_f32_32x32x16_bf16 per fragment pair: the 16 bytes are 8 bf16 of k = 16 s + 8 (lane >> 5) + j
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = ry_mfma_32x32x16_bf16(__builtin_bit_cast(u16x8, af[i]), __builtin_bit_cast(u16x8, bf[j]), acc[i][j]);
+            } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
+            }
         }
         }
         __syncthreads();                       // DMA of chunk k + 1 landed (vmcnt) and buffer BUF is free again
@@ -564,7 +577,11 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
                 const int ob = rO[ml];
                 if (ob >= 0) {
                     float v = acc[i][j][r];
-                    if (p.splits == 1) v = ry_act(fmaf(v, sc, sh), p.act, p.slope);
+                    if (p.splits == 1) {
+                        v = ry_act(fmaf(v, sc, sh), p.act, p.slope);
+                        if (p.out16) p.out16[(size_t)ob * g.N + n] = ry_f2bf(v);
+                        if (!p.out) continue;
+                    }
                     outp[(size_t)ob * g.N + n] = v;
                 }
             }
@@ -572,196 +589,11 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_f32_ldsdma(RyIgemmParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// ry_igemm_bf16 -- the same implicit GEMM with bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), BASELINE
-// config #5.  Activations stay fp32 in HBM and are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when the A tile is written to
-// LDS; filters are converted once at `ry_net_set_dtype` and stored as [phase][N/64][tap][C/64][64][64] bf16 (8 KB blocks).
-// BK = 64: 16 MFMAs per wave per chunk at 1/16 of the fp32 MFMA cost, so this kernel is bound by the global->LDS path,
-// not by the matrix pipe.  LDS rows are 64 bf16 + 8 pad = 144 bytes (conflict-free ds_read_b128, same argument as the
-// 36-float rows of the fp32 kernel).  Everything else (row geometry, sub-pixel phases, split-K slabs, epilogue) is shared.
-// ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
-RY_KERNEL(256) void ry_igemm_bf16(RyIgemmParams p) {
-    constexpr int BK = 64, BKP = 72, NS = BK / 16;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int AR = BM / 16;                    // A: 16 threads x 16 bytes (4 fp32) per row, 16 rows per pass
-    constexpr int BR = BN / 32;                    // B: 8 threads x 16 bytes (8 bf16) per row, 32 rows per pass
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
-    __shared__ __attribute__((aligned(16))) unsigned short As[BM * BKP];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[BN * BKP];
-    __shared__ int rY[BM], rX[BM], rP[BM], rO[BM];
-
-    const RyConvGeom& g = p.g;
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int total_tiles = p.splits * p.mtiles * p.ntiles * p.g.nphases;
-    const int per_xcd = (total_tiles + 7) >> 3;
-    int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (lid >= total_tiles) return;
-    const int phase = lid % p.g.nphases; lid /= p.g.nphases;
-    const int nt = lid % p.ntiles; lid /= p.ntiles;
-    const int mt = lid % p.mtiles;
-    const int split = lid / p.mtiles;
-    const int m0 = mt * BM;
-    const int n0 = nt * BN;
-    const int Ctot = g.C1 + g.C2;
-    const int Mimg = g.Mh * g.Mw;
-    const int M = g.B * Mimg;
-    const bool subpix = g.ostride == 2;
-    const int pdy = subpix ? (phase >> 1) : 0, pdx = subpix ? (phase & 1) : 0;
-
-    for (int r = tid; r < BM; r += 256) {
-        const int m = m0 + r;
-        int yb = -(1 << 20), xb = 0, pb = 0, ob = -1;
-        bool live = m < M;
-        int b = 0, ry = 0, rx = 0;
-        if (p.tw > 0) {
-            const int th = BM / p.tw, tcols = g.Mw / p.tw, trows = g.Mh / th;
-            const int tx = mt % tcols, ty = (mt / tcols) % trows;
-            b = mt / (tcols * trows);
-            ry = ty * th + r / p.tw; rx = tx * p.tw + r % p.tw;
-            live = b < g.B;
-        } else if (live) {
-            b = m / Mimg; const int rem = m - b * Mimg;
-            ry = rem / g.Mw; rx = rem - ry * g.Mw;
-        }
-        if (live) {
-            yb = ry * g.stride - g.pad;
-            xb = rx * g.stride - g.pad;
-            pb = b * g.Hi * g.Wi;
-            ob = (b * g.Ho + ry * g.ostride + pdy) * g.Wo + rx * g.ostride + pdx;
-        }
-        rY[r] = yb; rX[r] = xb; rP[r] = pb; rO[r] = ob;
-    }
-    __syncthreads();
-
-    const int ca = (tid & 15) * 4, ra = tid >> 4;  // A: float column / first row of this thread
-    const int cb = (tid & 7) * 8, rb = tid >> 3;   // B: bf16 column / first row
-    int ayb[AR], axb[AR], aoff1[AR], aoff2[AR];
-#pragma unroll
-    for (int j = 0; j < AR; ++j) {
-        ayb[j] = rY[ra + 16 * j]; axb[j] = rX[ra + 16 * j];
-        const int pixb = rP[ra + 16 * j] + ayb[j] * g.Wi + axb[j];
-        aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + ca : 0;
-        aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + ca : 0;
-    }
-    const int cpt = Ctot / BK;
-    const int nk = g.ntaps * cpt;
-    unsigned boff[BR];
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-        const int n = n0 + rb + 32 * j;
-        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * nk * 4096 + (n & 63) * 64 + cb);
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int kc_begin = (int)(((long long)nk * split) / p.splits);
-    const int kc_end = (int)(((long long)nk * (split + 1)) / p.splits);
-    int tap = kc_begin / cpt;
-    int cib = kc_begin - tap * cpt;
-    int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
-
-    f32x4 areg[AR];
-    u16x8 breg[BR];
-    unsigned amask = 0;
-    const float* src = g.src1;
-    const unsigned short* wt16 = reinterpret_cast<const unsigned short*>(p.wt);
-    int delta = 0, dy = 0, dx = 0;
-    bool first = true;
-    unsigned bdelta = 0;
-    auto chunk_setup = [&]() {
-        const int ci0 = cib * BK;
-        first = ci0 < g.C1;
-        src = first ? g.src1 : g.src2;
-        const int Cs = first ? g.C1 : g.C2;
-        const int cil = first ? ci0 : ci0 - g.C1;
-        dy = subpix ? pdy - ky : ky; dx = subpix ? pdx - kx : kx;
-        delta = (dy * g.Wi + dx) * Cs + cil;
-        bdelta = (unsigned)((tap * cpt + cib) * 4096);
-        amask = 0;
-        if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
-    };
-    auto load_a = [&](int j) {
-        const int iy = ayb[j] + dy, ix = axb[j] + dx;
-        const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-        const int off = ok ? (first ? aoff1[j] : aoff2[j]) + delta : ca;
-        areg[j] = ry_ld4(src + (unsigned)off);
-        amask |= ok ? (1u << j) : 0u;
-    };
-    auto load_b = [&](int j) { breg[j] = *reinterpret_cast<const u16x8*>(wt16 + (boff[j] + bdelta)); };
-
-    const int nchunks = kc_end - kc_begin;
-    if (nchunks > 0) {
-        chunk_setup();
-#pragma unroll
-        for (int j = 0; j < AR; ++j) load_a(j);
-#pragma unroll
-        for (int j = 0; j < BR; ++j) load_b(j);
-    }
-    for (int k = 0; k < nchunks; ++k) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            f32x4 v = areg[j];
-            if (!(amask & (1u << j))) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
-            u16x4 h;
-            h[0] = ry_f2bf(v[0]); h[1] = ry_f2bf(v[1]); h[2] = ry_f2bf(v[2]); h[3] = ry_f2bf(v[3]);
-            *reinterpret_cast<u16x4*>(&As[(ra + 16 * j) * BKP + ca]) = h;
-        }
-#pragma unroll
-        for (int j = 0; j < BR; ++j) *reinterpret_cast<u16x8*>(&Bs[(rb + 32 * j) * BKP + cb]) = breg[j];
-        __syncthreads();
-        const bool more = k + 1 < nchunks;
-        if (more) chunk_setup();
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            u16x8 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u16x8*>(&As[((wm * TM + i) * 32 + lr) * BKP + s * 16 + lh * 8]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const u16x8*>(&Bs[((wn * TN + j) * 32 + lr) * BKP + s * 16 + lh * 8]);
-            if (more) {                            // slice s of the next chunk's loads
-#pragma unroll
-                for (int j = 0; j < AR; ++j) if (j % NS == s) load_a(j);
-#pragma unroll
-                for (int j = 0; j < BR; ++j) if (j % NS == s) load_b(j);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
-        }
-    }
-
-    float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + lr;
-        float sc = 1.f, sh = 0.f;
-        if (p.splits == 1) { sc = p.scale[n]; sh = p.shift[n]; }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int ob = rO[ml];
-                if (ob >= 0) {
-                    float v = acc[i][j][r];
-                    if (p.splits == 1) v = ry_act(fmaf(v, sc, sh), p.act, p.slope);
-                    outp[(size_t)ob * g.N + n] = v;
-                }
-            }
-        }
-    }
+// four fp32 -> four bf16 (RNE), one 8-byte store
+RY_DEV void ry_st4_bf16(unsigned short* q, f32x4 v) {
+    u16x4 h;
+    h[0] = ry_f2bf(v[0]); h[1] = ry_f2bf(v[1]); h[2] = ry_f2bf(v[2]); h[3] = ry_f2bf(v[3]);
+    *reinterpret_cast<u16x4*>(q) = h;
 }
 
 struct RyReduceParams {
@@ -770,7 +602,8 @@ struct RyReduceParams {
     long long slab_stride;
     const float* scale;
     const float* shift;
-    float* out;
+    float* out;                 // fp32 output, or null
+    unsigned short* out16;      // bf16 copy of the output (consumers on the bf16 path), or null
     long long total;            // elements (multiple of 4)
     int N;
     int act;
@@ -797,7 +630,8 @@ RY_KERNEL(256) void ry_splitk_reduce(RyReduceParams p) {
     f32x4 o;
 #pragma unroll
     for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(s[u], sc[u], sh[u]), p.act, p.slope);
-    ry_st4(p.out + i4, o);
+    if (p.out) ry_st4(p.out + i4, o);
+    if (p.out16) ry_st4_bf16(p.out16 + i4, o);
 }
 
 // Many slabs, few outputs (the weight-streaming layers at the bottom of the U-Net): 64 float4 columns per workgroup,
@@ -830,7 +664,8 @@ RY_KERNEL(256) void ry_splitk_reduce_wide(RyReduceParams p) {
         f32x4 o;
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(s[u], sc[u], sh[u]), p.act, p.slope);
-        ry_st4(p.out + i4, o);
+        if (p.out) ry_st4(p.out + i4, o);
+        if (p.out16) ry_st4_bf16(p.out16 + i4, o);
     }
 }
 
@@ -889,6 +724,7 @@ struct RySrFirstParams {
     const float* scale;
     const float* shift;
     float* out;                 // [B][H][W][N]
+    unsigned short* out16;      // optional bf16 copy (consumers on the bf16 path)
     int B, H, W, N;
     int act;
     float slope;
@@ -934,7 +770,9 @@ RY_KERNEL(256) void ry_sr_first(RySrFirstParams p) {
         f32x4 o;
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(acc[u], sc[u], sh[u]), p.act, p.slope);
-        ry_st4(p.out + (((size_t)b * p.H + y) * p.W + x0 + j) * p.N + cq * 4, o);
+        const size_t oi = (((size_t)b * p.H + y) * p.W + x0 + j) * p.N + cq * 4;
+        ry_st4(p.out + oi, o);
+        if (p.out16) ry_st4_bf16(p.out16 + oi, o);
     }
 }
 

@@ -158,7 +158,7 @@ struct Layer {
     float* w1d = nullptr;                // stage-1 [Ctot][N][4]
     float* wig = nullptr;                // stage-2 implicit-GEMM blocks [phase][N/64][tap][Ctot/32][fragment order], see wig_inblock()
     float* wdir = nullptr;               // stage-2 direct [phase][tap][Ctot][N]
-    float* wig16 = nullptr;              // stage-2 implicit-GEMM bf16 [phase][N/64][tap][Ctot/64][64][64] (ry_net_set_dtype)
+    float* wig16 = nullptr;              // stage-2 implicit-GEMM bf16 blocks [phase][N/64][tap][Ctot/64][fragment order], see wig16_inblock() (ry_net_set_dtype)
     int cin() const { return cin_a + cin_b; }
 };
 
@@ -293,6 +293,12 @@ static inline size_t wig_inblock(int nl, int k) {
     return (size_t)(nl >> 5) * 1024 + (size_t)(k >> 3) * 256 + (size_t)((((k >> 2) & 1) * 32 + (nl & 31)) * 4) + (size_t)(k & 3);
 }
 
+// bf16 blocks of 64 output channels x 64 input channels, same idea: [n/32 : 2][s : 4][lane : 64][j : 8] with
+// lane = 32 * lh + (n % 32) and k = 16 s + 8 lh + j (the 8 bf16 a lane feeds to one v_mfma_f32_32x32x16_bf16); index in bf16 units.
+static inline size_t wig16_inblock(int nl, int k) {
+    return (size_t)(nl >> 5) * 2048 + (size_t)(k >> 4) * 512 + (size_t)((((k >> 3) & 1) * 32 + (nl & 31)) * 8) + (size_t)(k & 7);
+}
+
 static void relayout_igemm(const Layer& l, const float* W, std::vector<float>& out) {
     const TapTable t = make_taps(l);
     const int C = l.cin(), N = l.cout, cpt = C / 32;
@@ -337,7 +343,9 @@ struct LayerPlan {
     // stage-2
     int path = 0, tile = 0;
     int kg = 1;                               // K groups inside a workgroup (LDS-DMA implicit GEMM): 2 = split-K summed through the LDS
-    float* out = nullptr;                     // NHWC activation
+    float* out = nullptr;                     // NHWC activation, fp32
+    unsigned short* out16 = nullptr;          // NHWC activation, bf16 copy for consumers on the bf16 path (bf16 mode only)
+    bool w32 = true, w16 = false;             // which copies the producer writes
     float* slabs = nullptr;
     int last_rows = 0, last_cols = 0, last_exp = 0;   // PATH_LAST: fused exp / edge-pad / crop
     double flops = 0, bytes = 0;
@@ -467,20 +475,11 @@ static void tile_dims(int tile, int* bm, int* bn) {
     }
 }
 
-static const char* tile_name16(int tile) {
-    switch (tile) {
-        case TILE_128x128: return "ry_igemm_bf16<128,128>";
-        case TILE_96x128: return "ry_igemm_bf16<96,128>";
-        case TILE_64x128: return "ry_igemm_bf16<64,128>";
-        case TILE_128x64: return "ry_igemm_bf16<128,64>";
-        default: return "ry_igemm_bf16<32,128>";
-    }
-}
 
 static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
 static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
-static int g_igemm_dbg = 0; // RY_IGEMM_DBG: ablation bits of ry_igemm_f32_ldsdma (diagnostics; wrong results)
+static int g_igemm_dbg = 0; // RY_IGEMM_DBG: ablation bits of ry_igemm_ldsdma (diagnostics; wrong results)
 static int g_kgroups = 1;   // RY_KGROUPS=0: never split K inside a workgroup (external split-K + reduce kernel only)
 static int g_ldsdma = 1;    // RY_LDSDMA=0: register-staged ry_igemm_f32 instead of the LDS-DMA kernel (A/B; ~5 % slower end to end)
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
@@ -488,26 +487,38 @@ static unsigned long long* g_dbg = nullptr;
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
 // Kernel names as rocprofv3 prints them (template arguments, no spaces): bench.py matches them against profiles/*.
-static const char* tile_name(int tile, int kg) {
-    const bool dma = g_ldsdma && !g_timing;
-    const bool k2 = dma && kg == 2;
+static const char* tile_name(int tile, int kg, bool bf16) {
+    const bool dma = (g_ldsdma && !g_timing) || bf16;
+    static const char* const names[8][2][2] = {
+        {{"ry_igemm_ldsdma<32,128,1,4,1,false>", "ry_igemm_ldsdma<32,128,1,4,1,true>"}, {"ry_igemm_ldsdma<32,128,1,4,2,false>", "ry_igemm_ldsdma<32,128,1,4,2,true>"}},
+        {{"ry_igemm_ldsdma<128,128,2,2,1,false>", "ry_igemm_ldsdma<128,128,2,2,1,true>"}, {"ry_igemm_ldsdma<128,128,2,2,2,false>", "ry_igemm_ldsdma<128,128,2,2,2,true>"}},
+        {{nullptr, nullptr}, {nullptr, nullptr}},
+        {{"ry_igemm_ldsdma<64,128,1,4,1,false>", "ry_igemm_ldsdma<64,128,1,4,1,true>"}, {"ry_igemm_ldsdma<64,128,1,4,2,false>", "ry_igemm_ldsdma<64,128,1,4,2,true>"}},
+        {{"ry_igemm_ldsdma<32,128,1,4,1,false>", "ry_igemm_ldsdma<32,128,1,4,1,true>"}, {"ry_igemm_ldsdma<32,128,1,4,2,false>", "ry_igemm_ldsdma<32,128,1,4,2,true>"}},
+        {{"ry_igemm_ldsdma<128,64,4,1,1,false>", "ry_igemm_ldsdma<128,64,4,1,1,true>"}, {"ry_igemm_ldsdma<128,64,4,1,2,false>", "ry_igemm_ldsdma<128,64,4,1,2,true>"}},
+        {{"ry_igemm_ldsdma<96,128,1,4,1,false>", "ry_igemm_ldsdma<96,128,1,4,1,true>"}, {"ry_igemm_ldsdma<96,128,1,4,2,false>", "ry_igemm_ldsdma<96,128,1,4,2,true>"}},
+        {{nullptr, nullptr}, {nullptr, nullptr}}};
+    if (dma && tile >= 0 && tile < 8 && names[tile][0][0]) return names[tile][kg == 2][bf16];
     switch (tile) {
-        case TILE_128x128: return k2 ? "ry_igemm_f32_ldsdma<128,128,2,2,2>" : dma ? "ry_igemm_f32_ldsdma<128,128,2,2,1>" : "ry_igemm_f32<128,128>";
+        case TILE_128x128: return "ry_igemm_f32<128,128>";
         case TILE_256x64: return "ry_igemm_f32<256,64>";
-        case TILE_64x128: return k2 ? "ry_igemm_f32_ldsdma<64,128,1,4,2>" : dma ? "ry_igemm_f32_ldsdma<64,128,1,4,1>" : "ry_igemm_f32<64,128>";
-        case TILE_128x64: return k2 ? "ry_igemm_f32_ldsdma<128,64,4,1,2>" : dma ? "ry_igemm_f32_ldsdma<128,64,4,1,1>" : "ry_igemm_f32<128,64>";
-        case TILE_96x128: return k2 ? "ry_igemm_f32_ldsdma<96,128,1,4,2>" : dma ? "ry_igemm_f32_ldsdma<96,128,1,4,1>" : "ry_igemm_f32<96,128>";
+        case TILE_64x128: return "ry_igemm_f32<64,128>";
+        case TILE_128x64: return "ry_igemm_f32<128,64>";
+        case TILE_96x128: return "ry_igemm_f32<96,128>";
         case TILE_256x128: return "ry_igemm_f32<256,128>";
-        default: return k2 ? "ry_igemm_f32_ldsdma<32,128,1,4,2>" : dma ? "ry_igemm_f32_ldsdma<32,128,1,4,1>" : "ry_igemm_f32<32,128>";
+        default: return "ry_igemm_f32<32,128>";
     }
 }
 
 // ---- choice of tile, split-K and K groups for one stage-2 layer ----
 // Workgroups of one tile that fit a CU.  LDS-DMA kernel: two unpadded BK = 32 buffers; register-staged kernel: one padded
 // buffer, limited to 3 by its VGPR budget.
+static double g_plan_peak = 157.3e6;   // flop per microsecond the planner prices the main loop at (fp32 MFMA peak; bf16: see choose_igemm)
+static int g_plan_ck = 32;             // input channels per K chunk of the kernel being planned
+
 static int tile_occ(int tile, int kg) {
     int bm, bn; tile_dims(tile, &bm, &bn);
-    if (g_ldsdma && bm <= 128) {
+    if ((g_ldsdma || g_plan_ck == 64) && bm <= 128) {
         const int occ = (160 * 1024) / (kg * (bm + bn) * 32 * 4 * 2 + bm * 16);
         const int cap = 4 / kg;                                          // <= 128 VGPRs: four waves per SIMD
         return occ > cap ? cap : occ;
@@ -530,7 +541,7 @@ static double est_time(long blocks, int bm, int bn, int s, int occ, int kg, int 
     const long g = blocks * s;
     const long per_cu = (g + 255) / 256;
     const long full = per_cu / occ, rem = per_cu % occ;
-    const double tile_us = 2.0 * bm * bn * (32.0 * nk) / (157.3e6 / 256.0);   // one tile on one CU at the MFMA peak
+    const double tile_us = 2.0 * bm * bn * ((double)g_plan_ck * nk) / (g_plan_peak / 256.0);   // one tile on one CU at the peak
     const double w = tile_us / (double)(s * kg);                              // work of one four-wave group
     double t = (double)full * occ * kg * w / cu_rate(occ * kg) + (rem ? (double)rem * kg * w / cu_rate((int)rem * kg) : 0.0);
     t += 4.0 + (double)M * N * 4.0 / 5.0e6;                                     // launch + ramp, output stores at ~5 TB/s (exposed: one round)
@@ -552,17 +563,20 @@ static int best_split(long blocks, int bm, int bn, int nk, bool tinyM, int occ, 
     return best;
 }
 
-static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits, int* kg) {
+static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits, int* kg, bool bf16 = false) {
+    // bf16: 64 channels per chunk; the kernel is bound by the operand movement, not the matrix pipe: price
+    // the main loop at the measured rate so that the fixed costs (launch, stores, slabs) weigh as they do in the measurements
+    g_plan_peak = bf16 ? 0.86e9 : 157.3e6; g_plan_ck = bf16 ? 64 : 32;   // 128x128 bf16 tiles measured ~620 TF = 0.72 x 860
     // MFMA-bound layers: every CU should hold a full set of co-resident wave groups for the whole launch.  Candidate
     // M-tiles 128 / 96 / 64 (N-tile 128), with one or two K groups per workgroup and the best external split-K, are
     // compared by estimated time.
-    const bool kg_ok = g_ldsdma && g_kgroups && M > 64 && nk >= 16;
+    const bool kg_ok = (g_ldsdma || bf16) && g_kgroups && M > 64 && nk >= 16;
     const int N = l.cout;
     if (*tile == 0) {
-        if (N % 128 != 0) *tile = g_tile64;
+        if (N % 128 != 0) *tile = bf16 ? TILE_128x64 : g_tile64;
         else if (M <= 32) *tile = TILE_32x128;
         else if (M <= 64) *tile = TILE_64x128;
-        else if (g_bigtile && M >= 2048) *tile = TILE_256x128;
+        else if (g_bigtile && !bf16 && M >= 2048) *tile = TILE_256x128;
         else {
             const int cand[3] = {TILE_128x128, TILE_96x128, TILE_64x128};
             const double bias[3] = {1.0, 1.02, 1.08};                     // smaller tiles re-read more B per flop
@@ -574,7 +588,9 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
                     const long mt = (M + bm - 1) / bm;
                     double t = 0.0;
                     best_split(mt * (N / bn) * nphases, bm, bn, nk, false, tile_occ(cand[c], kk), kk, M, N, &t);
-                    t *= bias[c];
+                    // fp32: smaller tiles re-read more B per flop; bf16: the kernel is bound by the operand movement, time
+                    // scales with operand bytes per flop, (1/BM + 1/BN)
+                    t *= bf16 ? (1.0 / bm + 1.0 / bn) * 64.0 : bias[c];
                     if (t < bt - 1e-9) { bt = t; btile = cand[c]; bk = kk; }
                 }
             *tile = btile;
@@ -592,7 +608,7 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
             if (t2 < t1 - 1e-9) *kg = 2;
         }
     }
-    if (bm > 128 || !g_ldsdma) *kg = 1;
+    if (bm > 128 || !(g_ldsdma || bf16)) *kg = 1;
     if (*splits == 0) *splits = best_split(blocks, bm, bn, nk, M <= 64, tile_occ(*tile, *kg), *kg, M, N, nullptr);
     if (*splits * *kg > nk) { *kg = 1; if (*splits > nk) *splits = nk; }
 }
@@ -602,12 +618,13 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     fill_geom(g, l, lp, B, s1, C1, s2, C2);
     const int M = B * g.Mh * g.Mw;
     if (lp.path == PATH_IGEMM || lp.path == PATH_IGEMM_BF16) {
-        const bool bf16 = lp.path == PATH_IGEMM_BF16;
+        const bool bf16 = lp.path == PATH_IGEMM_BF16;       // s1 / s2 then point to bf16 activations
         RyIgemmParams p;
         p.g = g; p.wt = bf16 ? l.wig16 : l.wig; p.scale = l.scale; p.shift = l.shift;
         p.splits = lp.splits; p.act = l.act; p.slope = slope;
         p.slab_stride = (long long)B * lp.Ho * lp.Wo * l.cout;
-        p.out = lp.splits > 1 ? lp.slabs : lp.out;
+        p.out = lp.splits > 1 ? lp.slabs : (lp.w32 ? lp.out : nullptr);
+        p.out16 = (lp.splits == 1 && lp.w16) ? lp.out16 : nullptr;
         int bm, bn; tile_dims(lp.tile, &bm, &bn);
         p.mtiles = (M + bm - 1) / bm; p.ntiles = l.cout / bn;
         p.tw = 0;
@@ -618,26 +635,32 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         }
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
         dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
-        RY_TRY(Lc.begin(bf16 ? tile_name16(lp.tile) : tile_name(lp.tile, lp.kg), l.name, lp.flops, lp.bytes, grid));
+        RY_TRY(Lc.begin(tile_name(lp.tile, lp.kg, bf16), l.name, lp.flops, lp.bytes, grid));
         p.dbg = g_dbg; p.dbg_flags = g_igemm_dbg; p.zeros = Lc.ctx->zero_page;
 #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
     do {                                                                                                    \
         if (g_ldsdma && !g_timing && BM_ <= 128) {                                                            \
-            if (lp.kg == 2) RY_LAUNCH((ry_igemm_f32_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 2>), grid, 512, Lc.stream, p); \
-            else RY_LAUNCH((ry_igemm_f32_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 1>), grid, 256, Lc.stream, p);          \
+            if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 2, false>), grid, 512, Lc.stream, p); \
+            else RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 1, false>), grid, 256, Lc.stream, p);          \
         }                                                                                                   \
         else if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
         else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
         else RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 0>), grid, 256, Lc.stream, p);               \
     } while (0)
+#define RY_IGEMM16_LAUNCH(BM_, BN_, WM_, WN_)                                                                  \
+    do {                                                                                                    \
+        if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, true>), grid, 512, Lc.stream, p);    \
+        else RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, true>), grid, 256, Lc.stream, p);               \
+    } while (0)
         if (bf16) {
             switch (lp.tile) {
-                case TILE_128x128: RY_LAUNCH((ry_igemm_bf16<128, 128, 2, 2>), grid, 256, Lc.stream, p); break;
-                case TILE_96x128: RY_LAUNCH((ry_igemm_bf16<96, 128, 1, 4>), grid, 256, Lc.stream, p); break;
-                case TILE_64x128: RY_LAUNCH((ry_igemm_bf16<64, 128, 1, 4>), grid, 256, Lc.stream, p); break;
-                case TILE_128x64: RY_LAUNCH((ry_igemm_bf16<128, 64, 4, 1>), grid, 256, Lc.stream, p); break;
-                default: RY_LAUNCH((ry_igemm_bf16<32, 128, 1, 4>), grid, 256, Lc.stream, p); break;
+                case TILE_128x128: RY_IGEMM16_LAUNCH(128, 128, 2, 2); break;
+                case TILE_96x128: RY_IGEMM16_LAUNCH(96, 128, 1, 4); break;
+                case TILE_64x128: RY_IGEMM16_LAUNCH(64, 128, 1, 4); break;
+                case TILE_128x64: RY_IGEMM16_LAUNCH(128, 64, 4, 1); break;
+                default: RY_IGEMM16_LAUNCH(32, 128, 1, 4); break;
             }
+#undef RY_IGEMM16_LAUNCH
         } else
         switch (lp.tile) {
             case TILE_128x128:
@@ -655,7 +678,8 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         if (lp.splits > 1) {
             RyReduceParams r;
             r.slabs = lp.slabs; r.splits = lp.splits; r.slab_stride = p.slab_stride;
-            r.scale = l.scale; r.shift = l.shift; r.out = lp.out; r.total = p.slab_stride; r.N = l.cout;
+            r.scale = l.scale; r.shift = l.shift; r.out = lp.w32 ? lp.out : nullptr; r.out16 = lp.w16 ? lp.out16 : nullptr;
+            r.total = p.slab_stride; r.N = l.cout;
             r.act = l.act; r.slope = slope;
             if (lp.splits >= 16 && r.total <= (1 << 20)) {      // many slabs, few outputs
                 dim3 rg((unsigned)((r.total / 4 + 63) / 64));
@@ -670,7 +694,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         }
     } else if (lp.path == PATH_FIRST) {
         RySrFirstParams p;
-        p.x = s1; p.w = l.wdir; p.scale = l.scale; p.shift = l.shift; p.out = lp.out;
+        p.x = s1; p.w = l.wdir; p.scale = l.scale; p.shift = l.shift; p.out = lp.out; p.out16 = lp.w16 ? lp.out16 : nullptr;
         p.B = B; p.H = lp.Hi; p.W = lp.Wi; p.N = l.cout; p.act = l.act; p.slope = slope;
         const long long total = (long long)B * lp.Hi * ((lp.Wi + 3) / 4) * (l.cout / 4);
         dim3 grid((unsigned)((total + 255) / 256));
@@ -807,13 +831,23 @@ static int build_plan(ry_net* net, Plan& P) {
                 const TapTable t = make_taps(l);
                 const int M = B * (l.deconv ? lp.Hi * lp.Wi : lp.Ho * lp.Wo);
                 const int nk = t.ntaps * (l.cin() / 32);
-                lp.path = PATH_IGEMM; lp.tile = 0; lp.splits = 0;
-                const bool want16 = net->dtype == 1 && l.wig16;
-                lp.kg = want16 ? 1 : 0;                                // the bf16 kernel has no K groups
-                choose_igemm(l, M, t.nphases, nk, &lp.tile, &lp.splits, &lp.kg);
-                if (want16 && lp.tile != TILE_256x64 && lp.tile != TILE_256x128) {
-                    lp.path = PATH_IGEMM_BF16;                         // 64-deep K chunks: half as many as the fp32 kernel
-                    if (lp.splits > nk / 2) lp.splits = nk / 2 > 0 ? nk / 2 : 1;
+                lp.path = PATH_IGEMM; lp.tile = 0; lp.splits = 0; lp.kg = 0;
+                // bf16 mode: a layer runs on bf16 operands when its filters were converted and every producer it reads can
+                // write a bf16 copy of its output (the first layer, implicit-GEMM layers and their reduce kernels can)
+                bool want16 = net->dtype == 1 && l.wig16;
+                for (int src : {l.src_a, l.src_b}) {
+                    if (src < 0) continue;
+                    const LayerPlan& sp = P.lp[src];
+                    const bool dma_kernel = sp.path == PATH_IGEMM_BF16 ||
+                                            (sp.path == PATH_IGEMM && g_ldsdma && !g_timing && sp.tile != TILE_256x64 && sp.tile != TILE_256x128);
+                    if (sp.path != PATH_FIRST && !dma_kernel) want16 = false;       // that producer cannot write a bf16 copy
+                }
+                if (l.src_a < 0) want16 = false;
+                if (want16) {
+                    lp.path = PATH_IGEMM_BF16;
+                    choose_igemm(l, M, t.nphases, t.ntaps * (l.cin() / 64), &lp.tile, &lp.splits, &lp.kg, true);
+                } else {
+                    choose_igemm(l, M, t.nphases, nk, &lp.tile, &lp.splits, &lp.kg);
                 }
                 if (lp.splits > 1) RY_TRY(P.arena.alloc(&lp.slabs, out_elems * lp.splits));
             } else {
@@ -827,6 +861,23 @@ static int build_plan(ry_net* net, Plan& P) {
                         lp.last_exp = P.mode == 1;
                     }
                 }
+            }
+        }
+    }
+    // bf16 mode: which copies of each activation are needed (fp32 for fp32 consumers and the caller, bf16 for bf16 consumers)
+    if (nd == 2 && net->dtype == 1) {
+        std::vector<char> need32(16, 0), need16(16, 0);
+        need32[15] = 1;
+        for (int i = 0; i < 16; ++i)
+            for (int src : {net->layers[i].src_a, net->layers[i].src_b})
+                if (src >= 0) (P.lp[i].path == PATH_IGEMM_BF16 ? need16 : need32)[src] = 1;
+        for (int i = 0; i < 16; ++i) {
+            LayerPlan& lp = P.lp[i];
+            lp.w32 = need32[i] || lp.path == PATH_DIRECT || lp.path == PATH_LAST; lp.w16 = need16[i];
+            if (lp.w16) {
+                float* q = nullptr;
+                RY_TRY(P.arena.alloc(&q, ((size_t)B * lp.Ho * lp.Wo * net->layers[i].cout + 1) / 2));
+                lp.out16 = reinterpret_cast<unsigned short*>(q);
             }
         }
     }
@@ -886,8 +937,10 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
         if (nd == 1) {
             RY_TRY(launch_conv1d(Lc, l, lp, B, src1d_of(net, P, l.src_a), src1d_of(net, P, l.src_b), slope));
         } else {
-            const float* s1 = l.src_a < 0 ? (P.mode == 1 ? P.x_in : P.cur_in) : P.lp[l.src_a].out;
-            const float* s2 = l.src_b >= 0 ? P.lp[l.src_b].out : nullptr;
+            const bool in16 = lp.path == PATH_IGEMM_BF16;       // bf16 consumers read the producers' bf16 copies
+            const float* s1 = l.src_a < 0 ? (P.mode == 1 ? P.x_in : P.cur_in)
+                                          : in16 ? reinterpret_cast<const float*>(P.lp[l.src_a].out16) : P.lp[l.src_a].out;
+            const float* s2 = l.src_b < 0 ? nullptr : in16 ? reinterpret_cast<const float*>(P.lp[l.src_b].out16) : P.lp[l.src_b].out;
             LayerPlan lq = lp;
             if (i == 15 && (P.mode == 0 || lp.path == PATH_LAST)) lq.out = P.cur_out;   // last layer writes the caller's block
             if (i == 15 && P.mode == 1 && lp.path == PATH_LAST) lq.last_rows = P.n_frames;
@@ -1175,7 +1228,7 @@ int ry_net_set_dtype(ry_net* net, int dtype) {
             for (size_t o = 0; o < outer; ++o)
                 for (int c = 0; c < C; ++c)
                     for (int nl = 0; nl < 64; ++nl)
-                        w16[((o * (C / 64) + c / 64) * 64 + nl) * 64 + c % 64] = host_f2bf(w32[(o * (C / 32) + c / 32) * 2048 + wig_inblock(nl, c % 32)]);
+                        w16[(o * (C / 64) + c / 64) * 4096 + wig16_inblock(nl, c % 64)] = host_f2bf(w32[(o * (C / 32) + c / 32) * 2048 + wig_inblock(nl, c % 32)]);
             float* d = nullptr;
             RY_TRY(net->weights.alloc(&d, (n + 1) / 2));
             RT_TRY(rt::h2d(d, w16.data(), n * sizeof(unsigned short), ctx->stream));
@@ -1489,15 +1542,13 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
         const int M = B * (transposed ? H * Wd : lp.Ho * lp.Wo);
         lp.kg = (tile & 16) ? 2 : ((tile & 32) ? 1 : 0);                    // +16: two K groups per workgroup, +32: one, else automatic
         tile &= 15;
-        if (lp.path == PATH_IGEMM_BF16) lp.kg = 1;
         lp.tile = tile; lp.splits = splits;
         if (tile < 0 || tile > TILE_256x128) return fail(RY_EINVAL, "unknown tile");
         if ((tile == TILE_256x64 || tile == TILE_128x64) ? Cout % 64 : (tile != 0 && Cout % 128)) return fail(RY_EINVAL, "tile does not divide Cout");
-        choose_igemm(l, M, t.nphases, t.ntaps * (Cin / 32), &lp.tile, &lp.splits, &lp.kg);
-        if (lp.path == PATH_IGEMM_BF16) {
-            if (lp.tile == TILE_256x64 || lp.tile == TILE_256x128) return fail(RY_EINVAL, "no bf16 instantiation of that tile");
-            const int nk64 = t.ntaps * (Cin / 64);
-            if (lp.splits > nk64) lp.splits = nk64;
+        const bool op16 = lp.path == PATH_IGEMM_BF16;
+        if (op16 && (tile == TILE_256x64 || tile == TILE_256x128)) return fail(RY_EINVAL, "no bf16 instantiation of that tile");
+        choose_igemm(l, M, t.nphases, t.ntaps * (Cin / (op16 ? 64 : 32)), &lp.tile, &lp.splits, &lp.kg, op16);
+        if (op16) {
             // bf16 filters of this single layer
             const size_t n = (size_t)t.nphases * Cout * t.ntaps * Cin;
             std::vector<float> w32;
@@ -1507,7 +1558,7 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
             for (size_t o = 0; o < outer; ++o)
                 for (int c = 0; c < Cin; ++c)
                     for (int nl = 0; nl < 64; ++nl)
-                        w16[((o * (Cin / 64) + c / 64) * 64 + nl) * 64 + c % 64] = host_f2bf(w32[(o * (Cin / 32) + c / 32) * 2048 + wig_inblock(nl, c % 32)]);
+                        w16[(o * (Cin / 64) + c / 64) * 4096 + wig16_inblock(nl, c % 64)] = host_f2bf(w32[(o * (Cin / 32) + c / 32) * 2048 + wig_inblock(nl, c % 32)]);
             RY_TRY(arena.alloc(&l.wig16, (n + 1) / 2));
             RT_TRY(rt::h2d(l.wig16, w16.data(), n * sizeof(unsigned short), ctx->stream));
             RT_TRY(rt::stream_sync(ctx->stream));
@@ -1533,6 +1584,14 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
         RT_TRY(rt::h2d(dx2, hb.data(), npix * Ch * sizeof(float), ctx->stream));
         RT_TRY(rt::stream_sync(ctx->stream));
         RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Ch, dx2, Ch, 0.2f));
+    } else if (lp.path == PATH_IGEMM_BF16) {
+        // the bf16 kernel reads bf16 activations (in a predictor the producing layer writes them): round the input here
+        const size_t nx = (size_t)B * H * Wd * Cin;
+        std::vector<unsigned short> x16(nx);
+        for (size_t q = 0; q < nx; ++q) x16[q] = host_f2bf(x[q]);
+        RT_TRY(rt::h2d(dx, x16.data(), nx * sizeof(unsigned short), ctx->stream));
+        RT_TRY(rt::stream_sync(ctx->stream));
+        RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Cin, nullptr, 0, 0.2f));
     } else {
         RT_TRY(rt::h2d(dx, x, (size_t)B * H * Wd * Cin * sizeof(float), ctx->stream));
         RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Cin, nullptr, 0, 0.2f));

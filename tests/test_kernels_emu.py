@@ -56,6 +56,28 @@ def test_predictor_emu(emu_ctx, cfg):
     net.close()
 
 
+def test_stage2_bf16_pipeline_emu(emu_ctx):
+    """bf16 mode of the stage-2 predictor: implicit-GEMM layers read / write bf16 activations (the first layer and the
+    split-K reduce kernels write bf16 copies), the end layers stay fp32.  A base-64 net with two stride-2 levels keeps the
+    emulator run short.  Stated tolerance of the mode against the fp32 oracle: 3e-2 (tests/test_gpu_parity.py)."""
+    d = NetDesc(2, 1, 1, 64, 2)
+    P = synthetic_params(d, 420, bias_std=0.05)
+    net = engine.Net(emu_ctx, d, flatten_params(d, P), width=16)
+    x = numpy.random.default_rng(21).normal(size=(1, 8, 16)).astype('f4')
+    ref = cases.oracle_forward(d, P, x)
+    y32 = net.forward(x)
+    assert rel_max(y32, ref) < cases.TOL
+    net.set_dtype('bf16')
+    y16 = net.forward(x)
+    names = [q['name'] for q in net.profile(1, 8, 1)]
+    assert any(n.endswith(',true>') for n in names), names           # the bf16 kernels did run
+    assert not numpy.array_equal(y16, y32)
+    assert rel_max(y16, ref) < 3e-2
+    net.set_dtype('f32')
+    assert numpy.array_equal(net.forward(x), y32)                      # and the exact path comes back bit for bit
+    net.close()
+
+
 @pytest.mark.parametrize('n_frames', [1, 37, 100, 128])
 def test_stage1_convert_emu(emu_ctx, n_frames):
     d = NetDesc(1, 9, 9, 8, 8)
