@@ -27,6 +27,7 @@ struct State {
     ucontext_t sched;
     int cur = 0;
     int nthreads = 0;
+    int live = 0;                      // fibers that have not returned yet: a barrier waits for these only (like the hardware)
     int bar_arrived = 0, bar_gen = 0;
     int wave_arrived[kMaxWaves] = {0}, wave_gen[kMaxWaves] = {0};
     float wa[kMaxWaves][64], wb[kMaxWaves][64];
@@ -40,6 +41,8 @@ void yield_to_sched() { swapcontext(&S->fibers[S->cur].ctx, &S->sched); }
 void trampoline() {
     (*S->body)();
     S->fibers[S->cur].done = true;
+    // a thread that returns no longer takes part in barriers: release one that was only waiting for it
+    if (--S->live > 0 && S->bar_arrived == S->live) { S->bar_arrived = 0; ++S->bar_gen; }
     // falls through to uc_link (= scheduler)
 }
 
@@ -64,6 +67,7 @@ void run_block(State& st, dim3 bidx, dim3 grid, dim3 block) {
     S = &st;
     const int n = (int)block.x;
     st.nthreads = n;
+    st.live = n;
     st.bar_arrived = 0;
     for (int w = 0; w < kMaxWaves; ++w) st.wave_arrived[w] = 0;
     if ((int)st.fibers.size() < n) {
@@ -99,7 +103,7 @@ void run_block(State& st, dim3 bidx, dim3 grid, dim3 block) {
 
 void sync_block() {
     const int g = S->bar_gen;
-    if (++S->bar_arrived == S->nthreads) {
+    if (++S->bar_arrived == S->live) {
         S->bar_arrived = 0;
         ++S->bar_gen;
     } else {
