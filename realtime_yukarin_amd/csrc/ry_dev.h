@@ -39,6 +39,13 @@ RY_DEV void ry_glds16(const float* gsrc_lane, float* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 RY_DEV int ry_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Lanes of one wave exchange data through the LDS: LDS instructions of a wave execute in order, so no hardware barrier is
+// needed -- only the compiler must not move the reads above the writes.
+RY_DEV void ry_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 RY_DEV float ry_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 RY_DEV float ry_shfl(float v, int src) { return __shfl(v, src, 64); }
 RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }

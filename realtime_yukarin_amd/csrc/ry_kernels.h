@@ -560,31 +560,63 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += scr[((i * TN + j) * 16 + r) * 64];
+        ry_wave_sync();                        // the epilogue reuses this wave's region as its transposition scratch
     }
 
     if (p.dbg_flags & 4) return;
+    // ---- epilogue: folded BN + activation in registers, then every 32 x 32 accumulator tile is transposed through a
+    // 4-KiB per-wave LDS scratch (the operand buffers are idle now) so that a lane holds 4 consecutive channels of one
+    // pixel: 4 x 16-byte stores per tile instead of 16 x 4-byte ones, one row lookup per store.  (The scalar-store
+    // epilogue was ~60 instructions per store and ~10 us of a 125 us layer: all workgroups reach it together.)
     float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
+    float* T = (wave < 2 ? Bs0 : Bs1) + (wave & 1) * (KG > 1 ? TM * TN * 16 * 64 : 1024);
+    static_assert(BN * BK >= 2048, "two waves' transposition scratch fits one B buffer");
+    const bool final_ = p.splits == 1;
+    const int erow = lane >> 3, eslot = lane & 7;            // store role: row erow + 8 q of the tile, channels 4 eslot .. + 3
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + lr;
+        const int nbase = n0 + (wn * TN + j) * 32;
         float sc = 1.f, sh = 0.f;
-        if (p.splits == 1) { sc = p.scale[n]; sh = p.shift[n]; }
+        if (final_) { sc = p.scale[nbase + lr]; sh = p.shift[nbase + lr]; }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int ob = rO[ml];
-                if (ob >= 0) {
-                    float v = acc[i][j][r];
-                    if (p.splits == 1) {
-                        v = ry_act(fmaf(v, sc, sh), p.act, p.slope);
-                        if (p.out16) p.out16[(size_t)ob * g.N + n] = ry_f2bf(v);
-                        if (!p.out) continue;
-                    }
-                    outp[(size_t)ob * g.N + n] = v;
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+            if (final_) {
+                if (p.act == RY_ACT_LRELU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float x = fmaf(v[r], sc, sh); v[r] = x >= 0.f ? x : x * p.slope; }
+                } else if (p.act == RY_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float x = fmaf(v[r], sc, sh); v[r] = x > 0.f ? x : 0.f; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = fmaf(v[r], sc, sh);
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                T[row * 32 + ((((lr >> 2) ^ (row & 7)) << 2) | (lr & 3))] = v[r];
+            }
+            ry_wave_sync();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = erow + 8 * q;
+                const f32x4 o = ry_ld4(T + row * 32 + ((eslot ^ (row & 7)) << 2));
+                const int ob = rO[(wm * TM + i) * 32 + row];
+                if (ob >= 0) {
+                    const size_t oi = (size_t)ob * g.N + nbase + eslot * 4;
+                    if (!final_ || p.out) ry_st4(outp + oi, o);
+                    if (final_ && p.out16) {
+                        u16x4 h;
+                        h[0] = ry_f2bf(o[0]); h[1] = ry_f2bf(o[1]); h[2] = ry_f2bf(o[2]); h[3] = ry_f2bf(o[3]);
+                        *reinterpret_cast<u16x4*>(p.out16 + oi) = h;
+                    }
+                }
+            }
+            ry_wave_sync();
         }
     }
 }

@@ -101,6 +101,8 @@ void run_block(State& st, dim3 bidx, dim3 grid, dim3 block) {
 }
 }  // namespace
 
+void wave_sync() { sync_wave(); }
+
 void sync_block() {
     const int g = S->bar_gen;
     if (++S->bar_arrived == S->live) {

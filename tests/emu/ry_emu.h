@@ -27,6 +27,7 @@ struct dim3 {
 namespace ry_emu {
 extern thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 void sync_block();
+void wave_sync();
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
 f32x16 mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c);
 unsigned short f2bf(float f);
@@ -52,6 +53,7 @@ RY_DEV void ry_glds16(const float* gsrc_lane, float* lds_wave_base) {          /
     memcpy(lds_wave_base + 4 * (threadIdx.x & 63u), gsrc_lane, 16);
 }
 RY_DEV int ry_uniform(int v) { return v; }
+RY_DEV void ry_wave_sync() { ry_emu::wave_sync(); }
 RY_DEV float ry_shfl_xor(float v, int mask) { return ry_emu::shfl_xor(v, mask); }
 RY_DEV float ry_shfl(float v, int src) { return ry_emu::shfl(v, src); }
 RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }
