@@ -31,6 +31,17 @@ RY_DEV float ry_act(float v, int act, float slope) {
 }
 RY_DEV float ry_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
 
+// Exact x / d for 0 <= x < 2^24, 1 <= d < 2^24: one float multiply by a host-side reciprocal plus a +-1 fix-up (an integer
+// division is ~40 instructions on gfx950, and the prologue of the implicit GEMM -- executed once, all workgroups of a
+// one-round grid at the same time -- had a dozen of them).
+RY_DEV int ry_fdiv(int x, int d, float inv_d) {
+    int q = (int)((float)x * inv_d);
+    const int r = x - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Convolution geometry shared by the implicit-GEMM and the direct kernel.
 // GEMM rows enumerate (b, ry, rx) over an Mh x Mw grid per image; input coordinate of tap t is
@@ -64,6 +75,10 @@ struct RyIgemmParams {
     float slope;
     long long slab_stride;
     int mtiles, ntiles;         // 1-D XCD-aware grid: logical id = ((split*mtiles + mt)*ntiles + nt)*nphases + phase
+    // host-side helpers of the LDS-DMA kernel's prologue (reciprocals for ry_fdiv, the 2-D tile grid, the K split)
+    float inv_nphases, inv_ntiles, inv_mtiles, inv_Mimg, inv_Mw, inv_cpt, inv_kw, inv_tcols, inv_trows;
+    int tw_shift, th, tcols, trows;   // 2-D M-tiles: tw = 1 << tw_shift columns x th rows, tcols x trows tiles per image
+    int kq, krem;               // K chunks per split: split s takes kq + (s < krem) chunks starting at s * kq + min(s, krem)
     int tw;                     // > 0: an M-tile is a 2-D block of (BM/tw) x tw rows of the Mh x Mw grid (compact input footprint:
                                 //      overlapping taps hit L2); 0: BM consecutive rows in raster order
     unsigned long long* dbg;    // VAR bit 1 (diagnostic build of the kernel): per-phase shader-clock totals, else unused
@@ -363,10 +378,12 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     const int per_xcd = (total_tiles + 7) >> 3;
     int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (lid >= total_tiles) return;
-    const int phase = lid % p.g.nphases; lid /= p.g.nphases;
-    const int nt = lid % p.ntiles; lid /= p.ntiles;
-    const int mt = lid % p.mtiles;
-    const int split = lid / p.mtiles;
+    int q_ = ry_fdiv(lid, p.g.nphases, p.inv_nphases);
+    const int phase = lid - q_ * p.g.nphases; lid = q_;
+    q_ = ry_fdiv(lid, p.ntiles, p.inv_ntiles);
+    const int nt = lid - q_ * p.ntiles; lid = q_;
+    const int split = ry_fdiv(lid, p.mtiles, p.inv_mtiles);
+    const int mt = lid - split * p.mtiles;
     const int m0 = mt * BM;
     const int n0 = nt * BN;
     const int Ctot = g.C1 + g.C2;
@@ -381,14 +398,15 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
         bool live = m < M;
         int b = 0, ry = 0, rx = 0;
         if (p.tw > 0) {
-            const int th = BM / p.tw, tcols = g.Mw / p.tw, trows = g.Mh / th;
-            const int tx = mt % tcols, ty = (mt / tcols) % trows;
-            b = mt / (tcols * trows);
-            ry = ty * th + r / p.tw; rx = tx * p.tw + r % p.tw;
+            const int trow = ry_fdiv(mt, p.tcols, p.inv_tcols);              // tile row counted over the whole batch
+            const int tx = mt - trow * p.tcols;
+            b = ry_fdiv(trow, p.trows, p.inv_trows);
+            const int ty = trow - b * p.trows;
+            ry = ty * p.th + (r >> p.tw_shift); rx = tx * p.tw + (r & (p.tw - 1));
             live = b < g.B;
         } else if (live) {
-            b = m / Mimg; const int rem = m - b * Mimg;
-            ry = rem / g.Mw; rx = rem - ry * g.Mw;
+            b = ry_fdiv(m, Mimg, p.inv_Mimg); const int rem = m - b * Mimg;
+            ry = ry_fdiv(rem, g.Mw, p.inv_Mw); rx = rem - ry * g.Mw;
         }
         if (live) {
             yb = ry * g.stride - g.pad;
@@ -428,16 +446,14 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     }
 
     const int cpt = Ctot / CK;
-    const int nk = g.ntaps * cpt;
-    const int kc_begin = (int)(((long long)nk * split) / p.splits);
-    const int kc_end = (int)(((long long)nk * (split + 1)) / p.splits);
-    const int wg_chunks = (p.dbg_flags & 8) ? 0 : kc_end - kc_begin;
-    const int g_begin = kc_begin + (wg_chunks * grp) / KG;                 // this K group's share of the workgroup's range
-    const int nchunks = (wg_chunks * (grp + 1)) / KG - (wg_chunks * grp) / KG;
+    const int kc_begin = split * p.kq + (split < p.krem ? split : p.krem);
+    const int wg_chunks = (p.dbg_flags & 8) ? 0 : p.kq + (split < p.krem ? 1 : 0);
+    const int g_begin = kc_begin + (KG > 1 ? (wg_chunks >> 1) * grp : 0);  // this K group's share: the first floor(n / 2), the rest
+    const int nchunks = KG > 1 ? (grp ? wg_chunks - (wg_chunks >> 1) : (wg_chunks >> 1)) : wg_chunks;
     const int max_chunks = (wg_chunks + KG - 1) / KG;                      // barrier count is the same for both groups
-    int tap = g_begin / cpt;
+    int tap = ry_fdiv(g_begin, cpt, p.inv_cpt);
     int cib = g_begin - tap * cpt;
-    int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
+    int ky = ry_fdiv(tap, g.kw, p.inv_kw), kx = tap - ky * g.kw;
 
     // state of the chunk being fetched (wave-uniform)
     const float* c_src = nullptr; bool c_first = true; int c_delta = 0, c_dy = 0, c_dx = 0; unsigned c_bdelta = 0;

@@ -633,6 +633,20 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
                 if (bm % tw == 0 && g.Mw % tw == 0 && g.Mh % (bm / tw) == 0) { p.tw = tw; break; }
             }
         }
+        {   // prologue helpers of the LDS-DMA kernel (ry_fdiv reciprocals; operands stay below 2^24, checked here)
+            const int ck = bf16 ? 64 : 32, cpt = (C1 + C2) / ck, nkc = g.ntaps * cpt;
+            if ((long long)p.mtiles * p.ntiles * g.nphases * lp.splits >= (1 << 24) || M >= (1 << 24))
+                return fail(RY_EINVAL, "%s: more than 2^24 output rows or tiles in one launch; lower the batch", l.name);
+            p.inv_nphases = 1.f / g.nphases; p.inv_ntiles = 1.f / p.ntiles; p.inv_mtiles = 1.f / p.mtiles;
+            p.inv_Mimg = 1.f / (float)(g.Mh * g.Mw); p.inv_Mw = 1.f / g.Mw; p.inv_cpt = 1.f / cpt; p.inv_kw = 1.f / g.kw;
+            p.tw_shift = 0; p.th = 1; p.tcols = 1; p.trows = 1; p.inv_tcols = 1.f; p.inv_trows = 1.f;
+            if (p.tw > 0) {
+                while ((1 << p.tw_shift) < p.tw) ++p.tw_shift;
+                p.th = bm / p.tw; p.tcols = g.Mw / p.tw; p.trows = g.Mh / p.th;
+                p.inv_tcols = 1.f / p.tcols; p.inv_trows = 1.f / p.trows;
+            }
+            p.kq = nkc / lp.splits; p.krem = nkc % lp.splits;
+        }
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
         dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
         RY_TRY(Lc.begin(tile_name(lp.tile, lp.kg, bf16), l.name, lp.flops, lp.bytes, grid));
