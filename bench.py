@@ -221,7 +221,9 @@ def main():
         dname, dv = dom
         ach = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(dname)
-        peak_tf = 2500.0 if dname.endswith(',true>') else F32_MFMA_PEAK_TF      # ry_igemm_ldsdma<..., BF16 = true>: dense bf16 MFMA peak, else fp32-input MFMA peak
+        targs = dname[dname.find('<') + 1:-1].split(',') if dname.startswith('ry_igemm_ldsdma<') else []
+        is_bf16 = len(targs) > 5 and targs[5] == 'true'                # ry_igemm_ldsdma<BM,BN,WM,WN,KG,BF16,PATCH>
+        peak_tf = 2500.0 if is_bf16 else F32_MFMA_PEAK_TF             # dense bf16 MFMA peak, else fp32-input MFMA peak
         out['roofline'] = {'kernel': dname, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                            'frac': round(ach / peak_tf, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
                            'traffic_source': traffic_src,

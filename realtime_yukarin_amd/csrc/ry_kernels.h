@@ -355,19 +355,24 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 // ---------------------------------------------------------------------------------------------
 template <int V> struct RyConst { static constexpr int value = V; };
 
-template <int BM, int BN, int WM, int WN, int KG, bool BF16>
+template <int BM, int BN, int WM, int WN, int KG, bool BF16, bool PATCH>
 RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     constexpr int BK = 32, NS = 4;            // LDS rows of 128 bytes: 32 floats or 64 bf16
     constexpr int CK = BF16 ? 64 : 32;        // input channels per K chunk
     constexpr int ES = BF16 ? 8 : 4;          // elements per 16-byte slot
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int AG = BM / 8;                // 1-KiB DMA pieces of the A tile (8 rows each)
+    // PATCH (sub-pixel deconvolution, 16-pixel-wide 2-D tiles): the four taps of a phase read overlapping pixels, so the
+    // input patch of the tile ((BM / 16 + 1) x 17 pixels) is fetched ONCE per channel chunk and the A fragments of tap
+    // (ky, kx) are read from it at a uniform row offset -- 15 instead of 48 A pieces per chunk for a 96-row tile.
+    constexpr int PW = 17, PR = (BM / 16 + 1) * PW, PG = (PR + 7) / 8;
+    constexpr int AROWS = PATCH ? PG * 8 : BM;   // LDS rows of one A buffer
+    constexpr int AG = PATCH ? PG : BM / 8;      // 1-KiB DMA pieces of the A tile / patch (8 rows each)
     constexpr int BG = BN / 8;                // 1-KiB DMA pieces of the B tile ((32 columns, K step) each)
     constexpr int AI = (AG + 3) / 4, BI = (BG + 3) / 4, NI = AI + BI;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BM % 32 == 0 && BN % 32 == 0 && BM <= 128, "tile shape");
     static_assert(KG == 1 || KG == 2, "one or two K groups of four waves");
-    __shared__ __attribute__((aligned(16))) float As0[KG * BM * BK];
-    __shared__ __attribute__((aligned(16))) float As1[KG * BM * BK];
+    __shared__ __attribute__((aligned(16))) float As0[KG * AROWS * BK];
+    __shared__ __attribute__((aligned(16))) float As1[KG * AROWS * BK];
     __shared__ __attribute__((aligned(16))) float Bs0[KG * BN * BK];
     __shared__ __attribute__((aligned(16))) float Bs1[KG * BN * BK];
     __shared__ int rY[BM], rX[BM], rP[BM], rO[BM];
@@ -425,6 +430,27 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     // ---- A: DMA role of this lane = row drow / position dpos inside each 8-row piece this wave fills ----
     const int drow = lane >> 3, dpos = lane & 7;
     int ayb[AI], axb[AI], aoff1[AI], aoff2[AI];
+    if (PATCH) {
+        // patch pixel of this lane in each piece it fills: element offsets into the two sources, or -1 (outside the image,
+        // past the patch, past the batch: fetched from the zero page)
+        const int trow = ry_fdiv(mt, p.tcols, p.inv_tcols);
+        const int tx = mt - trow * p.tcols;
+        const int bimg = ry_fdiv(trow, p.trows, p.inv_trows);
+        const int ty = trow - bimg * p.trows;
+        const int oy0 = ty * (BM / 16) + pdy - 1, ox0 = tx * 16 + pdx - 1;   // input pixel of patch (0, 0): taps reach one pixel up / left of the phase
+#pragma unroll
+        for (int j = 0; j < AI; ++j) {
+            const int pr = (4 * j + wave) * 8 + drow;
+            const int py = ry_fdiv(pr, PW, 1.0f / PW), px = pr - py * PW;
+            const int iy = oy0 + py, ix = ox0 + px;
+            const bool ok = pr < PR && bimg < g.B && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            const int ce = (dpos ^ ((pr >> 1) & 7)) * ES;
+            const int pix = (bimg * g.Hi + iy) * g.Wi + ix;
+            aoff1[j] = ok ? pix * g.C1 + ce : -1;
+            aoff2[j] = ok ? pix * g.C2 + ce : -1;
+            ayb[j] = 0; axb[j] = 0;
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
         const int gi = 4 * j + wave;
@@ -434,6 +460,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
         const int pixb = rP[row] + ayb[j] * g.Wi + axb[j];
         aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + ce : 0;
         aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + ce : 0;
+    }
     }
     // ---- B: element offset of this lane's 16 bytes in the (tap 0, chunk 0) block of each (32 columns, K step) piece ----
     const int c32 = Ctot / CK;                 // K blocks of the filter layout (8 KiB each: 64 x 32 floats or 64 x 64 bf16)
@@ -446,44 +473,13 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     }
 
     const int cpt = Ctot / CK;
+    // K ranges are counted in units of one chunk (PATCH: one channel chunk = its four taps, so that every K group starts at tap 0)
+    constexpr int KU = PATCH ? 4 : 1;
     const int kc_begin = split * p.kq + (split < p.krem ? split : p.krem);
-    const int wg_chunks = (p.dbg_flags & 8) ? 0 : p.kq + (split < p.krem ? 1 : 0);
-    const int g_begin = kc_begin + (KG > 1 ? (wg_chunks >> 1) * grp : 0);  // this K group's share: the first floor(n / 2), the rest
-    const int nchunks = KG > 1 ? (grp ? wg_chunks - (wg_chunks >> 1) : (wg_chunks >> 1)) : wg_chunks;
-    const int max_chunks = (wg_chunks + KG - 1) / KG;                      // barrier count is the same for both groups
-    int tap = ry_fdiv(g_begin, cpt, p.inv_cpt);
-    int cib = g_begin - tap * cpt;
-    int ky = ry_fdiv(tap, g.kw, p.inv_kw), kx = tap - ky * g.kw;
-
-    // state of the chunk being fetched (wave-uniform)
-    const float* c_src = nullptr; bool c_first = true; int c_delta = 0, c_dy = 0, c_dx = 0; unsigned c_bdelta = 0;
-    auto next_chunk = [&]() {
-        const int ci0 = cib * CK;
-        c_first = ci0 < g.C1;
-        c_src = c_first ? g.src1 : g.src2;
-        const int Cs = c_first ? g.C1 : g.C2;
-        const int cil = c_first ? ci0 : ci0 - g.C1;
-        c_dy = subpix ? pdy - ky : ky; c_dx = subpix ? pdx - kx : kx;
-        c_delta = (c_dy * g.Wi + c_dx) * Cs + cil;
-        c_bdelta = (unsigned)((tap * c32 + cib) * 2048);
-        if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
-    };
-    auto dma_item = [&](int q, float* Ad, float* Bd) {     // q-th DMA instruction of this wave for the chunk being fetched
-        if (q < AI) {
-            const int j = q, gi = 4 * j + wave;
-            if (AG % 4 == 0 || gi < AG) {
-                const int iy = ayb[j] + c_dy, ix = axb[j] + c_dx;
-                const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-                const unsigned eo = (unsigned)((c_first ? aoff1[j] : aoff2[j]) + c_delta);     // elements (fp32 or bf16)
-                const float* gp = !ok ? p.zeros : BF16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(c_src) + eo) : c_src + eo;
-                ry_glds16(gp, Ad + gi * 256);
-            }
-        } else {
-            const int j = q - AI, gi = 4 * j + wave;
-            if (BG % 4 == 0 || gi < BG) ry_glds16(p.wt + (boff[j] + c_bdelta), Bd + gi * 256);
-        }
-    };
-
+    const int wg_units = (p.dbg_flags & 8) ? 0 : p.kq + (split < p.krem ? 1 : 0);
+    const int g_begin = (kc_begin + (KG > 1 ? (wg_units >> 1) * grp : 0)) * KU;   // this K group's share: the first floor(n / 2) units, the rest
+    const int nchunks = (KG > 1 ? (grp ? wg_units - (wg_units >> 1) : (wg_units >> 1)) : wg_units) * KU;
+    const int max_chunks = ((wg_units + KG - 1) / KG) * KU;                // barrier count is the same for both groups
     const int sw = (lr >> 1) & 7;                // swizzle key of every A fragment row this lane reads (tile rows are multiples of 32)
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -493,66 +489,204 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float* const A0 = As0 + grp * (BM * BK); float* const A1 = As1 + grp * (BM * BK);
+    float* const A0 = As0 + grp * (AROWS * BK); float* const A1 = As1 + grp * (AROWS * BK);
     float* const B0 = Bs0 + grp * (BN * BK); float* const B1 = Bs1 + grp * (BN * BK);
-    // A workgroup with at most two chunks per K group (the weight-streaming layers with M <= 64 rows and split-K in the
-    // hundreds) fetches both up front: its time is a chain of memory latencies, not MFMA work.
-    const bool pre2 = max_chunks <= 2;
-    if (nchunks > 0) {
-        next_chunk();
-#pragma unroll
-        for (int q = 0; q < NI; ++q) dma_item(q, A0, B0);
-        if (pre2 && nchunks > 1) {
-            next_chunk();
-#pragma unroll
-            for (int q = 0; q < NI; ++q) dma_item(q, A1, B1);
-        }
-    }
-    __syncthreads();
+    if constexpr (!PATCH) {
+        int tap = ry_fdiv(g_begin, cpt, p.inv_cpt);
+        int cib = g_begin - tap * cpt;
+        int ky = ry_fdiv(tap, g.kw, p.inv_kw), kx = tap - ky * g.kw;
 
-    auto run_chunk = [&](auto bufc, int k) {
-        constexpr int BUF = decltype(bufc)::value;
-        const float* Ac = BUF ? A1 : A0;
-        const float* Bc = BUF ? B1 : B0;
-        float* An = BUF ? A0 : A1;
-        float* Bn = BUF ? B0 : B1;
-        const bool more = (k + 1 < nchunks) && !pre2 && !(p.dbg_flags & 128);
-        if (more) next_chunk();
-        const float* Ab = Ac + ((wm * TM) * 32 + lr) * BK;
-        if (KG == 1 || k < nchunks) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int pos = ((2 * s + lh) ^ sw) * 4;
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = ry_ld4(Ab + i * 32 * BK + pos);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(Bc + ((wn * TN + j) * 4 + s) * 256 + lane * 4);
-            if (more) {
-#pragma unroll
-                for (int q = (s * NI) / NS; q < ((s + 1) * NI) / NS; ++q) dma_item(q, An, Bn);
-            }
-            if (BF16) {                        // one v_mfma_f32_32x32x16_bf16 per fragment pair: the 16 bytes are 8 bf16 of k = 16 s + 8 (lane >> 5) + j
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = ry_mfma_32x32x16_bf16(__builtin_bit_cast(u16x8, af[i]), __builtin_bit_cast(u16x8, bf[j]), acc[i][j]);
+        // state of the chunk being fetched (wave-uniform)
+        const float* c_src = nullptr; bool c_first = true; int c_delta = 0, c_dy = 0, c_dx = 0; unsigned c_bdelta = 0;
+        auto next_chunk = [&]() {
+            const int ci0 = cib * CK;
+            c_first = ci0 < g.C1;
+            c_src = c_first ? g.src1 : g.src2;
+            const int Cs = c_first ? g.C1 : g.C2;
+            const int cil = c_first ? ci0 : ci0 - g.C1;
+            c_dy = subpix ? pdy - ky : ky; c_dx = subpix ? pdx - kx : kx;
+            c_delta = (c_dy * g.Wi + c_dx) * Cs + cil;
+            c_bdelta = (unsigned)((tap * c32 + cib) * 2048);
+            if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
+        };
+        auto dma_item = [&](int q, float* Ad, float* Bd) {     // q-th DMA instruction of this wave for the chunk being fetched
+            if (q < AI) {
+                const int j = q, gi = 4 * j + wave;
+                if (AG % 4 == 0 || gi < AG) {
+                    const int iy = ayb[j] + c_dy, ix = axb[j] + c_dx;
+                    const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                    const unsigned eo = (unsigned)((c_first ? aoff1[j] : aoff2[j]) + c_delta);     // elements (fp32 or bf16)
+                    const float* gp = !ok ? p.zeros : BF16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(c_src) + eo) : c_src + eo;
+                    ry_glds16(gp, Ad + gi * 256);
+                }
             } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
+                const int j = q - AI, gi = 4 * j + wave;
+                if (BG % 4 == 0 || gi < BG) ry_glds16(p.wt + (boff[j] + c_bdelta), Bd + gi * 256);
+            }
+        };
+
+        // A workgroup with at most two chunks per K group (the weight-streaming layers with M <= 64 rows and split-K in the
+        // hundreds) fetches both up front: its time is a chain of memory latencies, not MFMA work.
+        const bool pre2 = max_chunks <= 2;
+        if (nchunks > 0) {
+            next_chunk();
+    #pragma unroll
+            for (int q = 0; q < NI; ++q) dma_item(q, A0, B0);
+            if (pre2 && nchunks > 1) {
+                next_chunk();
+    #pragma unroll
+                for (int q = 0; q < NI; ++q) dma_item(q, A1, B1);
             }
         }
+        __syncthreads();
+
+        auto run_chunk = [&](auto bufc, int k) {
+            constexpr int BUF = decltype(bufc)::value;
+            const float* Ac = BUF ? A1 : A0;
+            const float* Bc = BUF ? B1 : B0;
+            float* An = BUF ? A0 : A1;
+            float* Bn = BUF ? B0 : B1;
+            const bool more = (k + 1 < nchunks) && !pre2 && !(p.dbg_flags & 128);
+            if (more) next_chunk();
+            const float* Ab = Ac + ((wm * TM) * 32 + lr) * BK;
+            if (KG == 1 || k < nchunks) {
+    #pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int pos = ((2 * s + lh) ^ sw) * 4;
+                f32x4 af[TM], bf[TN];
+    #pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = ry_ld4(Ab + i * 32 * BK + pos);
+    #pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(Bc + ((wn * TN + j) * 4 + s) * 256 + lane * 4);
+                if (more) {
+    #pragma unroll
+                    for (int q = (s * NI) / NS; q < ((s + 1) * NI) / NS; ++q) dma_item(q, An, Bn);
+                }
+                if (BF16) {                        // one v_mfma_f32_32x32x16_bf16 per fragment pair: the 16 bytes are 8 bf16 of k = 16 s + 8 (lane >> 5) + j
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = ry_mfma_32x32x16_bf16(__builtin_bit_cast(u16x8, af[i]), __builtin_bit_cast(u16x8, bf[j]), acc[i][j]);
+                } else {
+    #pragma unroll
+                for (int t = 0; t < 4; ++t)
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
+                }
+            }
+            }
+            __syncthreads();                       // DMA of chunk k + 1 landed (vmcnt) and buffer BUF is free again
+        };
+        for (int k = 0; k < max_chunks; k += 2) {
+            run_chunk(RyConst<0>(), k);
+            if (k + 1 < max_chunks) run_chunk(RyConst<1>(), k + 1);
         }
-        __syncthreads();                       // DMA of chunk k + 1 landed (vmcnt) and buffer BUF is free again
-    };
-    for (int k = 0; k < max_chunks; k += 2) {
-        run_chunk(RyConst<0>(), k);
-        if (k + 1 < max_chunks) run_chunk(RyConst<1>(), k + 1);
+
+    } else
+    {
+        // ---------------- PATCH main loop: iteration k = (channel chunk k / 4, tap k % 4) ----------------
+        const int chunk0 = g_begin >> 2;              // K groups start at tap 0 (K units are whole chunks)
+        int pch = chunk0;                             // next channel chunk whose patch is fetched
+        int bit = 0;                                  // next iteration whose filters are fetched
+        const float* c_src = nullptr; bool c_first = true; int c_cil = 0; unsigned c_bdelta = 0;
+        auto next_patch = [&]() {
+            const int ci0 = pch * CK;
+            c_first = ci0 < g.C1;
+            c_src = c_first ? g.src1 : g.src2;
+            c_cil = c_first ? ci0 : ci0 - g.C1;
+            ++pch;
+        };
+        auto next_b = [&]() {
+            c_bdelta = (unsigned)(((bit & 3) * c32 + chunk0 + (bit >> 2)) * 2048);
+            ++bit;
+        };
+        auto patch_item = [&](int j, float* Ad) {
+            const int gi = 4 * j + wave;
+            if (AG % 4 == 0 || gi < AG) {
+                const int off = c_first ? aoff1[j] : aoff2[j];
+                const unsigned eo = (unsigned)(off + c_cil);
+                const float* gp = off < 0 ? p.zeros : BF16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(c_src) + eo) : c_src + eo;
+                ry_glds16(gp, Ad + gi * 256);
+            }
+        };
+        auto b_item = [&](int j, float* Bd) {
+            const int gi = 4 * j + wave;
+            if (BG % 4 == 0 || gi < BG) ry_glds16(p.wt + (boff[j] + c_bdelta), Bd + gi * 256);
+        };
+        int pbase[TM];                                // patch row of this lane's fragment rows for the tap at offset (0, 0)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { const int ml = (wm * TM + i) * 32 + lr; pbase[i] = (ml >> 4) * PW + (ml & 15); }
+        if (nchunks > 0) {
+            next_patch();
+#pragma unroll
+            for (int j = 0; j < AI; ++j) patch_item(j, A0);
+            next_b();
+#pragma unroll
+            for (int j = 0; j < BI; ++j) b_item(j, B0);
+        }
+        __syncthreads();
+        auto run_it = [&](auto k8c, int k) {
+            constexpr int K8 = decltype(k8c)::value;
+            constexpr int TAP = K8 & 3, ABUF = (K8 >> 2) & 1, BBUF = K8 & 1;
+            constexpr int TAPOFF = (1 - (TAP >> 1)) * PW + (1 - (TAP & 1));       // (dy - dymin) * PW + (dx - dxmin), dy = pdy - ky
+            const float* Ac = ABUF ? A1 : A0;
+            const float* Bc = BBUF ? B1 : B0;
+            float* An = ABUF ? A0 : A1;
+            float* Bn = BBUF ? B0 : B1;
+            const bool more_b = (k + 1 < nchunks) && !(p.dbg_flags & 128);
+            const bool more_a = TAP == 0 && (k + 4 < nchunks) && !(p.dbg_flags & 128);
+            if (more_b) next_b();
+            if (more_a) next_patch();
+            if (KG == 1 || k < nchunks) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int pr = pbase[i] + TAPOFF;
+                    af[i] = ry_ld4(Ac + pr * BK + (((2 * s + lh) ^ ((pr >> 1) & 7)) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(Bc + ((wn * TN + j) * 4 + s) * 256 + lane * 4);
+                if (more_b) {
+#pragma unroll
+                    for (int q = (s * BI) / NS; q < ((s + 1) * BI) / NS; ++q) b_item(q, Bn);
+                }
+                if (TAP == 0 && more_a) {
+#pragma unroll
+                    for (int q = (s * AI) / NS; q < ((s + 1) * AI) / NS; ++q) patch_item(q, An);
+                }
+                if (BF16) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = ry_mfma_32x32x16_bf16(__builtin_bit_cast(u16x8, af[i]), __builtin_bit_cast(u16x8, bf[j]), acc[i][j]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
+                }
+            }
+            }
+            __syncthreads();
+        };
+        for (int k = 0; k < max_chunks; k += 8) {
+            run_it(RyConst<0>(), k);
+            if (k + 1 < max_chunks) run_it(RyConst<1>(), k + 1);
+            if (k + 2 < max_chunks) run_it(RyConst<2>(), k + 2);
+            if (k + 3 < max_chunks) run_it(RyConst<3>(), k + 3);
+            if (k + 4 < max_chunks) run_it(RyConst<4>(), k + 4);
+            if (k + 5 < max_chunks) run_it(RyConst<5>(), k + 5);
+            if (k + 6 < max_chunks) run_it(RyConst<6>(), k + 6);
+            if (k + 7 < max_chunks) run_it(RyConst<7>(), k + 7);
+        }
     }
 
     if (KG > 1) {

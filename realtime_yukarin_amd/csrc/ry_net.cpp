@@ -480,6 +480,7 @@ static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in o
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
 static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
 static int g_igemm_dbg = 0; // RY_IGEMM_DBG: ablation bits of ry_igemm_ldsdma (diagnostics; wrong results)
+static int g_patch = 1;     // RY_PATCH=0: deconvolution layers gather every tap's A tile separately (no input-patch reuse)
 static int g_kgroups = 1;   // RY_KGROUPS=0: never split K inside a workgroup (external split-K + reduce kernel only)
 static int g_ldsdma = 1;    // RY_LDSDMA=0: register-staged ry_igemm_f32 instead of the LDS-DMA kernel (A/B; ~5 % slower end to end)
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
@@ -487,18 +488,21 @@ static unsigned long long* g_dbg = nullptr;
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
 // Kernel names as rocprofv3 prints them (template arguments, no spaces): bench.py matches them against profiles/*.
-static const char* tile_name(int tile, int kg, bool bf16) {
+static const char* tile_name(int tile, int kg, bool bf16, bool patch) {
     const bool dma = (g_ldsdma && !g_timing) || bf16;
-    static const char* const names[8][2][2] = {
-        {{"ry_igemm_ldsdma<32,128,1,4,1,false>", "ry_igemm_ldsdma<32,128,1,4,1,true>"}, {"ry_igemm_ldsdma<32,128,1,4,2,false>", "ry_igemm_ldsdma<32,128,1,4,2,true>"}},
-        {{"ry_igemm_ldsdma<128,128,2,2,1,false>", "ry_igemm_ldsdma<128,128,2,2,1,true>"}, {"ry_igemm_ldsdma<128,128,2,2,2,false>", "ry_igemm_ldsdma<128,128,2,2,2,true>"}},
-        {{nullptr, nullptr}, {nullptr, nullptr}},
-        {{"ry_igemm_ldsdma<64,128,1,4,1,false>", "ry_igemm_ldsdma<64,128,1,4,1,true>"}, {"ry_igemm_ldsdma<64,128,1,4,2,false>", "ry_igemm_ldsdma<64,128,1,4,2,true>"}},
-        {{"ry_igemm_ldsdma<32,128,1,4,1,false>", "ry_igemm_ldsdma<32,128,1,4,1,true>"}, {"ry_igemm_ldsdma<32,128,1,4,2,false>", "ry_igemm_ldsdma<32,128,1,4,2,true>"}},
-        {{"ry_igemm_ldsdma<128,64,4,1,1,false>", "ry_igemm_ldsdma<128,64,4,1,1,true>"}, {"ry_igemm_ldsdma<128,64,4,1,2,false>", "ry_igemm_ldsdma<128,64,4,1,2,true>"}},
-        {{"ry_igemm_ldsdma<96,128,1,4,1,false>", "ry_igemm_ldsdma<96,128,1,4,1,true>"}, {"ry_igemm_ldsdma<96,128,1,4,2,false>", "ry_igemm_ldsdma<96,128,1,4,2,true>"}},
-        {{nullptr, nullptr}, {nullptr, nullptr}}};
-    if (dma && tile >= 0 && tile < 8 && names[tile][0][0]) return names[tile][kg == 2][bf16];
+    if (dma && tile != TILE_256x64 && tile != TILE_256x128) {
+        static std::map<int, std::string> names;        // stable storage for the returned pointers
+        const int key = ((tile * 4 + kg) * 2 + (bf16 ? 1 : 0)) * 2 + (patch ? 1 : 0);
+        auto it = names.find(key);
+        if (it == names.end()) {
+            int bm, bn; tile_dims(tile, &bm, &bn);
+            const int wmv = (tile == TILE_128x128) ? 2 : (tile == TILE_128x64 ? 4 : 1), wnv = 4 / wmv;
+            char buf[96];
+            snprintf(buf, sizeof buf, "ry_igemm_ldsdma<%d,%d,%d,%d,%d,%s,%s>", bm, bn, wmv, wnv, kg == 2 ? 2 : 1, bf16 ? "true" : "false", patch ? "true" : "false");
+            it = names.emplace(key, buf).first;
+        }
+        return it->second.c_str();
+    }
     switch (tile) {
         case TILE_128x128: return "ry_igemm_f32<128,128>";
         case TILE_256x64: return "ry_igemm_f32<256,64>";
@@ -633,6 +637,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
                 if (bm % tw == 0 && g.Mw % tw == 0 && g.Mh % (bm / tw) == 0) { p.tw = tw; break; }
             }
         }
+        bool patch = false;
         {   // prologue helpers of the LDS-DMA kernel (ry_fdiv reciprocals; operands stay below 2^24, checked here)
             const int ck = bf16 ? 64 : 32, cpt = (C1 + C2) / ck, nkc = g.ntaps * cpt;
             if ((long long)p.mtiles * p.ntiles * g.nphases * lp.splits >= (1 << 24) || M >= (1 << 24))
@@ -645,17 +650,22 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
                 p.th = bm / p.tw; p.tcols = g.Mw / p.tw; p.trows = g.Mh / p.th;
                 p.inv_tcols = 1.f / p.tcols; p.inv_trows = 1.f / p.trows;
             }
-            p.kq = nkc / lp.splits; p.krem = nkc % lp.splits;
+            // sub-pixel deconvolution on 16-pixel-wide 2-D tiles: the patch variant of the kernel (K units = whole channel chunks)
+            patch = g_patch && (g_ldsdma || bf16) && !g_timing && g.ostride == 2 && p.tw == 16 && bm <= 128 && lp.splits * lp.kg <= cpt;
+            const int units = patch ? cpt : nkc;
+            p.kq = units / lp.splits; p.krem = units % lp.splits;
         }
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
         dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
-        RY_TRY(Lc.begin(tile_name(lp.tile, lp.kg, bf16), l.name, lp.flops, lp.bytes, grid));
+        RY_TRY(Lc.begin(tile_name(lp.tile, lp.kg, bf16, patch), l.name, lp.flops, lp.bytes, grid));
         p.dbg = g_dbg; p.dbg_flags = g_igemm_dbg; p.zeros = Lc.ctx->zero_page;
 #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
     do {                                                                                                    \
         if (g_ldsdma && !g_timing && BM_ <= 128) {                                                            \
-            if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 2, false>), grid, 512, Lc.stream, p); \
-            else RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 1, false>), grid, 256, Lc.stream, p);          \
+            if (patch && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 2, false, true>), grid, 512, Lc.stream, p); \
+            else if (patch) RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 1, false, true>), grid, 256, Lc.stream, p); \
+            else if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 2, false, false>), grid, 512, Lc.stream, p); \
+            else RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 1, false, false>), grid, 256, Lc.stream, p);          \
         }                                                                                                   \
         else if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
         else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
@@ -663,8 +673,10 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     } while (0)
 #define RY_IGEMM16_LAUNCH(BM_, BN_, WM_, WN_)                                                                  \
     do {                                                                                                    \
-        if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, true>), grid, 512, Lc.stream, p);    \
-        else RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, true>), grid, 256, Lc.stream, p);               \
+        if (patch && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, true, true>), grid, 512, Lc.stream, p); \
+        else if (patch) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, true, true>), grid, 256, Lc.stream, p); \
+        else if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, true, false>), grid, 512, Lc.stream, p);    \
+        else RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, true, false>), grid, 256, Lc.stream, p);               \
     } while (0)
         if (bf16) {
             switch (lp.tile) {
@@ -1079,6 +1091,7 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
     if (const char* e = getenv("RY_LDSDMA")) g_ldsdma = atoi(e);
     if (const char* e = getenv("RY_KGROUPS")) g_kgroups = atoi(e);
+    if (const char* e = getenv("RY_PATCH")) g_patch = atoi(e);
     if (const char* e = getenv("RY_S1_WGS")) g_s1_wgs = atoi(e);
     if (const char* e = getenv("RY_S1_MAXS")) g_s1_maxs = atoi(e);
     if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);

@@ -58,6 +58,12 @@ CONV2D_CASES = [
     (2, 8, 16, 32, 128, 4, 2, 1, True, 'relu', 'igemm', '64x128k2', 1),    # 4 chunks per phase: 2 + 2
     (1, 12, 16, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '32x128k2', 3), # 16 chunks, 3 external splits of 5/5/6 -> groups of 2+3 / 2+3 / 3+3
     (1, 24, 32, 64, 128, 4, 2, 1, False, 'relu', 'igemm', '96x128k1', 2),  # forced single group
+    # sub-pixel deconvolution on 16-pixel-wide 2-D tiles: the input-patch variant (one patch per channel chunk, 4 taps read from it)
+    (1, 12, 16, 128, 128, 4, 2, 1, True, 'relu', 'igemm', '96x128', 1),    # 4 chunks x 4 taps, 2 tiles of 6x16 per phase, image borders on every side
+    (2, 12, 32, 96, 128, 4, 2, 1, True, 'lrelu', 'igemm', '96x128k2', 1),  # 3 chunks: K groups of 1 + 2 chunks, batch 2, 2 tile columns
+    (1, 16, 16, 128, 64, 4, 2, 1, True, 'relu', 'igemm', '128x64', 2),     # 8x16 tiles, external split of 2 + 2 chunks
+    (1, 8, 16, 64, 128, 4, 2, 1, True, None, 'igemm', '64x128', 1),        # 4x16 tiles, 2 chunks
+    (1, 16, 32, 160, 128, 4, 2, 1, True, 'relu', 'igemm', '128x128k2', 1), # 5 chunks: groups of 2 + 3 (odd counts of 8 / 12 iterations)
 ]
 
 
@@ -70,6 +76,8 @@ def bf16_round(a):
 
 # B, H, W, Cin, Cout, k, stride, pad, transposed, act, tile, splits   (bf16-operand implicit GEMM, BASELINE config #5)
 CONV2D_BF16_CASES = [
+    (1, 12, 16, 256, 128, 4, 2, 1, True, 'relu', '96x128', 1),             # deconvolution patch variant in bf16: 4 chunks of 64 channels
+    (1, 16, 16, 128, 64, 4, 2, 1, True, 'relu', '128x64k2', 1),            # 2 chunks, one per K group
     (1, 12, 16, 64, 128, 4, 2, 1, False, 'lrelu', '32x128', 0),
     (2, 16, 16, 64, 128, 4, 2, 1, False, 'lrelu', '128x128', 1),
     (1, 32, 64, 64, 128, 4, 2, 1, False, 'relu', '128x128', 2),        # 2-D tiles, split-K

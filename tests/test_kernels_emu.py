@@ -70,7 +70,7 @@ def test_stage2_bf16_pipeline_emu(emu_ctx):
     net.set_dtype('bf16')
     y16 = net.forward(x)
     names = [q['name'] for q in net.profile(1, 8, 1)]
-    assert any(n.endswith(',true>') for n in names), names           # the bf16 kernels did run
+    assert any(n.startswith('ry_igemm_ldsdma<') and n[:-1].split(',')[5] == 'true' for n in names), names   # the bf16 kernels did run
     assert not numpy.array_equal(y16, y32)
     assert rel_max(y16, ref) < 3e-2
     net.set_dtype('f32')
