@@ -47,14 +47,13 @@ def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/*pmc_summary.txt):
     2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half size, MI355X_MICROARCH.md) + WRITE_SIZE.  None if absent."""
     import glob
-    key = kernel_name.replace(' ', '').rstrip('>')
+    key = kernel_name.replace(' ', '')
     for path in sorted(glob.glob(str(ROOT / 'profiles' / '*pmc_summary.txt')), reverse=True):
         for line in open(path):
             if line.startswith('#') or line.startswith('kernel'):
                 continue
-            name = line[:44].replace('void ', '').replace(' ', '')
-            if name.startswith(key):
-                cols = line[44:].split()
+            cols = line.split()
+            if cols and cols[0] == key:                     # the summary writes kernel names as one token without spaces
                 try:
                     return (2.0 * float(cols[-2]) + float(cols[-1])) * 1024.0, Path(path).name
                 except (ValueError, IndexError):

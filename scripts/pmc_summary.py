@@ -29,9 +29,13 @@ def durations(pmc_dir, p):
 
 
 def short(name):
+    """kernel name as one token: no 'void ', no argument list, no spaces (bench.py looks it up by this token)"""
     name = name.replace('(RyIgemmParams)', '').replace('(RyReduceParams)', '')
     i = name.find('(')
-    return (name if i < 0 else name[:i])
+    name = name if i < 0 else name[:i]
+    if name.startswith('void '):
+        name = name[5:]
+    return name.replace(' ', '')[:63]
 
 
 def main(pmc_dir, out, title):
@@ -44,7 +48,7 @@ def main(pmc_dir, out, title):
         f.write('# %s\n' % title)
         f.write('# GRBM_GUI_ACTIVE is summed over the 8 XCDs (clk = GUI / 8 / duration); FETCH_SIZE/WRITE_SIZE in KB per dispatch, '
                 'FETCH_SIZE reads 1/2 of wide coalesced streams on gfx950 (MI355X_MICROARCH.md)\n')
-        f.write('%-44s %8s %10s %8s %12s %12s %12s %12s %10s %12s %12s\n' % (
+        f.write('%-64s %8s %10s %8s %12s %12s %12s %12s %10s %12s %12s\n' % (
             'kernel', 'calls', 'avg_us', 'clk_GHz', 'mfma_busy%', 'wave_cyc', 'wait_any', 'wait_inst', 'bank_conf', 'fetch_KB', 'write_KB'))
         for n in names:
             c1, c2, c3, c4, c5 = (P[p].get(n, {}) for p in ('p1', 'p2', 'p3', 'p4', 'p5'))
@@ -53,8 +57,8 @@ def main(pmc_dir, out, title):
             clk = gui / 8.0 / (avg * 1e3) if avg else 0.0
             # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs (64 cycles per v_mfma_f32_32x32x2_f32); GUI / 8 = kernel cycles
             mfma = 100.0 * mean(c1.get('SQ_VALU_MFMA_BUSY_CYCLES', [])) / (gui / 8.0 * 1024.0) if gui else 0.0
-            f.write('%-44s %8d %10.1f %8.2f %12.1f %12.3g %12.3g %12.3g %10.3g %12.0f %12.0f\n' % (
-                short(n)[:44], len(dur[n]), avg, clk, mfma, total(c1.get('SQ_WAVE_CYCLES', [])), total(c2.get('SQ_WAIT_ANY', [])),
+            f.write('%-64s %8d %10.1f %8.2f %12.1f %12.3g %12.3g %12.3g %10.3g %12.0f %12.0f\n' % (
+                short(n), len(dur[n]), avg, clk, mfma, total(c1.get('SQ_WAVE_CYCLES', [])), total(c2.get('SQ_WAIT_ANY', [])),
                 total(c2.get('SQ_WAIT_INST_ANY', [])), total(c3.get('SQ_LDS_BANK_CONFLICT', [])),
                 mean(c4.get('FETCH_SIZE', [])), mean(c5.get('WRITE_SIZE', []))))
 
