@@ -355,18 +355,21 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 // ---------------------------------------------------------------------------------------------
 template <int V> struct RyConst { static constexpr int value = V; };
 
-template <int BM, int BN, int WM, int WN, int KG, bool BF16, bool PATCH>
+template <int BM, int BN, int WM, int WN, int KG, bool BF16, int PATCH>
 RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     constexpr int BK = 32, NS = 4;            // LDS rows of 128 bytes: 32 floats or 64 bf16
     constexpr int CK = BF16 ? 64 : 32;        // input channels per K chunk
     constexpr int ES = BF16 ? 8 : 4;          // elements per 16-byte slot
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    // PATCH (sub-pixel deconvolution, 16-pixel-wide 2-D tiles): the four taps of a phase read overlapping pixels, so the
+    // PATCH = 1 (sub-pixel deconvolution, 16-pixel-wide 2-D tiles): the four taps of a phase read overlapping pixels, so the
     // input patch of the tile ((BM / 16 + 1) x 17 pixels) is fetched ONCE per channel chunk and the A fragments of tap
     // (ky, kx) are read from it at a uniform row offset -- 15 instead of 48 A pieces per chunk for a 96-row tile.
+    // PATCH = 2 (k4 s2 p1 convolution): tap (ky, kx) = (2a + r, 2b + c) reads input pixel (2 (oy + a) - 1 + r, 2 (ox + b) - 1 + c),
+    // so for a fixed row / column parity (r, c) the four taps (a, b) are a 2 x 2 stride-1 stencil on that parity plane: the
+    // same patch scheme with one (BM / 16 + 1) x 17 patch per (channel chunk, parity) -- 60 instead of 192 A pieces per chunk.
     constexpr int PW = 17, PR = (BM / 16 + 1) * PW, PG = (PR + 7) / 8;
-    constexpr int AROWS = PATCH ? PG * 8 : BM;   // LDS rows of one A buffer
-    constexpr int AG = PATCH ? PG : BM / 8;      // 1-KiB DMA pieces of the A tile / patch (8 rows each)
+    constexpr int AROWS = PATCH != 0 ? PG * 8 : BM;   // LDS rows of one A buffer
+    constexpr int AG = PATCH != 0 ? PG : BM / 8;      // 1-KiB DMA pieces of the A tile / patch (8 rows each)
     constexpr int BG = BN / 8;                // 1-KiB DMA pieces of the B tile ((32 columns, K step) each)
     constexpr int AI = (AG + 3) / 4, BI = (BG + 3) / 4, NI = AI + BI;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BM % 32 == 0 && BN % 32 == 0 && BM <= 128, "tile shape");
@@ -430,25 +433,30 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     // ---- A: DMA role of this lane = row drow / position dpos inside each 8-row piece this wave fills ----
     const int drow = lane >> 3, dpos = lane & 7;
     int ayb[AI], axb[AI], aoff1[AI], aoff2[AI];
-    if (PATCH) {
-        // patch pixel of this lane in each piece it fills: element offsets into the two sources, or -1 (outside the image,
-        // past the patch, past the batch: fetched from the zero page)
+    if (PATCH != 0) {
+        // patch pixel of this lane in each piece it fills: its input coordinates (ayb / axb; far outside the image for rows
+        // past the patch or the batch) and its element offsets into the two sources; a fetch adds the uniform parity shift
+        // (PATCH = 2) and tests the image borders -- misses are fetched from the zero page
         const int trow = ry_fdiv(mt, p.tcols, p.inv_tcols);
         const int tx = mt - trow * p.tcols;
         const int bimg = ry_fdiv(trow, p.trows, p.inv_trows);
         const int ty = trow - bimg * p.trows;
-        const int oy0 = ty * (BM / 16) + pdy - 1, ox0 = tx * 16 + pdx - 1;   // input pixel of patch (0, 0): taps reach one pixel up / left of the phase
+        // input pixel of patch (0, 0): deconvolution: taps reach one pixel up / left of the phase; convolution: the parity-(1, 1)
+        // pixel 2 * (first output row / column of the tile)
+        const int oy0 = PATCH == 1 ? ty * (BM / 16) + pdy - 1 : 2 * ty * (BM / 16);
+        const int ox0 = PATCH == 1 ? tx * 16 + pdx - 1 : 2 * tx * 16;
+        constexpr int PS = PATCH == 1 ? 1 : 2;       // input pixels per patch pixel step
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
             const int pr = (4 * j + wave) * 8 + drow;
             const int py = ry_fdiv(pr, PW, 1.0f / PW), px = pr - py * PW;
-            const int iy = oy0 + py, ix = ox0 + px;
-            const bool ok = pr < PR && bimg < g.B && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            const int iy = oy0 + PS * py, ix = ox0 + PS * px;
+            const bool ok = pr < PR && bimg < g.B;
             const int ce = (dpos ^ ((pr >> 1) & 7)) * ES;
             const int pix = (bimg * g.Hi + iy) * g.Wi + ix;
-            aoff1[j] = ok ? pix * g.C1 + ce : -1;
-            aoff2[j] = ok ? pix * g.C2 + ce : -1;
-            ayb[j] = 0; axb[j] = 0;
+            ayb[j] = ok ? iy : -(1 << 20); axb[j] = ix;
+            aoff1[j] = ok ? pix * g.C1 + ce : 0;
+            aoff2[j] = ok ? pix * g.C2 + ce : 0;
         }
     } else {
 #pragma unroll
@@ -473,8 +481,8 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     }
 
     const int cpt = Ctot / CK;
-    // K ranges are counted in units of one chunk (PATCH: one channel chunk = its four taps, so that every K group starts at tap 0)
-    constexpr int KU = PATCH ? 4 : 1;
+    // K ranges are counted in units of one chunk (PATCH: one patch = four taps, so that every K group starts at tap 0)
+    constexpr int KU = PATCH != 0 ? 4 : 1;
     const int kc_begin = split * p.kq + (split < p.krem ? split : p.krem);
     const int wg_units = (p.dbg_flags & 8) ? 0 : p.kq + (split < p.krem ? 1 : 0);
     const int g_begin = (kc_begin + (KG > 1 ? (wg_units >> 1) * grp : 0)) * KU;   // this K group's share: the first floor(n / 2) units, the rest
@@ -491,7 +499,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
 
     float* const A0 = As0 + grp * (AROWS * BK); float* const A1 = As1 + grp * (AROWS * BK);
     float* const B0 = Bs0 + grp * (BN * BK); float* const B1 = Bs1 + grp * (BN * BK);
-    if constexpr (!PATCH) {
+    if constexpr (PATCH == 0) {
         int tap = ry_fdiv(g_begin, cpt, p.inv_cpt);
         int cib = g_begin - tap * cpt;
         int ky = ry_fdiv(tap, g.kw, p.inv_kw), kx = tap - ky * g.kw;
@@ -587,28 +595,39 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
 
     } else
     {
-        // ---------------- PATCH main loop: iteration k = (channel chunk k / 4, tap k % 4) ----------------
-        const int chunk0 = g_begin >> 2;              // K groups start at tap 0 (K units are whole chunks)
-        int pch = chunk0;                             // next channel chunk whose patch is fetched
+        // ---------------- PATCH main loop: iteration k = (patch k / 4, tap k % 4 of that patch) ----------------
+        // a patch is a channel chunk (deconvolution) or a (channel chunk, input parity) pair (convolution)
+        const int patch0 = g_begin >> 2;              // K groups start at tap 0 of a patch
+        int pch = patch0;                             // next patch to fetch
         int bit = 0;                                  // next iteration whose filters are fetched
-        const float* c_src = nullptr; bool c_first = true; int c_cil = 0; unsigned c_bdelta = 0;
+        const float* c_src = nullptr; bool c_first = true; int c_cil = 0, c_py = 0, c_px = 0, c_pdelta = 0; unsigned c_bdelta = 0;
         auto next_patch = [&]() {
-            const int ci0 = pch * CK;
+            const int chunk = PATCH == 2 ? pch >> 2 : pch;
+            const int ci0 = chunk * CK;
             c_first = ci0 < g.C1;
             c_src = c_first ? g.src1 : g.src2;
             c_cil = c_first ? ci0 : ci0 - g.C1;
+            if (PATCH == 2) {                         // parity (r, c) = ((pch >> 1) & 1, pch & 1): pixel = parity-(1, 1) pixel - (1 - r, 1 - c)
+                c_py = ((pch >> 1) & 1) - 1; c_px = (pch & 1) - 1;
+                c_pdelta = (c_py * g.Wi + c_px) * (c_first ? g.C1 : g.C2);
+            }
             ++pch;
         };
         auto next_b = [&]() {
-            c_bdelta = (unsigned)(((bit & 3) * c32 + chunk0 + (bit >> 2)) * 2048);
+            const int pi = patch0 + (bit >> 2), ti = bit & 3;
+            int tapw, chunk;
+            if (PATCH == 2) { chunk = pi >> 2; tapw = (2 * (ti >> 1) + ((pi >> 1) & 1)) * 4 + 2 * (ti & 1) + (pi & 1); }   // (ky, kx) = (2a + r, 2b + c)
+            else { chunk = pi; tapw = ti; }
+            c_bdelta = (unsigned)((tapw * c32 + chunk) * 2048);
             ++bit;
         };
         auto patch_item = [&](int j, float* Ad) {
             const int gi = 4 * j + wave;
             if (AG % 4 == 0 || gi < AG) {
-                const int off = c_first ? aoff1[j] : aoff2[j];
-                const unsigned eo = (unsigned)(off + c_cil);
-                const float* gp = off < 0 ? p.zeros : BF16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(c_src) + eo) : c_src + eo;
+                const int iy = ayb[j] + c_py, ix = axb[j] + c_px;
+                const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                const unsigned eo = (unsigned)((c_first ? aoff1[j] : aoff2[j]) + c_pdelta + c_cil);
+                const float* gp = !ok ? p.zeros : BF16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(c_src) + eo) : c_src + eo;
                 ry_glds16(gp, Ad + gi * 256);
             }
         };
@@ -631,7 +650,8 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
         auto run_it = [&](auto k8c, int k) {
             constexpr int K8 = decltype(k8c)::value;
             constexpr int TAP = K8 & 3, ABUF = (K8 >> 2) & 1, BBUF = K8 & 1;
-            constexpr int TAPOFF = (1 - (TAP >> 1)) * PW + (1 - (TAP & 1));       // (dy - dymin) * PW + (dx - dxmin), dy = pdy - ky
+            // patch row offset of the tap: deconvolution (dy - dymin, dx - dxmin) with dy = pdy - ky; convolution (a, b)
+            constexpr int TAPOFF = PATCH == 1 ? (1 - (TAP >> 1)) * PW + (1 - (TAP & 1)) : (TAP >> 1) * PW + (TAP & 1);
             const float* Ac = ABUF ? A1 : A0;
             const float* Bc = BBUF ? B1 : B0;
             float* An = ABUF ? A0 : A1;

@@ -342,6 +342,7 @@ struct LayerPlan {
     float* raw = nullptr;                     // [splits][B*Lo][N] raw sums
     // stage-2
     int path = 0, tile = 0;
+    bool any_m_patch = false;                 // op-level calls (tests): take the input-patch variants whatever the row count
     int kg = 1;                               // K groups inside a workgroup (LDS-DMA implicit GEMM): 2 = split-K summed through the LDS
     float* out = nullptr;                     // NHWC activation, fp32
     unsigned short* out16 = nullptr;          // NHWC activation, bf16 copy for consumers on the bf16 path (bf16 mode only)
@@ -480,7 +481,7 @@ static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in o
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
 static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
 static int g_igemm_dbg = 0; // RY_IGEMM_DBG: ablation bits of ry_igemm_ldsdma (diagnostics; wrong results)
-static int g_patch = 1;     // RY_PATCH=0: deconvolution layers gather every tap's A tile separately (no input-patch reuse)
+static int g_patch = 3;     // RY_PATCH: bit 0 = input-patch reuse in the deconvolution layers, bit 1 = in the k4 s2 convolution layers (0: every tap gathers its own A tile)
 static int g_kgroups = 1;   // RY_KGROUPS=0: never split K inside a workgroup (external split-K + reduce kernel only)
 static int g_ldsdma = 1;    // RY_LDSDMA=0: register-staged ry_igemm_f32 instead of the LDS-DMA kernel (A/B; ~5 % slower end to end)
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
@@ -488,17 +489,17 @@ static unsigned long long* g_dbg = nullptr;
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
 // Kernel names as rocprofv3 prints them (template arguments, no spaces): bench.py matches them against profiles/*.
-static const char* tile_name(int tile, int kg, bool bf16, bool patch) {
+static const char* tile_name(int tile, int kg, bool bf16, int patch) {
     const bool dma = (g_ldsdma && !g_timing) || bf16;
     if (dma && tile != TILE_256x64 && tile != TILE_256x128) {
         static std::map<int, std::string> names;        // stable storage for the returned pointers
-        const int key = ((tile * 4 + kg) * 2 + (bf16 ? 1 : 0)) * 2 + (patch ? 1 : 0);
+        const int key = ((tile * 4 + kg) * 2 + (bf16 ? 1 : 0)) * 4 + patch;
         auto it = names.find(key);
         if (it == names.end()) {
             int bm, bn; tile_dims(tile, &bm, &bn);
             const int wmv = (tile == TILE_128x128) ? 2 : (tile == TILE_128x64 ? 4 : 1), wnv = 4 / wmv;
             char buf[96];
-            snprintf(buf, sizeof buf, "ry_igemm_ldsdma<%d,%d,%d,%d,%d,%s,%s>", bm, bn, wmv, wnv, kg == 2 ? 2 : 1, bf16 ? "true" : "false", patch ? "true" : "false");
+            snprintf(buf, sizeof buf, "ry_igemm_ldsdma<%d,%d,%d,%d,%d,%s,%d>", bm, bn, wmv, wnv, kg == 2 ? 2 : 1, bf16 ? "true" : "false", patch);
             it = names.emplace(key, buf).first;
         }
         return it->second.c_str();
@@ -637,7 +638,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
                 if (bm % tw == 0 && g.Mw % tw == 0 && g.Mh % (bm / tw) == 0) { p.tw = tw; break; }
             }
         }
-        bool patch = false;
+        int patch = 0;
         {   // prologue helpers of the LDS-DMA kernel (ry_fdiv reciprocals; operands stay below 2^24, checked here)
             const int ck = bf16 ? 64 : 32, cpt = (C1 + C2) / ck, nkc = g.ntaps * cpt;
             if ((long long)p.mtiles * p.ntiles * g.nphases * lp.splits >= (1 << 24) || M >= (1 << 24))
@@ -651,8 +652,12 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
                 p.inv_tcols = 1.f / p.tcols; p.inv_trows = 1.f / p.trows;
             }
             // sub-pixel deconvolution on 16-pixel-wide 2-D tiles: the patch variant of the kernel (K units = whole channel chunks)
-            patch = g_patch && (g_ldsdma || bf16) && !g_timing && g.ostride == 2 && p.tw == 16 && bm <= 128 && lp.splits * lp.kg <= cpt;
-            const int units = patch ? cpt : nkc;
+            // 1: sub-pixel deconvolution, one patch per channel chunk; 2: k4 s2 p1 convolution, one patch per (chunk, input parity)
+            if (g_patch && (g_ldsdma || bf16) && !g_timing && p.tw == 16 && bm <= 128 && (M >= 512 || lp.any_m_patch)) {   // small layers: the longer set-up costs more than the reuse saves (measured at M = 192)
+                if (g.ostride == 2 && (g_patch & 1) && lp.splits * lp.kg <= cpt) patch = 1;
+                else if (!l.deconv && l.k == 4 && l.stride == 2 && l.pad == 1 && l.dil == 1 && (g_patch & 2) && lp.splits * lp.kg <= 4 * cpt) patch = 2;
+            }
+            const int units = patch == 1 ? cpt : patch == 2 ? 4 * cpt : nkc;
             p.kq = units / lp.splits; p.krem = units % lp.splits;
         }
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
@@ -662,10 +667,13 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
 #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
     do {                                                                                                    \
         if (g_ldsdma && !g_timing && BM_ <= 128) {                                                            \
-            if (patch && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 2, false, true>), grid, 512, Lc.stream, p); \
-            else if (patch) RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 1, false, true>), grid, 256, Lc.stream, p); \
-            else if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 2, false, false>), grid, 512, Lc.stream, p); \
-            else RY_LAUNCH((ry_igemm_ldsdma<(BM_ <= 128 ? BM_ : 128), BN_, WM_, WN_, 1, false, false>), grid, 256, Lc.stream, p);          \
+            constexpr int BMc = BM_ <= 128 ? BM_ : 128;                                                        \
+            if (patch == 1 && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 2, false, 1>), grid, 512, Lc.stream, p); \
+            else if (patch == 1) RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 1, false, 1>), grid, 256, Lc.stream, p);          \
+            else if (patch == 2 && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 2, false, 2>), grid, 512, Lc.stream, p); \
+            else if (patch == 2) RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 1, false, 2>), grid, 256, Lc.stream, p);          \
+            else if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 2, false, 0>), grid, 512, Lc.stream, p);          \
+            else RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 1, false, 0>), grid, 256, Lc.stream, p);                          \
         }                                                                                                   \
         else if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
         else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
@@ -673,10 +681,12 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     } while (0)
 #define RY_IGEMM16_LAUNCH(BM_, BN_, WM_, WN_)                                                                  \
     do {                                                                                                    \
-        if (patch && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, true, true>), grid, 512, Lc.stream, p); \
-        else if (patch) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, true, true>), grid, 256, Lc.stream, p); \
-        else if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, true, false>), grid, 512, Lc.stream, p);    \
-        else RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, true, false>), grid, 256, Lc.stream, p);               \
+        if (patch == 1 && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, true, 1>), grid, 512, Lc.stream, p); \
+        else if (patch == 1) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, true, 1>), grid, 256, Lc.stream, p);          \
+        else if (patch == 2 && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, true, 2>), grid, 512, Lc.stream, p); \
+        else if (patch == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, true, 2>), grid, 256, Lc.stream, p);          \
+        else if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, true, 0>), grid, 512, Lc.stream, p);          \
+        else RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, true, 0>), grid, 256, Lc.stream, p);                          \
     } while (0)
         if (bf16) {
             switch (lp.tile) {
@@ -1568,6 +1578,7 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
         const TapTable t = make_taps(l);
         const int M = B * (transposed ? H * Wd : lp.Ho * lp.Wo);
         lp.kg = (tile & 16) ? 2 : ((tile & 32) ? 1 : 0);                    // +16: two K groups per workgroup, +32: one, else automatic
+        lp.any_m_patch = true;
         tile &= 15;
         lp.tile = tile; lp.splits = splits;
         if (tile < 0 || tile > TILE_256x128) return fail(RY_EINVAL, "unknown tile");

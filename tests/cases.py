@@ -64,6 +64,11 @@ CONV2D_CASES = [
     (1, 16, 16, 128, 64, 4, 2, 1, True, 'relu', 'igemm', '128x64', 2),     # 8x16 tiles, external split of 2 + 2 chunks
     (1, 8, 16, 64, 128, 4, 2, 1, True, None, 'igemm', '64x128', 1),        # 4x16 tiles, 2 chunks
     (1, 16, 32, 160, 128, 4, 2, 1, True, 'relu', 'igemm', '128x128k2', 1), # 5 chunks: groups of 2 + 3 (odd counts of 8 / 12 iterations)
+    # k4 s2 convolution on 16-pixel-wide 2-D tiles: one patch per (channel chunk, input parity), image borders on every side
+    (1, 32, 32, 64, 64, 4, 2, 1, False, 'relu', 'igemm', '128x64', 1),     # 16x16 outputs = 2 tiles of 8x16; 2 chunks x 4 parities
+    (2, 16, 32, 96, 128, 4, 2, 1, False, 'lrelu', 'igemm', '64x128k2', 1), # batch 2, 12 patches: K groups of 6 + 6
+    (1, 24, 64, 32, 128, 4, 2, 1, False, None, 'igemm', '96x128', 3),      # 2 tile columns, 4 patches over 3 external splits (2 + 1 + 1)
+    (1, 32, 32, 160, 128, 4, 2, 1, False, 'relu', 'igemm', '128x128k2', 1),# 20 patches: groups of 10 + 10
 ]
 
 
@@ -76,6 +81,7 @@ def bf16_round(a):
 
 # B, H, W, Cin, Cout, k, stride, pad, transposed, act, tile, splits   (bf16-operand implicit GEMM, BASELINE config #5)
 CONV2D_BF16_CASES = [
+    (1, 24, 32, 128, 128, 4, 2, 1, False, 'lrelu', '96x128', 1),           # k4 s2 convolution patch variant in bf16: 2 chunks x 4 parities
     (1, 12, 16, 256, 128, 4, 2, 1, True, 'relu', '96x128', 1),             # deconvolution patch variant in bf16: 4 chunks of 64 channels
     (1, 16, 16, 128, 64, 4, 2, 1, True, 'relu', '128x64k2', 1),            # 2 chunks, one per K group
     (1, 12, 16, 64, 128, 4, 2, 1, False, 'lrelu', '32x128', 0),
