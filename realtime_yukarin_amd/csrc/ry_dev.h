@@ -38,6 +38,13 @@ RY_DEV void ry_glds16(const float* gsrc_lane, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// The same with a wave-uniform base and a 32-bit byte offset per lane: lets the compiler use the scalar-base addressing mode
+// (one address VGPR per lane instead of a 64-bit pair, no 64-bit add per piece).
+RY_DEV void ry_glds16_off(const float* base_uniform, unsigned byte_off_lane, float* lds_wave_base) {
+    const char* q = reinterpret_cast<const char*>(base_uniform) + byte_off_lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 RY_DEV int ry_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // Lanes of one wave exchange data through the LDS: LDS instructions of a wave execute in order, so no hardware barrier is
 // needed -- only the compiler must not move the reads above the writes.

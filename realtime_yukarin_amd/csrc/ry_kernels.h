@@ -59,6 +59,8 @@ struct RyConvGeom {
     int nphases, ntaps;
     int kw;                     // taps per kernel row (conv: k, sub-pixel deconv: 2); taps are row-major
     int N;                      // output channels
+    unsigned zoff1, zoff2;      // LDS-DMA kernel: byte offset of >= 16 zero bytes behind each source (the buffers carry a zeroed tail): padded
+                                // rows are fetched from there, so every lane of a piece shares ONE scalar base (scalar-base addressing mode)
     signed char tdy[4][16], tdx[4][16];
     signed char pdy[4], pdx[4];
 };
@@ -83,7 +85,6 @@ struct RyIgemmParams {
                                 //      overlapping taps hit L2); 0: BM consecutive rows in raster order
     unsigned long long* dbg;    // VAR bit 1 (diagnostic build of the kernel): per-phase shader-clock totals, else unused
     int dbg_flags;              // diagnostics of ry_igemm_ldsdma (wrong results): 4 skip the output stores, 8 skip the K loop, 128 skip the loads in the K loop
-    const float* zeros;         // >= 16 bytes of zeros in device memory (source of padded rows for the direct-to-LDS kernel)
 };
 
 // VAR bit 1 (RY_TIMING=1, diagnostics only): every wave accumulates s_memtime deltas per loop phase into p.dbg.
@@ -341,7 +342,9 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 //   A (gathered pixels x channels): LDS rows of 32 floats, unpadded (the DMA destination is lane-linear); the 16-byte slot
 //     c of row r is stored at position c ^ ((r >> 1) & 7), which makes the ds_read_b128 fragment reads conflict-free
 //     (bank = (addr / 4) mod 64 inside the instruction's 16-lane groups).  The swizzle is applied on the SOURCE side: the
-//     lane that fills position q of row r fetches slot q ^ f(r).  Padding is fetched from a zero page.
+//     lane that fills position q of row r fetches slot q ^ f(r).  Padding is fetched from the zeroed tail behind the source buffer
+//     (RyConvGeom::zoff1 / zoff2), so all lanes of a piece share ONE scalar base: global_load_lds ... v_off, s[base:base+1]
+//     reads one address VGPR per lane instead of a 64-bit pair and needs no 64-bit add (stage 2 1.34 -> 1.305 ms).
 //   B (filters) is stored in fragment order by the host (ry_net.cpp: wig_inblock), one 1-KiB piece per (32 columns, K step):
 //     the pieces are DMA-copied into the LDS as they are and read back lane-linearly (conflict-free, no swizzle).
 //     (Loading them global -> registers in the 1 x 4 wave layouts, bypassing the LDS, measured 2 % slower: DESIGN.md 4.1.)
@@ -436,7 +439,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     if (PATCH != 0) {
         // patch pixel of this lane in each piece it fills: its input coordinates (ayb / axb; far outside the image for rows
         // past the patch or the batch) and its element offsets into the two sources; a fetch adds the uniform parity shift
-        // (PATCH = 2) and tests the image borders -- misses are fetched from the zero page
+        // (PATCH = 2) and tests the image borders -- misses are fetched from the zeroed tail of the source
         const int trow = ry_fdiv(mt, p.tcols, p.inv_tcols);
         const int tx = mt - trow * p.tcols;
         const int bimg = ry_fdiv(trow, p.trows, p.inv_trows);
@@ -524,12 +527,11 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
                     const int iy = ayb[j] + c_dy, ix = axb[j] + c_dx;
                     const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
                     const unsigned eo = (unsigned)((c_first ? aoff1[j] : aoff2[j]) + c_delta);     // elements (fp32 or bf16)
-                    const float* gp = !ok ? p.zeros : BF16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(c_src) + eo) : c_src + eo;
-                    ry_glds16(gp, Ad + gi * 256);
+                    ry_glds16_off(c_src, ok ? eo * (BF16 ? 2u : 4u) : (c_first ? g.zoff1 : g.zoff2), Ad + gi * 256);
                 }
             } else {
                 const int j = q - AI, gi = 4 * j + wave;
-                if (BG % 4 == 0 || gi < BG) ry_glds16(p.wt + (boff[j] + c_bdelta), Bd + gi * 256);
+                if (BG % 4 == 0 || gi < BG) ry_glds16_off(p.wt, (boff[j] + c_bdelta) * 4u, Bd + gi * 256);
             }
         };
 
@@ -627,13 +629,12 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
                 const int iy = ayb[j] + c_py, ix = axb[j] + c_px;
                 const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
                 const unsigned eo = (unsigned)((c_first ? aoff1[j] : aoff2[j]) + c_pdelta + c_cil);
-                const float* gp = !ok ? p.zeros : BF16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(c_src) + eo) : c_src + eo;
-                ry_glds16(gp, Ad + gi * 256);
+                ry_glds16_off(c_src, ok ? eo * (BF16 ? 2u : 4u) : (c_first ? g.zoff1 : g.zoff2), Ad + gi * 256);
             }
         };
         auto b_item = [&](int j, float* Bd) {
             const int gi = 4 * j + wave;
-            if (BG % 4 == 0 || gi < BG) ry_glds16(p.wt + (boff[j] + c_bdelta), Bd + gi * 256);
+            if (BG % 4 == 0 || gi < BG) ry_glds16_off(p.wt, (boff[j] + c_bdelta) * 4u, Bd + gi * 256);
         };
         int pbase[TM];                                // patch row of this lane's fragment rows for the tap at offset (0, 0)
 #pragma unroll

@@ -108,7 +108,6 @@ struct ry_ctx {
     rt::Event t0, t1;
     bool timers = false;
     std::vector<void*> owned;            // context-lifetime device allocations
-    float* zero_page = nullptr;          // 256 bytes of zeros: source of padded rows for the LDS-DMA implicit GEMM
 
     int alloc(float** p, size_t nfloats) {
         void* q = nullptr;
@@ -450,6 +449,16 @@ struct Launcher {
     }
 };
 
+// Activation buffers that an implicit-GEMM layer may read end in ZTAIL zeroed floats: the LDS-DMA kernel fetches its padding
+// from there (RyConvGeom::zoff1 / zoff2); nothing ever writes them.
+static const size_t ZTAIL = 64;
+static int alloc_ztail(ry_ctx* ctx, Arena& arena, float** p, size_t nfloats) {
+    RY_TRY(arena.alloc(p, nfloats + ZTAIL));
+    RT_TRY(rt::dmemset(*p + nfloats, 0, ZTAIL * sizeof(float), ctx->stream));
+    RT_TRY(rt::stream_sync(ctx->stream));
+    return RY_OK;
+}
+
 static void fill_geom(RyConvGeom& g, const Layer& l, const LayerPlan& lp, int B, const float* s1, int C1, const float* s2, int C2) {
     memset(&g, 0, sizeof g);
     const TapTable t = make_taps(l);
@@ -458,6 +467,8 @@ static void fill_geom(RyConvGeom& g, const Layer& l, const LayerPlan& lp, int B,
     if (l.deconv) { g.Mh = lp.Hi; g.Mw = lp.Wi; g.stride = 1; g.pad = 0; g.ostride = 2; }
     else { g.Mh = lp.Ho; g.Mw = lp.Wo; g.stride = l.stride; g.pad = l.pad; g.ostride = 1; }
     g.nphases = t.nphases; g.ntaps = t.ntaps; g.N = l.cout; g.kw = l.deconv ? 2 : l.k;
+    const size_t esize = lp.path == PATH_IGEMM_BF16 ? 2 : 4;                  // implicit-GEMM sources end in a zeroed tail (ZTAIL floats)
+    g.zoff1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C1 * esize); g.zoff2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C2 * esize);
     for (int ph = 0; ph < 4; ++ph) {
         g.pdy[ph] = (signed char)t.pdy[ph]; g.pdx[ph] = (signed char)t.pdx[ph];
         for (int tt = 0; tt < 16; ++tt) { g.tdy[ph][tt] = (signed char)t.dy[ph][tt]; g.tdx[ph][tt] = (signed char)t.dx[ph][tt]; }
@@ -663,7 +674,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
         dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
         RY_TRY(Lc.begin(tile_name(lp.tile, lp.kg, bf16, patch), l.name, lp.flops, lp.bytes, grid));
-        p.dbg = g_dbg; p.dbg_flags = g_igemm_dbg; p.zeros = Lc.ctx->zero_page;
+        p.dbg = g_dbg; p.dbg_flags = g_igemm_dbg;
 #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
     do {                                                                                                    \
         if (g_ldsdma && !g_timing && BM_ <= 128) {                                                            \
@@ -850,6 +861,8 @@ static int build_plan(ry_net* net, Plan& P) {
         lp.bytes = 4.0 * ((double)l.cin() * l.cout * taps + in_area * l.cin() + out_area * l.cout);
         if ((double)out_area * l.cout >= 2.0e9 || in_area * l.cin() >= 2.0e9)
             return fail(RY_EINVAL, "%s: activation exceeds 2^31 elements; lower the batch", l.name);
+        if (nd == 2 && ((double)out_area * l.cout >= 1.0e9 || in_area * l.cin() >= 1.0e9))
+            return fail(RY_EINVAL, "%s: activation exceeds 4 GB (32-bit byte offsets of the implicit GEMM); lower the batch", l.name);
     }
     // buffers
     for (int i = 0; i < 16; ++i) {
@@ -862,7 +875,7 @@ static int build_plan(ry_net* net, Plan& P) {
             lp.slab_stride = (long long)out_elems;
             RY_TRY(P.arena.alloc(&lp.raw, out_elems * lp.splits));
         } else {
-            RY_TRY(P.arena.alloc(&lp.out, out_elems));
+            RY_TRY(alloc_ztail(net->ctx, P.arena, &lp.out, out_elems));
             if (l.wig) {
                 const TapTable t = make_taps(l);
                 const int M = B * (l.deconv ? lp.Hi * lp.Wi : lp.Ho * lp.Wo);
@@ -912,7 +925,7 @@ static int build_plan(ry_net* net, Plan& P) {
             lp.w32 = need32[i] || lp.path == PATH_DIRECT || lp.path == PATH_LAST; lp.w16 = need16[i];
             if (lp.w16) {
                 float* q = nullptr;
-                RY_TRY(P.arena.alloc(&q, ((size_t)B * lp.Ho * lp.Wo * net->layers[i].cout + 1) / 2));
+                RY_TRY(alloc_ztail(net->ctx, P.arena, &q, ((size_t)B * lp.Ho * lp.Wo * net->layers[i].cout + 1) / 2));
                 lp.out16 = reinterpret_cast<unsigned short*>(q);
             }
         }
@@ -1130,10 +1143,6 @@ int ry_init(int device, ry_ctx** out) {
     RT_TRY(rt::event_create(&c->t0));
     RT_TRY(rt::event_create(&c->t1));
     c->timers = true;
-    RY_TRY(c->alloc(&c->zero_page, 64));
-    c->owned.push_back(c->zero_page);
-    RT_TRY(rt::dmemset(c->zero_page, 0, 64 * sizeof(float), c->stream));
-    RT_TRY(rt::stream_sync(c->stream));
     RY_TRY(read_env_switches());
     *out = c.release();
     return RY_OK;
@@ -1604,7 +1613,7 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
         if (lp.splits > 1) RY_TRY(arena.alloc(&lp.slabs, out_elems * lp.splits));
     }
     float* dx = nullptr;
-    RY_TRY(arena.alloc(&dx, (size_t)B * H * Wd * Cin));
+    RY_TRY(alloc_ztail(ctx, arena, &dx, (size_t)B * H * Wd * Cin));
     RY_TRY(arena.alloc(&lp.out, out_elems));
     Launcher Lc{nullptr, ctx, ctx->stream, nullptr, nullptr};
     if (lp.path == PATH_LAST) {
@@ -1627,6 +1636,7 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
         const size_t nx = (size_t)B * H * Wd * Cin;
         std::vector<unsigned short> x16(nx);
         for (size_t q = 0; q < nx; ++q) x16[q] = host_f2bf(x[q]);
+        RT_TRY(rt::dmemset(dx, 0, (nx + ZTAIL) * sizeof(float), ctx->stream));      // the bf16 data ends half way: zero tail right behind it
         RT_TRY(rt::h2d(dx, x16.data(), nx * sizeof(unsigned short), ctx->stream));
         RT_TRY(rt::stream_sync(ctx->stream));
         RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Cin, nullptr, 0, 0.2f));

@@ -52,6 +52,9 @@ RY_DEV unsigned short ry_f2bf(float f) { return ry_emu::f2bf(f); }
 RY_DEV void ry_glds16(const float* gsrc_lane, float* lds_wave_base) {          // emulated global_load_lds_dwordx4
     memcpy(lds_wave_base + 4 * (threadIdx.x & 63u), gsrc_lane, 16);
 }
+RY_DEV void ry_glds16_off(const float* base_uniform, unsigned byte_off_lane, float* lds_wave_base) {
+    ry_glds16(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base_uniform) + byte_off_lane), lds_wave_base);
+}
 RY_DEV int ry_uniform(int v) { return v; }
 RY_DEV void ry_wave_sync() { ry_emu::wave_sync(); }
 RY_DEV float ry_shfl_xor(float v, int mask) { return ry_emu::shfl_xor(v, mask); }
