@@ -216,7 +216,10 @@ def main():
         for s in st2 + st1:
             f = fam.setdefault(s['name'], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             f['ms'] += s['ms']; f['flops'] += s['flops']; f['bytes'] += s['bytes']; f['launches'] += 1
-        dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
+        # dominant kernel = the family with the most time in the stage that bounds the step (stage 2; stage 1 overlaps on its own
+        # stream and has its own HBM roofline object below)
+        st2_names = set(s['name'] for s in st2)
+        dom = max(((k, v) for k, v in fam.items() if k in st2_names), key=lambda kv: kv[1]['ms'])
         dname, dv = dom
         ach = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(dname)
