@@ -403,6 +403,43 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     const bool subpix = g.ostride == 2;
     const int pdy = subpix ? (phase >> 1) : 0, pdx = subpix ? (phase & 1) : 0;
 
+    const int lane = tid & 63, wave = ry_uniform((tid >> 6) & 3);
+    const int grp = KG > 1 ? ry_uniform(tid >> 8) : 0;      // K group of this wave: the groups split the K range of the workgroup
+    // ---- B: element offset of this lane's 16 bytes in the (tap 0, chunk 0) block of each (32 columns, K step) piece ----
+    const int c32 = Ctot / CK;                 // K blocks of the filter layout (8 KiB each: 64 x 32 floats or 64 x 64 bf16)
+    unsigned boff[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int gi = 4 * j + wave, gq = gi < BG ? gi : 0;
+        const int n = n0 + (gq >> 2) * 32;
+        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * c32) * 2048 + ((n >> 5) & 1) * 1024 + (gq & 3) * 256 + lane * 4);
+    }
+
+    const int cpt = Ctot / CK;
+    // K ranges are counted in units of one chunk (PATCH: one patch = four taps, so that every K group starts at tap 0)
+    constexpr int KU = PATCH != 0 ? 4 : 1;
+    const int kc_begin = split * p.kq + (split < p.krem ? split : p.krem);
+    const int wg_units = (p.dbg_flags & 8) ? 0 : p.kq + (split < p.krem ? 1 : 0);
+    const int g_begin = (kc_begin + (KG > 1 ? (wg_units >> 1) * grp : 0)) * KU;   // this K group's share: the first floor(n / 2) units, the rest
+    const int nchunks = (KG > 1 ? (grp ? wg_units - (wg_units >> 1) : (wg_units >> 1)) : wg_units) * KU;
+    const int max_chunks = ((wg_units + KG - 1) / KG) * KU;                // barrier count is the same for both groups
+    float* const A0 = As0 + grp * (AROWS * BK); float* const A1 = As1 + grp * (AROWS * BK);
+    float* const B0 = Bs0 + grp * (BN * BK); float* const B1 = Bs1 + grp * (BN * BK);
+    // The filters of the first iteration do not depend on the row tables: request them now (from HBM: the longest latency of
+    // the prologue) and set up the A side while they travel.  PATCH kernels only -- there the A set-up does not read the LDS
+    // row tables, so no barrier (and its vmcnt(0)) sits between this request and the first one of the main loop.
+    if (PATCH != 0 && nchunks > 0) {
+        const int pi = g_begin >> 2;
+        const int chunk = PATCH == 2 ? pi >> 2 : pi;
+        const int tapw = PATCH == 2 ? ((pi >> 1) & 1) * 4 + (pi & 1) : 0;      // tap (a, b) = (0, 0) of the first patch
+        const unsigned bd0 = (unsigned)((tapw * c32 + chunk) * 2048);
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const int gi = 4 * j + wave;
+            if (BG % 4 == 0 || gi < BG) ry_glds16_off(p.wt, (boff[j] + bd0) * 4u, B0 + gi * 256);
+        }
+    }
+
     for (int r = tid; r < BM; r += 256 * KG) {
         const int m = m0 + r;
         int yb = -(1 << 20), xb = 0, pb = 0, ob = -1;
@@ -427,10 +464,8 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
         }
         rY[r] = yb; rX[r] = xb; rP[r] = pb; rO[r] = ob;
     }
-    __syncthreads();
+    if (PATCH == 0) __syncthreads();           // the gather set-up reads the tables; PATCH kernels need rO only in the epilogue
 
-    const int lane = tid & 63, wave = ry_uniform((tid >> 6) & 3);
-    const int grp = KG > 1 ? ry_uniform(tid >> 8) : 0;      // K group of this wave: the groups split the K range of the workgroup
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
     // ---- A: DMA role of this lane = row drow / position dpos inside each 8-row piece this wave fills ----
@@ -473,24 +508,6 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
         aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + ce : 0;
     }
     }
-    // ---- B: element offset of this lane's 16 bytes in the (tap 0, chunk 0) block of each (32 columns, K step) piece ----
-    const int c32 = Ctot / CK;                 // K blocks of the filter layout (8 KiB each: 64 x 32 floats or 64 x 64 bf16)
-    unsigned boff[BI];
-#pragma unroll
-    for (int j = 0; j < BI; ++j) {
-        const int gi = 4 * j + wave, gq = gi < BG ? gi : 0;
-        const int n = n0 + (gq >> 2) * 32;
-        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * c32) * 2048 + ((n >> 5) & 1) * 1024 + (gq & 3) * 256 + lane * 4);
-    }
-
-    const int cpt = Ctot / CK;
-    // K ranges are counted in units of one chunk (PATCH: one patch = four taps, so that every K group starts at tap 0)
-    constexpr int KU = PATCH != 0 ? 4 : 1;
-    const int kc_begin = split * p.kq + (split < p.krem ? split : p.krem);
-    const int wg_units = (p.dbg_flags & 8) ? 0 : p.kq + (split < p.krem ? 1 : 0);
-    const int g_begin = (kc_begin + (KG > 1 ? (wg_units >> 1) * grp : 0)) * KU;   // this K group's share: the first floor(n / 2) units, the rest
-    const int nchunks = (KG > 1 ? (grp ? wg_units - (wg_units >> 1) : (wg_units >> 1)) : wg_units) * KU;
-    const int max_chunks = ((wg_units + KG - 1) / KG) * KU;                // barrier count is the same for both groups
     const int sw = (lr >> 1) & 7;                // swizzle key of every A fragment row this lane reads (tile rows are multiples of 32)
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -500,8 +517,6 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float* const A0 = As0 + grp * (AROWS * BK); float* const A1 = As1 + grp * (AROWS * BK);
-    float* const B0 = Bs0 + grp * (BN * BK); float* const B1 = Bs1 + grp * (BN * BK);
     if constexpr (PATCH == 0) {
         int tap = ry_fdiv(g_begin, cpt, p.inv_cpt);
         int cib = g_begin - tap * cpt;
@@ -643,9 +658,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
             next_patch();
 #pragma unroll
             for (int j = 0; j < AI; ++j) patch_item(j, A0);
-            next_b();
-#pragma unroll
-            for (int j = 0; j < BI; ++j) b_item(j, B0);
+            next_b();                                 // its pieces were requested at the top of the kernel
         }
         __syncthreads();
         auto run_it = [&](auto k8c, int k) {

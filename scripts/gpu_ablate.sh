@@ -1,7 +1,7 @@
 #!/bin/bash
-# ablation of the LDS-DMA kernel (RY_IGEMM_DBG: 4 no output stores, 8 no K loop, 128 no loads in the K loop) -- wrong results, timing only
+# repeated default bench lines (A/B against another build: run the same script on both)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
-B="python bench.py --profile-only --profile-reps 10"
-for i in 1 2; do
-for f in 0 128 132; do echo "dbg $f: $(RY_IGEMM_DBG=$f $B 2>/dev/null | cut -c1-260)"; done
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -2
+for i in 1 2 3 4; do
+echo "bench: $(python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['graph_replay_ms'], d['roofline']['kernel'], d['roofline']['achieved'])")"
 done
