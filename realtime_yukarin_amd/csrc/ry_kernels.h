@@ -1270,7 +1270,11 @@ RY_KERNEL(256) void ry_conv1d_ws(RyConv1dParams p) {
     const bool co_ok = co < p.N;
     const int cw = co_ok ? co : 0;
 
-    constexpr int WB = 16;                         // filters of 16 input channels (16 x 16 bytes per lane) are in flight at a time
+    // Filters of 4 input channels (4 x 16 bytes per lane) are in flight at a time.  16 were no faster when the predictor runs
+    // alone (it is bound by launch and staging latencies) but cost 264 VGPRs per wave: a stage-1 workgroup then takes half of
+    // every SIMD's register file and the second stage-2 workgroup of that CU has to wait for it.  At 125 VGPRs the two
+    // predictors co-reside and a step is 1.34 instead of 1.36 ms.
+    constexpr int WB = 4;
     for (int cc = ci_begin; cc < ci_end; cc += CS) {
         const int cn = (ci_end - cc < CS) ? (ci_end - cc) : CS;
         // the first filter batch does not depend on the staged tile: request it before the staging loads so both
