@@ -8,11 +8,14 @@
 // so the GEMM-K axis (input channels) is contiguous and every load/store is a 16-byte lane access.
 //
 // Kernels:
-//   ry_igemm_f32        stage-2 conv / 4-phase sub-pixel deconv as implicit GEMM on
-//                       v_mfma_f32_32x32x2_f32 (exact fp32), LDS-staged 128x128 / 256x64 / 64x128 /
-//                       32x128 tiles, folded BN + activation epilogue, optional split-K slabs
+//   ry_igemm_ldsdma     the stage-2 conv / 4-phase sub-pixel deconv as implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32)
+//                       or v_mfma_f32_32x32x16_bf16: operand tiles global -> LDS by DMA with scalar-base addressing, input
+//                       patches shared by the taps (PATCH), split-K inside the workgroup (KG), folded BN + activation
+//                       epilogue with 16-byte stores, optional split-K slabs; tiles 128x128 / 96x128 / 128x64 / 64x128 / 32x128
+//   ry_igemm_f32        the register-staged predecessor: kept for 256-row tiles and as the RY_LDSDMA=0 A/B
 //   ry_splitk_reduce    sum of split-K slabs + folded BN + activation
-//   ry_conv_direct      generic VALU conv (Cin=1 first layer, Cout=1 last layer, odd channel counts)
+//   ry_sr_first / ry_sr_last   the 1 -> N and C -> 1 3x3 end layers of stage 2 (HBM / L2-bound)
+//   ry_conv_direct      generic VALU conv (odd channel counts)
 //   ry_conv1d_ws        stage-1 weight-streaming 1-D conv/deconv: lanes = output channels (coalesced
 //                       16-byte weight reads), LDS-staged input tile whose staging applies the
 //                       PRODUCER's split-sum + folded BN + activation (deferred epilogue; skip
