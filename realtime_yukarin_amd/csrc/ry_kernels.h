@@ -83,6 +83,8 @@ struct RyIgemmParams {
     // host-side helpers of the LDS-DMA kernel's prologue (reciprocals for ry_fdiv, the 2-D tile grid, the K split)
     float inv_nphases, inv_ntiles, inv_mtiles, inv_Mimg, inv_Mw, inv_cpt, inv_kw, inv_tcols, inv_trows;
     int tw_shift, th, tcols, trows;   // 2-D M-tiles: tw = 1 << tw_shift columns x th rows, tcols x trows tiles per image
+    int xcd_gs, xcd_gs_shift, xcd_nsg, xcd_mtg;   // LDS-DMA kernel: XCD grouping (gs slice groups of xcd_nsg slices x 8/gs M-tile groups of xcd_mtg tiles); 0 = contiguous runs
+    float inv_xcd_nsg, inv_nsl; // reciprocals of xcd_nsg and of the slice count splits * ntiles * nphases
     int kq, krem;               // K chunks per split: split s takes kq + (s < krem) chunks starting at s * kq + min(s, krem)
     int tw;                     // > 0: an M-tile is a 2-D block of (BM/tw) x tw rows of the Mh x Mw grid (compact input footprint:
                                 //      overlapping taps hit L2); 0: BM consecutive rows in raster order
@@ -388,16 +390,31 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
 
     const RyConvGeom& g = p.g;
     const int tid = (int)threadIdx.x;
+    // Workgroup b runs on XCD b % 8 (one L2 each).  A tile is (M-tile mt, filter slice sl = (split, N-tile, phase)): M-tiles
+    // share filters, slices share input pixels.  The host splits the 8 XCDs into gm x gs groups (xcd_gs = gs) so that the L2
+    // miss traffic gm * (filter bytes) + gs * (input bytes) is smallest: XCD (xm, xs) owns M-tile block xm and slice block xs.
     const int total_tiles = p.splits * p.mtiles * p.ntiles * p.g.nphases;
-    const int per_xcd = (total_tiles + 7) >> 3;
-    int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (lid >= total_tiles) return;
-    int q_ = ry_fdiv(lid, p.g.nphases, p.inv_nphases);
-    const int phase = lid - q_ * p.g.nphases; lid = q_;
-    q_ = ry_fdiv(lid, p.ntiles, p.inv_ntiles);
-    const int nt = lid - q_ * p.ntiles; lid = q_;
-    const int split = ry_fdiv(lid, p.mtiles, p.inv_mtiles);
-    const int mt = lid - split * p.mtiles;
+    int mt, sl;
+    if (p.xcd_gs > 0) {
+        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        const int xm = xcd >> p.xcd_gs_shift, xs = xcd & (p.xcd_gs - 1);
+        const int mtl = ry_fdiv(j, p.xcd_nsg, p.inv_xcd_nsg);
+        if (mtl >= p.xcd_mtg) return;
+        mt = xm * p.xcd_mtg + mtl;
+        sl = xs * p.xcd_nsg + (j - mtl * p.xcd_nsg);
+    } else {                                               // no even split: contiguous runs of (mt, slice) pairs per XCD
+        const int per_xcd = (total_tiles + 7) >> 3;
+        const int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+        if (lid >= total_tiles) return;
+        const int nsl = p.splits * p.ntiles * p.g.nphases;
+        const int q0 = ry_fdiv(lid, nsl, p.inv_nsl);
+        const int msl = lid - q0 * nsl;                     // (mt, slice) with the slice fastest ...
+        sl = msl; mt = q0;                                  // ... = the old order for split-free launches
+    }
+    int q_ = ry_fdiv(sl, p.g.nphases, p.inv_nphases);
+    const int phase = sl - q_ * p.g.nphases; sl = q_;
+    const int split = ry_fdiv(sl, p.ntiles, p.inv_ntiles);
+    const int nt = sl - split * p.ntiles;
     const int m0 = mt * BM;
     const int n0 = nt * BN;
     const int Ctot = g.C1 + g.C2;

@@ -492,6 +492,7 @@ static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in o
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
 static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
 static int g_igemm_dbg = 0; // RY_IGEMM_DBG: ablation bits of ry_igemm_ldsdma (diagnostics; wrong results)
+static int g_xcd_groups = 1;   // RY_XCD_GROUPS=0: contiguous runs of tiles per XCD instead of the M-tile x filter-slice grouping
 static int g_patch = 3;     // RY_PATCH: bit 0 = input-patch reuse in the deconvolution layers, bit 1 = in the k4 s2 convolution layers (0: every tap gathers its own A tile)
 static int g_kgroups = 1;   // RY_KGROUPS=0: never split K inside a workgroup (external split-K + reduce kernel only)
 static int g_ldsdma = 1;    // RY_LDSDMA=0: register-staged ry_igemm_f32 instead of the LDS-DMA kernel (A/B; ~5 % slower end to end)
@@ -655,6 +656,22 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             if ((long long)p.mtiles * p.ntiles * g.nphases * lp.splits >= (1 << 24) || M >= (1 << 24))
                 return fail(RY_EINVAL, "%s: more than 2^24 output rows or tiles in one launch; lower the batch", l.name);
             p.inv_nphases = 1.f / g.nphases; p.inv_ntiles = 1.f / p.ntiles; p.inv_mtiles = 1.f / p.mtiles;
+            // XCD grouping: gm M-tile groups x gs slice groups (gm * gs = 8 L2s); every filter byte is fetched by gm L2s, every
+            // input byte by gs -- pick the split with the least L2 miss traffic among those that divide evenly
+            const int nsl = lp.splits * p.ntiles * g.nphases;
+            p.inv_nsl = 1.f / nsl;
+            p.xcd_gs = 0; p.xcd_gs_shift = 0; p.xcd_nsg = 1; p.xcd_mtg = 1; p.inv_xcd_nsg = 1.f;
+            if (g_xcd_groups) {
+                const double wbytes = (double)g.nphases * l.cout * g.ntaps * (C1 + C2), abytes = (double)B * lp.Hi * lp.Wi * (C1 + C2);
+                double best = 1e300;
+                for (int sh = 0; sh <= 3; ++sh) {
+                    const int gs = 1 << sh, gm = 8 >> sh;
+                    if (nsl % gs != 0 || p.mtiles % gm != 0) continue;
+                    const double cost = gm * wbytes + gs * abytes;
+                    if (cost < best) { best = cost; p.xcd_gs = gs; p.xcd_gs_shift = sh; p.xcd_nsg = nsl / gs; p.xcd_mtg = p.mtiles / gm; }
+                }
+                if (p.xcd_gs) p.inv_xcd_nsg = 1.f / p.xcd_nsg;
+            }
             p.inv_Mimg = 1.f / (float)(g.Mh * g.Mw); p.inv_Mw = 1.f / g.Mw; p.inv_cpt = 1.f / cpt; p.inv_kw = 1.f / g.kw;
             p.tw_shift = 0; p.th = 1; p.tcols = 1; p.trows = 1; p.inv_tcols = 1.f; p.inv_trows = 1.f;
             if (p.tw > 0) {
@@ -1115,6 +1132,7 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_LDSDMA")) g_ldsdma = atoi(e);
     if (const char* e = getenv("RY_KGROUPS")) g_kgroups = atoi(e);
     if (const char* e = getenv("RY_PATCH")) g_patch = atoi(e);
+    if (const char* e = getenv("RY_XCD_GROUPS")) g_xcd_groups = atoi(e);
     if (const char* e = getenv("RY_S1_WGS")) g_s1_wgs = atoi(e);
     if (const char* e = getenv("RY_S1_MAXS")) g_s1_maxs = atoi(e);
     if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);
