@@ -340,24 +340,28 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// ry_igemm_ldsdma<.., BF16 = false> -- the default stage-2 implicit GEMM (fp32 operands, v_mfma_f32_32x32x2_f32);
-// BF16 = true: the same kernel on bf16 activations and filters (v_mfma_f32_32x32x16_bf16, 64 channels per K chunk).  Operand tiles go global -> LDS by DMA
-// (global_load_lds_dwordx4), issued by the same four waves that run the MFMAs: no staging registers, no ds_write, one
-// barrier per 32-wide K chunk.
-//   A (gathered pixels x channels): LDS rows of 32 floats, unpadded (the DMA destination is lane-linear); the 16-byte slot
-//     c of row r is stored at position c ^ ((r >> 1) & 7), which makes the ds_read_b128 fragment reads conflict-free
-//     (bank = (addr / 4) mod 64 inside the instruction's 16-lane groups).  The swizzle is applied on the SOURCE side: the
-//     lane that fills position q of row r fetches slot q ^ f(r).  Padding is fetched from the zeroed tail behind the source buffer
-//     (RyConvGeom::zoff1 / zoff2), so all lanes of a piece share ONE scalar base: global_load_lds ... v_off, s[base:base+1]
-//     reads one address VGPR per lane instead of a 64-bit pair and needs no 64-bit add (stage 2 1.34 -> 1.305 ms).
-//   B (filters) is stored in fragment order by the host (ry_net.cpp: wig_inblock), one 1-KiB piece per (32 columns, K step):
-//     the pieces are DMA-copied into the LDS as they are and read back lane-linearly (conflict-free, no swizzle).
-//     (Loading them global -> registers in the 1 x 4 wave layouts, bypassing the LDS, measured 2 % slower: DESIGN.md 4.1.)
-// Two buffers held in DISTINCT __shared__ arrays and a loop unrolled by two, so that the compiler's LDS-DMA alias tracking
-// does not order the reads of buffer k & 1 behind the DMA into the other buffer.
-// KG = 2 (512 threads): two groups of four waves each take half of the workgroup's K range with their own buffers and are
-// summed through the LDS at the end -- split-K without slabs in HBM or a reduce kernel, for layers whose tile count only
-// fills the chip once (the co-resident second workgroup of a CU becomes the second K group of the same tile).
+// ry_igemm_ldsdma<BM, BN, WM, WN, KG, BF16, PATCH> -- the stage-2 implicit GEMM (DESIGN.md 4.1 has the measurements behind
+// every choice below).
+//   BF16 = false: fp32 operands, v_mfma_f32_32x32x2_f32, 32 input channels per K chunk (exact fp32: the headline path);
+//   BF16 = true:  bf16 activations and filters, v_mfma_f32_32x32x16_bf16, 64 channels per chunk (BASELINE config #5).
+// Operand tiles go global -> LDS by DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction), issued by the same waves that
+// run the MFMAs: no staging registers, no ds_write, one barrier per K chunk.  Every piece uses the scalar-base addressing
+// mode (wave-uniform base + 32-bit lane offset); padding comes from the zeroed tail behind the source buffer
+// (RyConvGeom::zoff1 / zoff2) so that it shares the base.
+//   A (pixels x channels): LDS rows of 128 bytes, unpadded (the DMA destination is lane-linear); the 16-byte slot c of row r
+//     is stored at position c ^ ((r >> 1) & 7), which makes the ds_read_b128 fragment reads conflict-free (bank = (addr / 4)
+//     mod 64 inside the instruction's 16-lane groups).  The swizzle is applied on the SOURCE side: the lane that fills
+//     position q of row r fetches slot q ^ f(r).
+//     PATCH = 0: every tap gathers its own BM rows.  PATCH = 1 / 2: the taps of a deconvolution phase / of one input parity
+//     of a k4 s2 convolution read one shared (BM / 16 + 1) x 17-pixel patch at compile-time row offsets (see below).
+//   B (filters): stored in fragment order by the host (ry_net.cpp: wig_inblock / wig16_inblock), one 1-KiB piece per
+//     (32 columns, K step); copied as is, read back lane-linearly.
+// Buffers are double, held in DISTINCT __shared__ arrays with loops unrolled so that every buffer index is static: the
+// compiler's LDS-DMA alias tracking then does not order the reads of one buffer behind the DMA into the other.
+// KG = 2 (512 threads): two groups of four waves take the two halves of the workgroup's K range with their own buffers and
+// are summed through the LDS at the end -- split-K without slabs in HBM or a reduce launch.
+// Epilogue: folded BN + activation in registers, 32 x 32 tiles transposed through the LDS, 16-byte stores (fp32 and / or a
+// bf16 copy for bf16 consumers), or raw split-K slabs.
 // dbg_flags (RY_IGEMM_DBG, diagnostics with wrong results): 4 skip the output stores, 8 skip the K loop, 128 skip the
 // loads inside the K loop.
 // ---------------------------------------------------------------------------------------------
