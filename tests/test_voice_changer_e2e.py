@@ -159,3 +159,60 @@ def test_reference_voice_changer_and_convert_stream_run_unchanged_on_the_shims(m
     assert numpy.allclose(got.sp, out.sp, rtol=1e-6)
     for m in [k for k in sys.modules if k.startswith('realtime_voice_conversion')]:
         sys.modules.pop(m)
+
+
+@pytest.mark.skipif(not REF.exists(), reason='/root/reference is not mounted here')
+def test_convert_worker_mirror_matches_the_reference_loop_and_stays_bounded(models, on_emulator, monkeypatch):
+    """`realtime_yukarin_amd.worker.convert_worker` over FeatureQueues against the reference's loop body
+    (convert_worker.py:33-57) run inline: same windows out, while the mirror's stream no longer grows."""
+    import threading
+    for p in (str(ROOT / 'tests' / 'stubs'), str(REF)):
+        monkeypatch.syspath_prepend(p)
+    vc_mod = importlib.import_module('realtime_voice_conversion.yukarin_wrapper.voice_changer')
+    st_mod = importlib.import_module('realtime_voice_conversion.stream')
+    util = importlib.import_module('realtime_voice_conversion.worker.utility')
+    from realtime_yukarin_amd import worker
+    from realtime_yukarin_amd.transport import FeatureQueue
+    ac, sr = build_converters(models)
+    time_length, extra_time, n_items = 0.3, 0.1, 7
+    rng = numpy.random.default_rng(5)
+    inputs = []
+    for _ in range(n_items):
+        wave, feat = make_input(rng)
+        inputs.append(vc_mod.AcousticFeatureWrapper(wave=wave, **feat))
+
+    # the reference's loop body, inline
+    stream = st_mod.ConvertStream(voice_changer=vc_mod.VoiceChanger(super_resolution=sr, acoustic_converter=ac, threshold=60))
+    wrapper = st_mod.StreamWrapper(stream=stream, extra_time=extra_time)
+    want, start_time = [], extra_time
+    for f in inputs:
+        stream.add(start_time=start_time, data=f)
+        start_time += time_length
+        want.append(wrapper.process_next(time_length=time_length))
+    assert len(stream.stream) == n_items                                      # never trimmed
+
+    q_in, q_out = FeatureQueue(slots=4, slot_bytes=4 << 20), FeatureQueue(slots=4, slot_bytes=4 << 20)
+    lock = threading.Lock(); lock.acquire()
+    seen = {}
+    real_remove = st_mod.ConvertStream.remove
+
+    def counting_remove(self, end_time):
+        real_remove(self, end_time)
+        seen['segments'] = max(seen.get('segments', 0), len(self.stream))
+    monkeypatch.setattr(st_mod.ConvertStream, 'remove', counting_remove)
+    t = threading.Thread(target=worker.convert_worker, args=(ac, sr, time_length, extra_time, 60, q_in, q_out, lock), daemon=True)
+    t.start()
+    for i, f in enumerate(inputs):
+        q_in.put(util.Item(item=f, index=i))
+        got = q_out.get(timeout=300)
+        assert got.index == i and got.item.sp.shape == want[i].sp.shape == (60, 513)
+        # the reference's VoiceChanger goes step by step (host mc2sp in float64), the mirror's fused core does mc2sp in fp32
+        assert float(numpy.abs(got.item.sp / want[i].sp - 1).max()) < 2e-5 and numpy.array_equal(got.item.f0, want[i].f0)
+        assert numpy.array_equal(got.item.ap, want[i].ap) and numpy.array_equal(got.item.voiced, want[i].voiced)   # (mc is not a key of the output segments, feature_segment.py:20)
+    q_in.put(None)
+    t.join(timeout=30)
+    assert not t.is_alive() and not lock.locked()
+    assert seen['segments'] <= 3                                              # bounded by the overlap, not by the run length
+    q_in.close(); q_out.close()
+    for m in [k for k in sys.modules if k.startswith('realtime_voice_conversion')]:
+        sys.modules.pop(m)
