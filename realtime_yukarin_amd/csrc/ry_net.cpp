@@ -498,6 +498,7 @@ static int g_kgroups = 1;   // RY_KGROUPS=0: never split K inside a workgroup (e
 static int g_ldsdma = 1;    // RY_LDSDMA=0: register-staged ry_igemm_f32 instead of the LDS-DMA kernel (A/B; ~5 % slower end to end)
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
 static unsigned long long* g_dbg = nullptr;
+static int g_force[16][3];   // RY_PLAN="layer:tile:splits:kgroups,...": tuning aid, fixes the stage-2 plan of single layers (0 = planner's choice)
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
 // Kernel names as rocprofv3 prints them (template arguments, no spaces): bench.py matches them against profiles/*.
@@ -572,7 +573,7 @@ static int best_split(long blocks, int bm, int bn, int nk, bool tinyM, int occ, 
     int best = 1; double bt = 1e30;
     for (int s = 1; s <= smax && s <= (nk >= min_chunks ? nk / min_chunks : 1); ++s) {
         double t;
-        if (tinyM) { const long g = blocks * s; t = g >= 1024 ? 1.0 + 1e-4 * s : 1024.0 / (double)g; }   // weight streaming: fill the chip with loads in flight
+        if (tinyM) { const long g = blocks * s; t = g >= 512 ? 1.0 + 1e-4 * s : 512.0 / (double)g; }   // weight streaming: two workgroups per CU keep enough loads in flight (1024 measured 30 % slower: more slabs, same bandwidth)
         else t = est_time(blocks, bm, bn, s, occ, kg, M, N, nk);
         if (t < bt - 1e-9) { bt = t; best = s; }
     }
@@ -898,6 +899,7 @@ static int build_plan(ry_net* net, Plan& P) {
                 const int M = B * (l.deconv ? lp.Hi * lp.Wi : lp.Ho * lp.Wo);
                 const int nk = t.ntaps * (l.cin() / 32);
                 lp.path = PATH_IGEMM; lp.tile = 0; lp.splits = 0; lp.kg = 0;
+                { lp.tile = g_force[i][0]; lp.splits = g_force[i][1]; lp.kg = g_force[i][2]; }
                 // bf16 mode: a layer runs on bf16 operands when its filters were converted and every producer it reads can
                 // write a bf16 copy of its output (the first layer, implicit-GEMM layers and their reduce kernels can)
                 bool want16 = net->dtype == 1 && l.wig16;
@@ -1145,6 +1147,17 @@ static int read_env_switches() {
     }
 #endif
     if (const char* e = getenv("RY_TILE64")) g_tile64 = atoi(e) == 256 ? TILE_256x64 : TILE_128x64;
+    memset(g_force, 0, sizeof(g_force));
+    if (const char* e = getenv("RY_PLAN")) {
+        for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
+            int i = -1, t = 0, sp = 0, kg = 0;
+            if (sscanf(q, "%d:%d:%d:%d", &i, &t, &sp, &kg) >= 2 && i >= 0 && i < 16 && t >= 0 && t <= TILE_256x128 && sp >= 0 && kg >= 0 && kg <= 2) {
+                g_force[i][0] = t; g_force[i][1] = sp; g_force[i][2] = kg;
+            } else {
+                return fail(RY_EINVAL, "RY_PLAN: expected layer:tile:splits:kgroups[,...]");
+            }
+        }
+    }
     return RY_OK;
 }
 
