@@ -531,8 +531,8 @@ static const char* tile_name(int tile, int kg, bool bf16, int patch) {
 // ---- choice of tile, split-K and K groups for one stage-2 layer ----
 // Workgroups of one tile that fit a CU.  LDS-DMA kernel: two unpadded BK = 32 buffers; register-staged kernel: one padded
 // buffer, limited to 3 by its VGPR budget.
-static double g_plan_peak = 157.3e6;   // flop per microsecond the planner prices the main loop at (fp32 MFMA peak; bf16: see choose_igemm)
-static int g_plan_ck = 32;             // input channels per K chunk of the kernel being planned
+static thread_local double g_plan_peak = 157.3e6;   // flop per microsecond the planner prices the main loop at (fp32 MFMA peak; bf16: see choose_igemm)
+static thread_local int g_plan_ck = 32;             // input channels per K chunk of the kernel being planned
 
 static int tile_occ(int tile, int kg) {
     int bm, bn; tile_dims(tile, &bm, &bn);
@@ -1509,7 +1509,7 @@ int ry_mc2sp(ry_ctx* ctx, const float* mc, const float* mtx, int n, int m, int b
     return RY_OK;
 }
 
-// diagnostics: read and reset the phase totals of the RY_TIMING=1 kernel variant (8 counters)
+// diagnostics: the plan (tile, external splits, K groups, estimated time) the stage-2 planner picks for one layer shape
 int ry_debug_plan_igemm(int M, int Cout, int nphases, int nk, int* tile, int* splits, int* kgroups, double* est_us) {
     if (!tile || !splits || !kgroups) return fail(RY_EINVAL, "null argument");
     if (M < 1 || Cout < 64 || Cout % 64 != 0 || nphases < 1 || nk < 1) return fail(RY_EINVAL, "not an implicit-GEMM layer shape");
@@ -1524,6 +1524,7 @@ int ry_debug_plan_igemm(int M, int Cout, int nphases, int nk, int* tile, int* sp
     return RY_OK;
 }
 
+// diagnostics: read and reset the phase totals of the RY_TIMING=1 kernel variant (8 counters)
 int ry_debug_igemm_phases(ry_ctx* ctx, unsigned long long* out8) {
     if (!ctx || !out8) return fail(RY_EINVAL, "null argument");
     for (int i = 0; i < 8; ++i) out8[i] = 0;

@@ -101,3 +101,25 @@ def test_stage2_convert_emu(emu_ctx, n_frames):
         r = unet.stage2_convert(sp[w], P)
         assert float(numpy.abs(y[w] / r - 1).max()) < cases.TOL
     net.close()
+
+
+def test_convert_edge_inputs_emu(emu_ctx):
+    """Edges of the two wrappers: an empty window is an error (numpy.pad mode='minimum' refuses an empty axis in the reference's
+    wrappers too), a wrong bin count is refused before any launch, non-finite input propagates instead of being masked, and
+    other float dtypes are cast like `.astype(numpy.float32)` at voice_changer.py:41."""
+    d1, d2 = NetDesc(1, 9, 9, 8, 8), NetDesc(2, 1, 1, 8, 8)
+    n1 = engine.Net(emu_ctx, d1, flatten_params(d1, synthetic_params(d1, 5)))
+    n2 = engine.Net(emu_ctx, d2, flatten_params(d2, synthetic_params(d2, 6)), width=128)
+    with pytest.raises(Exception, match='positive'):
+        n1.convert(numpy.zeros((0, 9), 'f4'))
+    with pytest.raises(Exception, match='positive'):
+        n2.convert(numpy.zeros((0, 129), 'f4'))
+    with pytest.raises(ValueError, match='bins'):
+        n2.convert(numpy.ones((5, 128), 'f4'))
+    x64 = numpy.random.default_rng(1).normal(size=(7, 9))
+    assert numpy.array_equal(n1.convert(x64), n1.convert(x64.astype('f4')))
+    sp = numpy.full((5, 129), 1e-3, 'f4')
+    sp[2, 40] = numpy.nan
+    assert numpy.isnan(n2.convert(sp)).any()
+    assert numpy.isfinite(n2.convert(numpy.full((5, 129), 1e-3, 'f4'))).all()      # ... and the net is still usable afterwards
+    n1.close(); n2.close()
