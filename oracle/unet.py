@@ -24,7 +24,7 @@ DEC_IN = [8, 16, 16, 16, 16, 8, 4]           # decoder c_j input channels / base
 DEC_OUT = [8, 8, 8, 8, 4, 2, 1]              # decoder c_j output channels / base
 
 
-def _cbr(x, P, prefix, sample, act):
+def _cbr(x, P, prefix, sample, act, ops=ops):
     """`CBR.__call__`: conv/deconv -> BatchNormalization -> (dropout = identity) -> activation."""
     W, b = P[prefix + '/c/W'], P[prefix + '/c/b']
     if sample == 'down':
@@ -38,21 +38,22 @@ def _cbr(x, P, prefix, sample, act):
     return ops.apply_act(h, act)
 
 
-def unet_forward(x, P, extensive_layers=8, return_all=False):
+def unet_forward(x, P, extensive_layers=8, return_all=False, ops=ops):
     """`Predictor.__call__` / `SRPredictor.__call__`: x (B, in_ch, *spatial) -> (B, out_ch, *spatial).
 
-    The spatial rank is taken from the weights (1 -> stage-1, 2 -> stage-2)."""
+    The spatial rank is taken from the weights (1 -> stage-1, 2 -> stage-2).  `ops` selects the operator restatement:
+    `ops_numpy` (default) or `c_ref` (the plain-C loop nests of ops_ref.c)."""
     e = int(extensive_layers)
     end_pad = 1 if e > 0 else 0
     hs = [ops.leaky_relu(ops.conv_nd(x, P['encoder/c0/W'], P['encoder/c0/b'], stride=1, pad=end_pad))]
     for i in range(1, 8):
-        hs.append(_cbr(hs[i - 1], P, 'encoder/c%d' % i, 'down' if i < e else 'same', 'lrelu'))
-    h = _cbr(hs[7], P, 'decoder/c0', 'up' if 7 < e else 'same', 'relu')
+        hs.append(_cbr(hs[i - 1], P, 'encoder/c%d' % i, 'down' if i < e else 'same', 'lrelu', ops))
+    h = _cbr(hs[7], P, 'decoder/c0', 'up' if 7 < e else 'same', 'relu', ops)
     acts = {'enc': hs, 'dec': [h]}
     for j in range(1, 8):
         h = np.concatenate([h, hs[7 - j]], axis=1)
         if j < 7:
-            h = _cbr(h, P, 'decoder/c%d' % j, 'up' if (7 - j) < e else 'same', 'relu')
+            h = _cbr(h, P, 'decoder/c%d' % j, 'up' if (7 - j) < e else 'same', 'relu', ops)
             acts['dec'].append(h)
         else:
             h = ops.conv_nd(h, P['decoder/c7/W'], P['decoder/c7/b'], stride=1, pad=end_pad)
@@ -66,7 +67,7 @@ def pad_frames(n):
     return 128 - n % 128
 
 
-def stage1_convert_core(x_nc, P, extensive_layers=8):
+def stage1_convert_core(x_nc, P, extensive_layers=8, ops=ops):
     """Array part of `AcousticConverter.convert` ([MEM]):
     x_nc (N, C_in) = encode_feature(...) before the transpose -> (N, C_out).
 
@@ -74,11 +75,11 @@ def stage1_convert_core(x_nc, P, extensive_layers=8):
     n = x_nc.shape[0]
     pad = pad_frames(n)
     x = np.pad(x_nc.T, [(0, 0), (0, pad)], mode='minimum')
-    y = unet_forward(x[np.newaxis], P, extensive_layers)[0]
+    y = unet_forward(x[np.newaxis], P, extensive_layers, ops=ops)[0]
     return np.ascontiguousarray(y[:, :-pad].T)
 
 
-def stage2_convert(sp, P, extensive_layers=8):
+def stage2_convert(sp, P, extensive_layers=8, ops=ops):
     """`SuperResolution.convert` ([MEM]): sp (N, F) float32 -> (N, F).
 
     pad 'minimum' along time -> log -> drop last bin -> (1,1,T,F-1) -> SRPredictor -> [0][0]
@@ -87,7 +88,7 @@ def stage2_convert(sp, P, extensive_layers=8):
     pad = pad_frames(n)
     x = np.pad(sp, [(0, pad), (0, 0)], mode='minimum')
     x = np.log(x)[:, :-1]
-    y = unet_forward(x[np.newaxis, np.newaxis], P, extensive_layers)[0, 0]
+    y = unet_forward(x[np.newaxis, np.newaxis], P, extensive_layers, ops=ops)[0, 0]
     y = np.pad(y, [(0, 0), (0, 1)], mode='edge')
     y = np.exp(y)
     return np.ascontiguousarray(y[:-pad])

@@ -100,6 +100,26 @@ def test_stage2_syn64_convert(syn64, n_frames):
     assert numpy.array_equal(y[:, -1], y[:, -2]), "pad(mode='edge') repeats the last predicted bin"
 
 
+def test_stage2_syn64_against_the_c_restatement(syn64):
+    """Full-size stage 2 against the plain-C loop nests (oracle/ops_ref.c), float and double sums: the HIP path sits as close
+    to the double-sum result as the fp32 CPU restatement does."""
+    from oracle import c_ref
+    _, (n2, _) = syn64
+    P2 = synth.model_params('SYN-64')[1][1]
+    sp = synth.stage2_input(100)[0]
+    y = n2.convert(sp)
+    r32 = unet.stage2_convert(sp, P2, ops=c_ref)
+    c_ref.ACC64 = True
+    try:
+        r64 = unet.stage2_convert(sp, P2, ops=c_ref)
+    finally:
+        c_ref.ACC64 = False
+    e_gpu, e_cpu = float(numpy.abs(y / r64 - 1).max()), float(numpy.abs(r32 / r64 - 1).max())
+    print('stage-2 vs double-sum C oracle: HIP %.2e, fp32 C %.2e' % (e_gpu, e_cpu))
+    assert float(numpy.abs(y / r32 - 1).max()) < cases.TOL and e_gpu < cases.TOL
+    assert e_gpu < 10 * e_cpu + 1e-6
+
+
 def test_windows_are_independent_and_batch_invariant(syn64):
     """Chunk-parallel property: a window's result does not depend on its batch neighbours."""
     (n1, _), (n2, _) = syn64
