@@ -1,0 +1,57 @@
+"""Soak run (GPU box): thousands of windows of changing length, silence pattern and batch through the drop-in entry points
+(`ry_vc_convert`, `ry_sr_convert`), exercising plan-cache eviction and hipGraph re-capture; a fixed probe window must come
+back bit-identical every time and the free device memory must not trend down (it saw-tooths with the bounded plan cache).  Usage: python scripts/gpu_soak.py [iterations]"""
+import sys
+import time
+from pathlib import Path
+
+import numpy
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch                                                                     # noqa: E402
+from realtime_yukarin_amd import engine, sptk, synth                             # noqa: E402
+from realtime_yukarin_amd.weights import flatten_params                          # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+(d1, P1), (d2, P2) = synth.model_params('SYN-64')
+ctx = engine.get_context(0)
+n1 = engine.Net(ctx, d1, flatten_params(d1, P1))
+n2 = engine.Net(ctx, d2, flatten_params(d2, P2), width=synth.FFT_BINS - 1)
+core = engine.VcCore(n1, n2, sptk.mc2sp_matrix(8, sptk.mcepalpha(16000), 1024))
+rng = numpy.random.default_rng(7)
+probe_x = synth.stage1_input(300)[0]
+probe_eff = rng.random(300) > 0.2
+probe = core.convert(probe_x[probe_eff], probe_eff)
+probe_sp = synth.stage2_input(200, windows=3)
+probe_b = n2.convert(probe_sp)
+free0 = None
+samples = []
+t0 = time.time()
+frames_done = 0
+for it in range(iters):
+    n = int(rng.integers(40, 700))
+    kind = it % 5
+    if kind < 3:                                        # one window through the fused core, data-dependent effective count
+        eff = rng.random(n) < rng.choice([0.0, 0.5, 0.9, 1.0], p=[0.05, 0.25, 0.4, 0.3])
+        x = rng.normal(size=(n, d1.in_ch)).astype('f4')
+        mc, sp = core.convert(x[eff], eff)
+        assert sp.shape == (n, synth.FFT_BINS) and numpy.isfinite(sp).all() and not mc[~eff].any()
+    else:                                               # a batch of windows through stage 2 alone (plan cache keys: batch x length)
+        b = int(rng.integers(1, 5))
+        sp = n2.convert(synth.stage2_input(min(n, 400), windows=b, seed=it))
+        assert sp.shape == (b, min(n, 400), synth.FFT_BINS) and numpy.isfinite(sp).all()
+    frames_done += n
+    if it % 250 == 249 or it == iters - 1:
+        again = core.convert(probe_x[probe_eff], probe_eff)
+        assert numpy.array_equal(again[0], probe[0]) and numpy.array_equal(again[1], probe[1]), 'probe window changed at %d' % it
+        assert numpy.array_equal(n2.convert(probe_sp), probe_b), 'probe batch changed at %d' % it
+        free = torch.cuda.mem_get_info()[0]
+        free0 = free0 or free
+        samples.append(free)
+        print('iter %5d  %.1f s  %.0f windows/s  free HBM %.2f GB (drift %+.1f MB)' % (
+            it + 1, time.time() - t0, (it + 1) / (time.time() - t0), free / 1e9, (free - free0) / 1e6), flush=True)
+# the plan cache (<= 16 plans per predictor, cleared when full) makes the free memory saw-tooth; it must not trend down
+half = len(samples) // 2
+assert min(samples[half:]) >= min(samples[:half]) - 1e9, 'device memory keeps shrinking: %s' % samples
+print('soak ok: %d windows, %d frames, probes bit-identical throughout' % (iters, frames_done))
+core.close(); n1.close(); n2.close()
