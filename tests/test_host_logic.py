@@ -1,0 +1,75 @@
+"""Host logic around the C ABI (no device work): the K-list weight validator refuses anything that is not exactly the
+predictor's parameter set, the flat blob round-trips, and the size / FLOP bookkeeping reproduces SURVEY.md section 8's numbers
+(the figures bench.py's roofline is computed from)."""
+import numpy
+import pytest
+
+from realtime_yukarin_amd import netspec, sptk, synth, weights
+from realtime_yukarin_amd.netspec import NetDesc
+
+
+def small():
+    d = NetDesc(1, 9, 9, 8, 8)
+    return d, weights.synthetic_params(d, 3, bias_std=0.05)
+
+
+def test_validator_accepts_the_klist_and_ignores_the_bn_counter():
+    d, P = small()
+    P['encoder/c3/batchnorm/N'] = numpy.array(12)                 # Chainer's save_npz also stores it
+    weights.validate_params(d, P)
+    assert weights.flatten_params(d, P).size == netspec.param_count(d)
+
+
+@pytest.mark.parametrize('damage', ['missing', 'extra', 'shape', 'swapped'])
+def test_validator_refuses_a_mismatch(damage, tmp_path):
+    d, P = small()
+    if damage == 'missing':
+        del P['decoder/c4/batchnorm/avg_var']
+    elif damage == 'extra':
+        P['encoder/c8/c/W'] = numpy.zeros((1, 1, 4), 'f4')
+    elif damage == 'shape':
+        P['encoder/c2/c/W'] = P['encoder/c2/c/W'][:, :, :3]
+    else:                                                         # a stage-1 file offered to a stage-2 predictor
+        d = NetDesc(2, 1, 1, 8, 8)
+    with pytest.raises(ValueError):
+        weights.validate_params(d, P)
+    weights.save_npz(tmp_path / 'm.npz', P)
+    with pytest.raises(ValueError):
+        weights.load_npz(d, tmp_path / 'm.npz')
+
+
+def test_blob_round_trip_and_npz_round_trip(tmp_path):
+    d, P = small()
+    blob = weights.flatten_params(d, P)
+    Q = weights.unflatten_params(d, blob)
+    assert list(Q) == [k for k, _ in netspec.param_list(d)] and all(numpy.array_equal(Q[k], P[k]) for k in Q)
+    with pytest.raises(ValueError):
+        weights.unflatten_params(d, blob[:-1])
+    weights.save_npz(tmp_path / 'm.npz', {k: v.astype('f8') for k, v in P.items()})          # a float64 file is cast, not refused
+    L = weights.load_npz(d, tmp_path / 'm.npz')
+    assert all(L[k].dtype == numpy.float32 and numpy.array_equal(L[k], P[k]) for k in L)
+
+
+def test_parameter_counts_and_flops_match_the_survey():
+    d1, d2 = synth.model_descs('SYN-64')
+    assert round(netspec.param_count(d1) / 1e6, 1) == 13.6 and round(netspec.param_count(d2) / 1e6, 1) == 54.4
+    assert round(netspec.flops(d1, 1024) / 1e9, 3) == 1.453 and round(netspec.flops(d1, 384) / 1e9, 3) == 0.545
+    assert round(netspec.flops(d2, 128, 512) / 1e9, 1) == 47.4 and round(netspec.flops(d2, 384, 512) / 1e9, 1) == 142.2
+    assert round(netspec.flops(d2, 512, 512) / 1e9, 1) == 189.6 and round(netspec.flops(d2, 128, 512) / 128 / 1e6) == 370   # MFLOP per padded frame
+    d8 = NetDesc(2, 1, 1, 8, 8)
+    assert round(netspec.param_count(d8) / 1e6, 2) == 0.85
+
+
+def test_pad_rule_and_extensive_layers():
+    assert [netspec.pad_frames(n) for n in (1, 100, 127, 128, 300, 1000)] == [127, 28, 1, 128, 84, 24]
+    d = NetDesc(1, 9, 9, 8, 3)
+    assert [netspec.enc_sample(d, i) for i in (1, 2, 3, 7)] == ['down', 'down', 'same', 'same']
+    assert [netspec.dec_sample(d, j) for j in (0, 4, 5, 6)] == ['same', 'same', 'up', 'up']
+
+
+def test_mcepalpha_reproduces_the_known_table():
+    assert [round(sptk.mcepalpha(fs), 3) for fs in (16000, 24000, 44100)] == [0.41, 0.466, 0.544]
+    m = sptk.mc2sp_matrix(8, 0.41, 1024)
+    assert m.shape == (9, 513) and m.dtype == numpy.float64
+    mc = numpy.random.default_rng(0).normal(size=(5, 9)) * 0.3
+    assert numpy.allclose(numpy.exp(mc @ m), sptk.mc2sp(mc, 0.41, 1024), rtol=1e-10)
