@@ -71,7 +71,10 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
 void ry_net_destroy(ry_net* net);
 
 /* BASELINE config #5: dtype 1 runs the stage-2 implicit-GEMM layers with bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate,
- * fp32 activations in HBM; filters converted once).  dtype 0 (default) is exact fp32.  Tolerance of the bf16 variant: DESIGN.md. */
+ * bf16 activations between those layers; filters converted once).  dtype 2 ("split-bf16") runs them as three bf16 products per fp32
+ * product -- x = hi + lo, w = hi + lo, x w ~ hi hi + lo hi + hi lo -- on the same instruction with fp32 accumulation: results agree
+ * with the fp32 path to ~2e-6 (inside the 1e-4 parity bar) at 3/16 of the matrix-pipe time.  dtype 0 (default) is exact fp32.
+ * Tolerances: DESIGN.md 4.6 / 4.7. */
 int ry_net_set_dtype(ry_net* net, int dtype);
 
 /* `Predictor.__call__` / `SRPredictor.__call__` on an already padded block (frames % 128 == 0 when

@@ -45,6 +45,25 @@ RY_DEV int ry_fdiv(int x, int d, float inv_d) {
     return q;
 }
 
+// four fp32 -> four bf16 (RNE), one 8-byte store
+RY_DEV void ry_st4_bf16(unsigned short* q, f32x4 v) {
+    u16x4 h;
+    h[0] = ry_f2bf(v[0]); h[1] = ry_f2bf(v[1]); h[2] = ry_f2bf(v[2]); h[3] = ry_f2bf(v[3]);
+    *reinterpret_cast<u16x4*>(q) = h;
+}
+RY_DEV float ry_bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+// Split-bf16 copy of four channels n .. n + 3 of pixel `pix` (N channels): the pixel keeps [hi (N) | lo (N)] with
+// hi = bf16(v), lo = bf16(v - hi) (both RNE; v - hi is exact in fp32), so that hi + lo carries 16 mantissa bits of v.
+// The implicit GEMM then runs hi*hi + lo*hi + hi*lo on the bf16 matrix pipe with fp32 accumulation.
+RY_DEV void ry_st4_bf16_x3(unsigned short* base, size_t pix, int N, int n, f32x4 v) {
+    u16x4 h, l;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { h[u] = ry_f2bf(v[u]); l[u] = ry_f2bf(v[u] - ry_bf2f(h[u])); }
+    unsigned short* q = base + pix * (size_t)(2 * N) + n;
+    *reinterpret_cast<u16x4*>(q) = h;
+    *reinterpret_cast<u16x4*>(q + N) = l;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Convolution geometry shared by the implicit-GEMM and the direct kernel.
 // GEMM rows enumerate (b, ry, rx) over an Mh x Mw grid per image; input coordinate of tap t is
@@ -56,6 +75,8 @@ struct RyConvGeom {
     const float* src1;
     const float* src2;          // second source of a skip concat (channels C1..C1+C2), or null
     int C1, C2;
+    int S1, S2;                 // LDS-DMA kernel: elements per pixel of each source (= C1 / C2, except in the split-bf16 mode where a pixel
+                                // keeps [hi | lo] = 2 C bf16 and the K axis runs over [hi | lo | hi] = 3 C: a channel offset past S wraps to 0)
     int B, Hi, Wi, Ho, Wo;
     int Mh, Mw;
     int stride, pad, ostride;
@@ -75,6 +96,7 @@ struct RyIgemmParams {
     const float* shift;         // [N] folded bias/BN shift
     float* out;                 // splits==1: NHWC output (may be null when only out16 is wanted); else slabs [split][B*Ho*Wo][N] of raw sums
     unsigned short* out16;      // splits==1: optional bf16 copy of the activated output (consumers on the bf16 path), else unused
+    int x3;                     // out16 format: 0 = [pixel][N] bf16; 1 = split-bf16 [pixel][hi (N) | lo (N)], lo = bf16(v - hi)
     int splits;
     int act;
     float slope;
@@ -517,8 +539,8 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
             const int ce = (dpos ^ ((pr >> 1) & 7)) * ES;
             const int pix = (bimg * g.Hi + iy) * g.Wi + ix;
             ayb[j] = ok ? iy : -(1 << 20); axb[j] = ix;
-            aoff1[j] = ok ? pix * g.C1 + ce : 0;
-            aoff2[j] = ok ? pix * g.C2 + ce : 0;
+            aoff1[j] = ok ? pix * g.S1 + ce : 0;
+            aoff2[j] = ok ? pix * g.S2 + ce : 0;
         }
     } else {
 #pragma unroll
@@ -528,8 +550,8 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
         const int ce = (dpos ^ ((row >> 1) & 7)) * ES;       // element offset of the slot this lane fetches
         ayb[j] = rY[row]; axb[j] = rX[row];
         const int pixb = rP[row] + ayb[j] * g.Wi + axb[j];
-        aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + ce : 0;
-        aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + ce : 0;
+        aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.S1 + ce : 0;
+        aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.S2 + ce : 0;
     }
     }
     const int sw = (lr >> 1) & 7;                // swizzle key of every A fragment row this lane reads (tile rows are multiples of 32)
@@ -552,8 +574,9 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
             const int ci0 = cib * CK;
             c_first = ci0 < g.C1;
             c_src = c_first ? g.src1 : g.src2;
-            const int Cs = c_first ? g.C1 : g.C2;
-            const int cil = c_first ? ci0 : ci0 - g.C1;
+            const int Cs = c_first ? g.S1 : g.S2;
+            int cil = c_first ? ci0 : ci0 - g.C1;
+            if (cil >= Cs) cil -= Cs;                  // split-bf16 sources: the third K segment reads the hi half again
             c_dy = subpix ? pdy - ky : ky; c_dx = subpix ? pdx - kx : kx;
             c_delta = (c_dy * g.Wi + c_dx) * Cs + cil;
             c_bdelta = (unsigned)((tap * c32 + cib) * 2048);
@@ -648,9 +671,10 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
             c_first = ci0 < g.C1;
             c_src = c_first ? g.src1 : g.src2;
             c_cil = c_first ? ci0 : ci0 - g.C1;
+            if (c_cil >= (c_first ? g.S1 : g.S2)) c_cil -= c_first ? g.S1 : g.S2;      // split-bf16 sources, as in the gather variant
             if (PATCH == 2) {                         // parity (r, c) = ((pch >> 1) & 1, pch & 1): pixel = parity-(1, 1) pixel - (1 - r, 1 - c)
                 c_py = ((pch >> 1) & 1) - 1; c_px = (pch & 1) - 1;
-                c_pdelta = (c_py * g.Wi + c_px) * (c_first ? g.C1 : g.C2);
+                c_pdelta = (c_py * g.Wi + c_px) * (c_first ? g.S1 : g.S2);
             }
             ++pch;
         };
@@ -818,22 +842,14 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
                     const size_t oi = (size_t)ob * g.N + nbase + eslot * 4;
                     if (!final_ || p.out) ry_st4(outp + oi, o);
                     if (final_ && p.out16) {
-                        u16x4 h;
-                        h[0] = ry_f2bf(o[0]); h[1] = ry_f2bf(o[1]); h[2] = ry_f2bf(o[2]); h[3] = ry_f2bf(o[3]);
-                        *reinterpret_cast<u16x4*>(p.out16 + oi) = h;
+                        if (p.x3) ry_st4_bf16_x3(p.out16, (size_t)ob, g.N, nbase + eslot * 4, o);
+                        else ry_st4_bf16(p.out16 + oi, o);
                     }
                 }
             }
             ry_wave_sync();
         }
     }
-}
-
-// four fp32 -> four bf16 (RNE), one 8-byte store
-RY_DEV void ry_st4_bf16(unsigned short* q, f32x4 v) {
-    u16x4 h;
-    h[0] = ry_f2bf(v[0]); h[1] = ry_f2bf(v[1]); h[2] = ry_f2bf(v[2]); h[3] = ry_f2bf(v[3]);
-    *reinterpret_cast<u16x4*>(q) = h;
 }
 
 struct RyReduceParams {
@@ -844,6 +860,7 @@ struct RyReduceParams {
     const float* shift;
     float* out;                 // fp32 output, or null
     unsigned short* out16;      // bf16 copy of the output (consumers on the bf16 path), or null
+    int x3;                     // out16 format: 0 = plain bf16, 1 = split-bf16 [pixel][hi | lo] (ry_st4_bf16_x3)
     long long total;            // elements (multiple of 4)
     int N;
     int act;
@@ -871,7 +888,10 @@ RY_KERNEL(256) void ry_splitk_reduce(RyReduceParams p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(s[u], sc[u], sh[u]), p.act, p.slope);
     if (p.out) ry_st4(p.out + i4, o);
-    if (p.out16) ry_st4_bf16(p.out16 + i4, o);
+    if (p.out16) {
+        if (p.x3) ry_st4_bf16_x3(p.out16, (size_t)(i4 / p.N), p.N, n, o);
+        else ry_st4_bf16(p.out16 + i4, o);
+    }
 }
 
 // Many slabs, few outputs (the weight-streaming layers at the bottom of the U-Net): 64 float4 columns per workgroup,
@@ -905,7 +925,10 @@ RY_KERNEL(256) void ry_splitk_reduce_wide(RyReduceParams p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(s[u], sc[u], sh[u]), p.act, p.slope);
         if (p.out) ry_st4(p.out + i4, o);
-        if (p.out16) ry_st4_bf16(p.out16 + i4, o);
+        if (p.out16) {
+            if (p.x3) ry_st4_bf16_x3(p.out16, (size_t)(i4 / p.N), p.N, n, o);
+            else ry_st4_bf16(p.out16 + i4, o);
+        }
     }
 }
 
@@ -965,6 +988,7 @@ struct RySrFirstParams {
     const float* shift;
     float* out;                 // [B][H][W][N]
     unsigned short* out16;      // optional bf16 copy (consumers on the bf16 path)
+    int x3;                     // out16 format: 0 = plain bf16, 1 = split-bf16 [pixel][hi | lo] (ry_st4_bf16_x3)
     int B, H, W, N;
     int act;
     float slope;
@@ -1011,8 +1035,11 @@ RY_KERNEL(256) void ry_sr_first(RySrFirstParams p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(acc[u], sc[u], sh[u]), p.act, p.slope);
         const size_t oi = (((size_t)b * p.H + y) * p.W + x0 + j) * p.N + cq * 4;
-        ry_st4(p.out + oi, o);
-        if (p.out16) ry_st4_bf16(p.out16 + oi, o);
+        if (p.out) ry_st4(p.out + oi, o);
+        if (p.out16) {
+            if (p.x3) ry_st4_bf16_x3(p.out16, ((size_t)b * p.H + y) * p.W + x0 + j, p.N, cq * 4, o);
+            else ry_st4_bf16(p.out16 + oi, o);
+        }
     }
 }
 

@@ -158,6 +158,7 @@ struct Layer {
     float* wig = nullptr;                // stage-2 implicit-GEMM blocks [phase][N/64][tap][Ctot/32][fragment order], see wig_inblock()
     float* wdir = nullptr;               // stage-2 direct [phase][tap][Ctot][N]
     float* wig16 = nullptr;              // stage-2 implicit-GEMM bf16 blocks [phase][N/64][tap][Ctot/64][fragment order], see wig16_inblock() (ry_net_set_dtype)
+    float* wigx3 = nullptr;              // split-bf16 blocks [phase][N/64][tap][3 Ctot/64][fragment order]: K runs over [hi | hi | lo] per source, see build_wigx3()
     int cin() const { return cin_a + cin_b; }
 };
 
@@ -329,7 +330,8 @@ static bool igemm_eligible(const Layer& l) {
 // ------------------------------------------------------------------------------------------------
 // per-layer launch plans
 // ------------------------------------------------------------------------------------------------
-enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4, PATH_IGEMM_BF16 = 5 };
+enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4, PATH_IGEMM_BF16 = 5,
+       PATH_IGEMM_X3 = 6 };   // op-level selector only (ry_conv2d): runs as PATH_IGEMM_BF16 with LayerPlan::x3
 enum { TILE_128x128 = 1, TILE_256x64 = 2, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5, TILE_96x128 = 6, TILE_256x128 = 7 };
 
 struct LayerPlan {
@@ -344,8 +346,10 @@ struct LayerPlan {
     bool any_m_patch = false;                 // op-level calls (tests): take the input-patch variants whatever the row count
     int kg = 1;                               // K groups inside a workgroup (LDS-DMA implicit GEMM): 2 = split-K summed through the LDS
     float* out = nullptr;                     // NHWC activation, fp32
-    unsigned short* out16 = nullptr;          // NHWC activation, bf16 copy for consumers on the bf16 path (bf16 mode only)
+    unsigned short* out16 = nullptr;          // NHWC activation, bf16 copy for consumers on the bf16 path (bf16 / split-bf16 mode only)
     bool w32 = true, w16 = false;             // which copies the producer writes
+    bool x3 = false;                          // PATH_IGEMM_BF16 in split-bf16 form: sources are [pixel][hi | lo], K = [hi | lo | hi] x filters [hi | hi | lo]
+    bool o16x3 = false;                       // format of the out16 copy this layer writes: plain bf16 or split [hi | lo]
     float* slabs = nullptr;
     int last_rows = 0, last_cols = 0, last_exp = 0;   // PATH_LAST: fused exp / edge-pad / crop
     double flops = 0, bytes = 0;
@@ -378,7 +382,8 @@ struct KernelRec {           // filled by the launch helpers when profiling
 };
 
 struct ry_net {
-    int dtype = 0;                           // 0 = fp32 MFMA, 1 = bf16 operands (fp32 accumulate) for the stage-2 implicit-GEMM layers
+    int dtype = 0;                           // 0 = fp32 MFMA, 1 = bf16 operands (fp32 accumulate) for the stage-2 implicit-GEMM layers,
+                                             // 2 = split-bf16 (hi*hi + lo*hi + hi*lo on the bf16 pipe, fp32 accumulate: fp32-class results)
     ry_ctx* ctx = nullptr;
     ry_stream_t stream = nullptr;            // each predictor enqueues on its own stream: stage-1 of one window overlaps stage-2 of another
     rt::Event done;                          // recorded after the last enqueue; ry_sync / ry_timer_stop wait on it
@@ -462,13 +467,14 @@ static int alloc_ztail(ry_ctx* ctx, Arena& arena, float** p, size_t nfloats) {
 static void fill_geom(RyConvGeom& g, const Layer& l, const LayerPlan& lp, int B, const float* s1, int C1, const float* s2, int C2) {
     memset(&g, 0, sizeof g);
     const TapTable t = make_taps(l);
-    g.src1 = s1; g.src2 = s2; g.C1 = C1; g.C2 = C2;
+    g.src1 = s1; g.src2 = s2; g.C1 = C1; g.C2 = C2; g.S1 = C1; g.S2 = C2;
+    if (lp.path == PATH_IGEMM_BF16 && lp.x3) { g.C1 = 3 * C1; g.C2 = 3 * C2; g.S1 = 2 * C1; g.S2 = 2 * C2; }   // K = [hi | lo | hi(wrapped)] over [hi | lo] pixels
     g.B = B; g.Hi = lp.Hi; g.Wi = lp.Wi; g.Ho = lp.Ho; g.Wo = lp.Wo;
     if (l.deconv) { g.Mh = lp.Hi; g.Mw = lp.Wi; g.stride = 1; g.pad = 0; g.ostride = 2; }
     else { g.Mh = lp.Ho; g.Mw = lp.Wo; g.stride = l.stride; g.pad = l.pad; g.ostride = 1; }
     g.nphases = t.nphases; g.ntaps = t.ntaps; g.N = l.cout; g.kw = l.deconv ? 2 : l.k;
     const size_t esize = lp.path == PATH_IGEMM_BF16 ? 2 : 4;                  // implicit-GEMM sources end in a zeroed tail (ZTAIL floats)
-    g.zoff1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C1 * esize); g.zoff2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C2 * esize);
+    g.zoff1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * g.S1 * esize); g.zoff2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * g.S2 * esize);
     for (int ph = 0; ph < 4; ++ph) {
         g.pdy[ph] = (signed char)t.pdy[ph]; g.pdx[ph] = (signed char)t.pdx[ph];
         for (int tt = 0; tt < 16; ++tt) { g.tdy[ph][tt] = (signed char)t.dy[ph][tt]; g.tdx[ph][tt] = (signed char)t.dx[ph][tt]; }
@@ -499,6 +505,7 @@ static int g_ldsdma = 1;    // RY_LDSDMA=0: register-staged ry_igemm_f32 instead
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
 static unsigned long long* g_dbg = nullptr;
 static int g_force[16][3];   // RY_PLAN="layer:tile:splits:kgroups,...": tuning aid, fixes the stage-2 plan of single layers (0 = planner's choice)
+static int g_x3_min_m = 512;   // RY_X3_MINM: split-bf16 mode runs a layer on the bf16 pipe from this many GEMM rows (per phase) up
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
 // Kernel names as rocprofv3 prints them (template arguments, no spaces): bench.py matches them against profiles/*.
@@ -637,8 +644,10 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     const int M = B * g.Mh * g.Mw;
     if (lp.path == PATH_IGEMM || lp.path == PATH_IGEMM_BF16) {
         const bool bf16 = lp.path == PATH_IGEMM_BF16;       // s1 / s2 then point to bf16 activations
+        if (bf16 && lp.x3) { C1 *= 3; C2 *= 3; }            // split-bf16: the K axis the kernel walks (g.C1 / g.C2)
         RyIgemmParams p;
-        p.g = g; p.wt = bf16 ? l.wig16 : l.wig; p.scale = l.scale; p.shift = l.shift;
+        p.g = g; p.wt = bf16 ? (lp.x3 ? l.wigx3 : l.wig16) : l.wig; p.scale = l.scale; p.shift = l.shift;
+        p.x3 = lp.o16x3 ? 1 : 0;
         p.splits = lp.splits; p.act = l.act; p.slope = slope;
         p.slab_stride = (long long)B * lp.Ho * lp.Wo * l.cout;
         p.out = lp.splits > 1 ? lp.slabs : (lp.w32 ? lp.out : nullptr);
@@ -744,6 +753,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             RyReduceParams r;
             r.slabs = lp.slabs; r.splits = lp.splits; r.slab_stride = p.slab_stride;
             r.scale = l.scale; r.shift = l.shift; r.out = lp.w32 ? lp.out : nullptr; r.out16 = lp.w16 ? lp.out16 : nullptr;
+            r.x3 = lp.o16x3 ? 1 : 0;
             r.total = p.slab_stride; r.N = l.cout;
             r.act = l.act; r.slope = slope;
             if (lp.splits >= 16 && r.total <= (1 << 20)) {      // many slabs, few outputs
@@ -760,6 +770,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     } else if (lp.path == PATH_FIRST) {
         RySrFirstParams p;
         p.x = s1; p.w = l.wdir; p.scale = l.scale; p.shift = l.shift; p.out = lp.out; p.out16 = lp.w16 ? lp.out16 : nullptr;
+        p.x3 = lp.o16x3 ? 1 : 0;
         p.B = B; p.H = lp.Hi; p.W = lp.Wi; p.N = l.cout; p.act = l.act; p.slope = slope;
         const long long total = (long long)B * lp.Hi * ((lp.Wi + 3) / 4) * (l.cout / 4);
         dim3 grid((unsigned)((total + 255) / 256));
@@ -902,7 +913,10 @@ static int build_plan(ry_net* net, Plan& P) {
                 { lp.tile = g_force[i][0]; lp.splits = g_force[i][1]; lp.kg = g_force[i][2]; }
                 // bf16 mode: a layer runs on bf16 operands when its filters were converted and every producer it reads can
                 // write a bf16 copy of its output (the first layer, implicit-GEMM layers and their reduce kernels can)
-                bool want16 = net->dtype == 1 && l.wig16;
+                // split-bf16 mode: the same, for the layers with enough rows to be bound by the matrix pipe (the weight-streaming
+                // layers at the bottom of the U-Net would read 1.5 x the filter bytes: they stay exact fp32)
+                const bool x3 = net->dtype == 2;
+                bool want16 = x3 ? (l.wigx3 && M >= g_x3_min_m) : (net->dtype == 1 && l.wig16);
                 for (int src : {l.src_a, l.src_b}) {
                     if (src < 0) continue;
                     const LayerPlan& sp = P.lp[src];
@@ -912,8 +926,8 @@ static int build_plan(ry_net* net, Plan& P) {
                 }
                 if (l.src_a < 0) want16 = false;
                 if (want16) {
-                    lp.path = PATH_IGEMM_BF16;
-                    choose_igemm(l, M, t.nphases, t.ntaps * (l.cin() / 64), &lp.tile, &lp.splits, &lp.kg, true);
+                    lp.path = PATH_IGEMM_BF16; lp.x3 = x3;
+                    choose_igemm(l, M, t.nphases, t.ntaps * ((x3 ? 3 : 1) * l.cin() / 64), &lp.tile, &lp.splits, &lp.kg, true);
                 } else {
                     choose_igemm(l, M, t.nphases, nk, &lp.tile, &lp.splits, &lp.kg);
                 }
@@ -933,7 +947,8 @@ static int build_plan(ry_net* net, Plan& P) {
         }
     }
     // bf16 mode: which copies of each activation are needed (fp32 for fp32 consumers and the caller, bf16 for bf16 consumers)
-    if (nd == 2 && net->dtype == 1) {
+    if (nd == 2 && net->dtype != 0) {
+        const bool x3 = net->dtype == 2;
         std::vector<char> need32(16, 0), need16(16, 0);
         need32[15] = 1;
         for (int i = 0; i < 16; ++i)
@@ -942,9 +957,10 @@ static int build_plan(ry_net* net, Plan& P) {
         for (int i = 0; i < 16; ++i) {
             LayerPlan& lp = P.lp[i];
             lp.w32 = need32[i] || lp.path == PATH_DIRECT || lp.path == PATH_LAST; lp.w16 = need16[i];
+            lp.o16x3 = x3;
             if (lp.w16) {
                 float* q = nullptr;
-                RY_TRY(alloc_ztail(net->ctx, P.arena, &q, ((size_t)B * lp.Ho * lp.Wo * net->layers[i].cout + 1) / 2));
+                RY_TRY(alloc_ztail(net->ctx, P.arena, &q, ((size_t)B * lp.Ho * lp.Wo * net->layers[i].cout * (x3 ? 2 : 1) + 1) / 2));
                 lp.out16 = reinterpret_cast<unsigned short*>(q);
             }
         }
@@ -1134,6 +1150,7 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_LDSDMA")) g_ldsdma = atoi(e);
     if (const char* e = getenv("RY_KGROUPS")) g_kgroups = atoi(e);
     if (const char* e = getenv("RY_PATCH")) g_patch = atoi(e);
+    if (const char* e = getenv("RY_X3_MINM")) g_x3_min_m = atoi(e);
     if (const char* e = getenv("RY_XCD_GROUPS")) g_xcd_groups = atoi(e);
     if (const char* e = getenv("RY_S1_WGS")) g_s1_wgs = atoi(e);
     if (const char* e = getenv("RY_S1_MAXS")) g_s1_maxs = atoi(e);
@@ -1283,10 +1300,33 @@ static unsigned short host_f2bf(float f) {
     return (unsigned short)(u >> 16);
 }
 
+static inline float host_bf2f(unsigned short h) { const unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// Split-bf16 filters of one layer from its fp32 fragment-order blocks (wig layout): the K axis of each source (C channels) becomes
+// [W_hi | W_hi | W_lo] (3 C), matching the activations' [x_hi | x_lo | x_hi]: the kernel's plain bf16 contraction over that axis is
+// x_hi W_hi + x_lo W_hi + x_hi W_lo.  hi = bf16(w), lo = bf16(w - hi), both RNE.
+static void build_wigx3(const Layer& l, const std::vector<float>& w32, std::vector<unsigned short>& out) {
+    const TapTable t = make_taps(l);
+    const int C = l.cin(), N = l.cout, K3 = 3 * C;
+    const size_t outer = (size_t)t.nphases * (N / 64) * t.ntaps;
+    out.assign(outer * (size_t)K3 * 64, 0);
+    for (size_t o = 0; o < outer; ++o)
+        for (int kk = 0; kk < K3; ++kk) {
+            int seg, c;
+            if (kk < 3 * l.cin_a) { seg = kk / l.cin_a; c = kk % l.cin_a; }
+            else { const int k2 = kk - 3 * l.cin_a; seg = k2 / l.cin_b; c = l.cin_a + k2 % l.cin_b; }
+            for (int nl = 0; nl < 64; ++nl) {
+                const float w = w32[(o * (C / 32) + c / 32) * 2048 + wig_inblock(nl, c % 32)];
+                const unsigned short hi = host_f2bf(w);
+                out[(o * (K3 / 64) + kk / 64) * 4096 + wig16_inblock(nl, kk % 64)] = seg == 2 ? host_f2bf(w - host_bf2f(hi)) : hi;
+            }
+        }
+}
+
 int ry_net_set_dtype(ry_net* net, int dtype) {
     if (!net) return fail(RY_EINVAL, "null argument");
-    if (dtype != 0 && dtype != 1) return fail(RY_EINVAL, "dtype must be 0 (fp32) or 1 (bf16 operands, fp32 accumulate)");
-    if (dtype == 1 && net->desc.ndim != 2) return fail(RY_EINVAL, "the bf16 variant exists for the stage-2 predictor only");
+    if (dtype < 0 || dtype > 2) return fail(RY_EINVAL, "dtype must be 0 (fp32), 1 (bf16 operands, fp32 accumulate) or 2 (split-bf16: three bf16 products per fp32 product, fp32 accumulate)");
+    if (dtype != 0 && net->desc.ndim != 2) return fail(RY_EINVAL, "the bf16 variants exist for the stage-2 predictor only");
     ry_ctx* ctx = net->ctx;
     RT_TRY(rt::set_device(ctx->device));
     RT_TRY(rt::stream_sync(net->stream));
@@ -1311,6 +1351,24 @@ int ry_net_set_dtype(ry_net* net, int dtype) {
             RT_TRY(rt::h2d(d, w16.data(), n * sizeof(unsigned short), ctx->stream));
             RT_TRY(rt::stream_sync(ctx->stream));
             l.wig16 = d;
+        }
+    }
+    if (dtype == 2) {
+        if (const char* e = getenv("RY_X3_MINM")) g_x3_min_m = atoi(e);      // read again here so that a test / sweep can move it per call
+        for (Layer& l : net->layers) {
+            if (!l.wig || l.wigx3 || l.cin_a % 64 != 0 || l.cin_b % 64 != 0) continue;
+            const TapTable t = make_taps(l);
+            const size_t n = (size_t)t.nphases * l.cout * t.ntaps * l.cin();
+            std::vector<float> w32(n);
+            RT_TRY(rt::d2h(w32.data(), l.wig, n * sizeof(float), ctx->stream));
+            RT_TRY(rt::stream_sync(ctx->stream));
+            std::vector<unsigned short> wx;
+            build_wigx3(l, w32, wx);
+            float* d = nullptr;
+            RY_TRY(net->weights.alloc(&d, (wx.size() + 1) / 2));
+            RT_TRY(rt::h2d(d, wx.data(), wx.size() * sizeof(unsigned short), ctx->stream));
+            RT_TRY(rt::stream_sync(ctx->stream));
+            l.wigx3 = d;
         }
     }
     net->dtype = dtype;
@@ -1610,8 +1668,9 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
     const bool k3 = !transposed && k == 3 && stride == 1 && pad == 1;
     if (path == PATH_FIRST && !(k3 && Cin == 1 && Cout % 4 == 0)) return fail(RY_EINVAL, "'first' path is the 1 -> N (N %% 4 == 0) 3x3 layer");
     if (path == PATH_LAST && !(k3 && Cout == 1 && Cin % 128 == 0)) return fail(RY_EINVAL, "'last' path is the C -> 1 (C %% 128 == 0) 3x3 layer");
-    if (path == PATH_IGEMM_BF16 && !(l.wig && Cin % 64 == 0)) return fail(RY_EINVAL, "bf16 implicit-GEMM path needs Cin %% 64 == 0 and Cout %% 64 == 0");
+    if ((path == PATH_IGEMM_BF16 || path == PATH_IGEMM_X3) && !(l.wig && Cin % 64 == 0)) return fail(RY_EINVAL, "bf16 implicit-GEMM path needs Cin %% 64 == 0 and Cout %% 64 == 0");
     lp.path = path ? path : (l.wig ? PATH_IGEMM : PATH_DIRECT);
+    if (path == PATH_IGEMM_X3) { lp.path = PATH_IGEMM_BF16; lp.x3 = true; }
     const size_t out_elems = (size_t)B * lp.Ho * lp.Wo * Cout;
     lp.splits = 1;
     lp.last_rows = lp.Ho; lp.last_cols = lp.Wo; lp.last_exp = 0;
@@ -1626,8 +1685,16 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
         if ((tile == TILE_256x64 || tile == TILE_128x64) ? Cout % 64 : (tile != 0 && Cout % 128)) return fail(RY_EINVAL, "tile does not divide Cout");
         const bool op16 = lp.path == PATH_IGEMM_BF16;
         if (op16 && (tile == TILE_256x64 || tile == TILE_256x128)) return fail(RY_EINVAL, "no bf16 instantiation of that tile");
-        choose_igemm(l, M, t.nphases, t.ntaps * (Cin / (op16 ? 64 : 32)), &lp.tile, &lp.splits, &lp.kg, op16);
-        if (op16) {
+        choose_igemm(l, M, t.nphases, t.ntaps * (lp.x3 ? 3 * Cin / 64 : Cin / (op16 ? 64 : 32)), &lp.tile, &lp.splits, &lp.kg, op16);
+        if (lp.x3) {
+            std::vector<float> w32;
+            relayout_igemm(l, Wt, w32);
+            std::vector<unsigned short> wx;
+            build_wigx3(l, w32, wx);
+            RY_TRY(arena.alloc(&l.wigx3, (wx.size() + 1) / 2));
+            RT_TRY(rt::h2d(l.wigx3, wx.data(), wx.size() * sizeof(unsigned short), ctx->stream));
+            RT_TRY(rt::stream_sync(ctx->stream));
+        } else if (op16) {
             // bf16 filters of this single layer
             const size_t n = (size_t)t.nphases * Cout * t.ntaps * Cin;
             std::vector<float> w32;
@@ -1666,10 +1733,18 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
     } else if (lp.path == PATH_IGEMM_BF16) {
         // the bf16 kernel reads bf16 activations (in a predictor the producing layer writes them): round the input here
         const size_t nx = (size_t)B * H * Wd * Cin;
-        std::vector<unsigned short> x16(nx);
-        for (size_t q = 0; q < nx; ++q) x16[q] = host_f2bf(x[q]);
-        RT_TRY(rt::dmemset(dx, 0, (nx + ZTAIL) * sizeof(float), ctx->stream));      // the bf16 data ends half way: zero tail right behind it
-        RT_TRY(rt::h2d(dx, x16.data(), nx * sizeof(unsigned short), ctx->stream));
+        std::vector<unsigned short> x16(lp.x3 ? 2 * nx : nx);
+        if (lp.x3) {                                   // split-bf16 sources: [pixel][hi (Cin) | lo (Cin)]
+            for (size_t q = 0; q < nx; ++q) {
+                const unsigned short hi = host_f2bf(x[q]);
+                const size_t pix = q / Cin, c = q % Cin;
+                x16[pix * 2 * Cin + c] = hi; x16[pix * 2 * Cin + Cin + c] = host_f2bf(x[q] - host_bf2f(hi));
+            }
+        } else {
+            for (size_t q = 0; q < nx; ++q) x16[q] = host_f2bf(x[q]);
+        }
+        RT_TRY(rt::dmemset(dx, 0, (nx + ZTAIL) * sizeof(float), ctx->stream));      // the bf16 data ends half way (split-bf16: at the end): zero tail right behind it
+        RT_TRY(rt::h2d(dx, x16.data(), x16.size() * sizeof(unsigned short), ctx->stream));
         RT_TRY(rt::stream_sync(ctx->stream));
         RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Cin, nullptr, 0, 0.2f));
     } else {

@@ -87,7 +87,7 @@ class Context(object):
         y = numpy.empty((B, max(Ho, 0), max(Wo, 0), Cout), dtype=numpy.float32)
         bnv = None if bn is None else numpy.ascontiguousarray(numpy.concatenate([numpy.ravel(v) for v in bn]), dtype=numpy.float32)
         bv = None if b is None else numpy.ascontiguousarray(b, dtype=numpy.float32)
-        pth = {'auto': 0, 'igemm': 1, 'direct': 2, 'first': 3, 'last': 4, 'igemm_bf16': 5}[path]
+        pth = {'auto': 0, 'igemm': 1, 'direct': 2, 'first': 3, 'last': 4, 'igemm_bf16': 5, 'igemm_x3': 6}[path]
         self.lib.check(self.lib.dll.ry_conv2d(self.handle, _lib._fptr(x), B, H, Wd, Cin, _lib._fptr(W), _lib._fptr(bv), _lib._fptr(bnv),
                                               Cout, k, stride, pad, int(bool(transposed)), _lib.ACTS[act], pth, _lib.TILES[tile],
                                               int(splits), _lib._fptr(y)))
@@ -165,8 +165,10 @@ class Net(object):
         self.handle = h
 
     def set_dtype(self, dtype: str):
-        """'f32' (exact fp32 MFMA, default) or 'bf16' (stage-2 only: bf16 operands, fp32 accumulate -- BASELINE config #5)."""
-        self.ctx.lib.check(self.ctx.lib.dll.ry_net_set_dtype(self.handle, {'f32': 0, 'bf16': 1}[dtype]))
+        """'f32' (exact fp32 MFMA, default), 'bf16' (stage-2 only: bf16 operands, fp32 accumulate -- BASELINE config #5) or
+        'bf16x3' (stage-2 only: every fp32 product as three bf16 products hi*hi + lo*hi + hi*lo on the bf16 matrix pipe, fp32
+        accumulate -- fp32-class results)."""
+        self.ctx.lib.check(self.ctx.lib.dll.ry_net_set_dtype(self.handle, {'f32': 0, 'bf16': 1, 'bf16x3': 2}[dtype]))
 
     def close(self):
         if self.handle is not None and self.ctx.handle is not None and self.ctx.pid == os.getpid():

@@ -109,6 +109,38 @@ def run_conv2d_bf16(ctx, rng, case, bn_params):
     return y, outs[0], outs[1]
 
 
+def bf16_split(a):
+    """float32 -> (hi, lo) with hi = bf16(a), lo = bf16(a - hi): the operands of the split-bf16 ('bf16x3') mode."""
+    hi = bf16_round(a)
+    return hi, bf16_round(numpy.asarray(a, dtype=numpy.float32) - hi)
+
+
+# split-bf16 implicit GEMM (dtype 'bf16x3'): the bf16 cases (K axis three times as long) + odd chunk counts per source
+CONV2D_X3_CASES = CONV2D_BF16_CASES + [
+    (1, 12, 16, 192, 128, 4, 2, 1, True, 'relu', '96x128k2', 1),           # deconvolution patches: 9 chunks in K groups of 4 + 5
+    (1, 16, 32, 64, 128, 4, 2, 1, False, 'lrelu', '64x128', 3),            # convolution patches: 12 (chunk, parity) units over 3 external splits
+    (1, 6, 8, 128, 128, 3, 1, 1, False, 'relu', '32x128', 4),              # gather variant, 9 taps x 6 chunks over 4 splits
+]
+
+
+def run_conv2d_x3(ctx, rng, case, bn_params):
+    """-> (y, float64 model of the kernel: x_hi w_hi + x_lo w_hi + x_hi w_lo, float64 oracle on the fp32 operands)"""
+    B, H, W_, Cin, Cout, k, s, p, tr, act, tile, splits = case
+    x = rng.normal(size=(B, H, W_, Cin)).astype('f4')
+    Wt = rng.normal(0, 0.1, size=(Cin, Cout, k, k) if tr else (Cout, Cin, k, k)).astype('f4')
+    b = rng.normal(0, 0.1, Cout).astype('f4')
+    bn = bn_params(rng, Cout)
+    y = ctx.conv2d(x, Wt, b, bn, stride=s, pad=p, transposed=tr, act=act, path='igemm_x3', tile=tile, splits=splits)
+    f = (lambda xx, ww, bb: ops.deconv_nd(xx, ww, bb, stride=s, pad=p)) if tr else (lambda xx, ww, bb: ops.conv_nd(xx, ww, bb, stride=s, pad=p))
+    (xh, xl), (wh, wl) = bf16_split(x), bf16_split(Wt)
+    t = lambda a: a.transpose(0, 3, 1, 2).astype('f8')
+    zero = numpy.zeros_like(b, dtype='f8')
+    r3 = f(t(xh), wh.astype('f8'), b.astype('f8')) + f(t(xl), wh.astype('f8'), zero) + f(t(xh), wl.astype('f8'), zero)
+    r = f(t(x), Wt.astype('f8'), b.astype('f8'))
+    fin = lambda q: ops.apply_act(ops.batch_norm_inference(q, *bn), act).transpose(0, 2, 3, 1)
+    return y, fin(r3), fin(r)
+
+
 def run_conv1d(ctx, rng, case, bn_params):
     B, L, Cin, Cout, k, s, p, d, tr, act, splits = case
     x = rng.normal(size=(B, L, Cin)).astype('f4')

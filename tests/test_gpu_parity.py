@@ -39,6 +39,15 @@ def test_conv2d_bf16_gpu(gpu_ctx, case):
     assert rel_max(y, r32) < 2e-2
 
 
+@pytest.mark.parametrize('case', cases.CONV2D_X3_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_x3_gpu(gpu_ctx, case):
+    """split-bf16 implicit GEMM (dtype 'bf16x3'): x w ~ x_hi w_hi + x_lo w_hi + x_hi w_lo on v_mfma_f32_32x32x16_bf16, fp32
+    accumulate -- against the float64 model of exactly that sum and against the fp32-operand oracle (north-star bar 1e-4)."""
+    y, r3, r = cases.run_conv2d_x3(gpu_ctx, numpy.random.default_rng(17), case, bn_params)
+    assert rel_max(y, r3) < 1e-5
+    assert rel_max(y, r) < 2e-5
+
+
 def test_mfma_fragment_map_is_transpose_detecting(gpu_ctx):
     """Asymmetric 1x1 'conv' = plain GEMM with A = identity rows: catches a swapped C/D row/col map."""
     Cin, Cout = 32, 128
@@ -162,6 +171,30 @@ def test_stage2_syn64_bf16_variant(gpu_ctx):
     print('stage-2 log-spectrum error vs fp32 oracle: fp32 path %.2e, bf16 path %.2e' % (e32, e16))
     assert e32 < cases.TOL
     assert 1e-5 < e16 < BF16_TOL, e16
+    net.close()
+
+
+def test_stage2_syn64_x3_variant(gpu_ctx):
+    """split-bf16 ('bf16x3') stage-2 at the BASELINE config #3 window (300 frames): three bf16 products per fp32 product on the
+    bf16 matrix pipe.  The mode has to stay inside the SAME parity bar as the fp32 path (1e-4, cases.TOL); measured ~2e-6."""
+    (_, _), (d2, P2) = synth.model_params('SYN-64')
+    net = engine.Net(gpu_ctx, d2, flatten_params(d2, P2), width=synth.FFT_BINS - 1)
+    t2 = torch_ref.TorchUNet(P2)
+    sp = synth.stage2_input(300)[0]
+    y32 = net.convert(sp)
+    net.set_dtype('bf16x3')
+    y3 = net.convert(sp)
+    names = [q['name'] for q in net.profile(1, 384, 1)]
+    assert sum(n.startswith('ry_igemm_ldsdma<') and n[:-1].split(',')[5] == 'true' for n in names) >= 8, names   # the MFMA-bound layers did take the bf16 pipe
+    net.set_dtype('f32')
+    assert numpy.array_equal(net.convert(sp), y32), 'switching back restores the exact fp32 path'
+    r = torch_ref.stage2_convert(t2, sp)
+    e32 = rel_max(numpy.log(y32), numpy.log(r))
+    e3 = rel_max(numpy.log(y3), numpy.log(r))
+    print('stage-2 log-spectrum error vs fp32 oracle: fp32 path %.2e, split-bf16 path %.2e; sp max rel %.2e' % (e32, e3, float(numpy.abs(y3 / r - 1).max())))
+    assert e32 < cases.TOL
+    assert e3 < 2e-5, e3                   # 5 x under the 1e-4 bar
+    assert float(numpy.abs(y3 / r - 1).max()) < cases.TOL
     net.close()
 
 

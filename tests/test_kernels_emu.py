@@ -33,6 +33,14 @@ def test_conv2d_bf16_emu(emu_ctx, case):
     assert rel_max(y, r32) < 2e-2          # and the price of bf16 operands against the fp32 oracle
 
 
+@pytest.mark.parametrize('case', cases.CONV2D_X3_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_x3_emu(emu_ctx, case):
+    """split-bf16 implicit GEMM: [hi | lo] sources, K axis [hi | lo | hi] against filters [hi | hi | lo]."""
+    y, r3, r = cases.run_conv2d_x3(emu_ctx, numpy.random.default_rng(17), case, bn_params)
+    assert rel_max(y, r3) < 1e-5           # exact model of the kernel up to fp32 accumulation order (K is 3 x 16 x Cin terms)
+    assert rel_max(y, r) < 1e-5            # and against the fp32-operand oracle: the dropped lo*lo term and the 16-bit split
+
+
 NETS = [
     # ndim, in, out, base, e, T, width, batch
     (1, 9, 9, 8, 8, 128, 1, 1),
@@ -123,3 +131,31 @@ def test_convert_edge_inputs_emu(emu_ctx):
     assert numpy.isnan(n2.convert(sp)).any()
     assert numpy.isfinite(n2.convert(numpy.full((5, 129), 1e-3, 'f4'))).all()      # ... and the net is still usable afterwards
     n1.close(); n2.close()
+
+
+def test_stage2_x3_pipeline_emu(emu_ctx, monkeypatch):
+    """split-bf16 ('bf16x3') mode of the stage-2 predictor: implicit-GEMM layers read [hi | lo] bf16 activations written by
+    their producers (first layer, implicit-GEMM epilogue, split-K reduce) and run three bf16 products per fp32 product.
+    Results must stay inside the fp32 parity bar (1e-4); layers under RY_X3_MINM rows stay on the exact fp32 kernel."""
+    d = NetDesc(2, 1, 1, 64, 3)
+    P = synthetic_params(d, 421, bias_std=0.05)
+    net = engine.Net(emu_ctx, d, flatten_params(d, P), width=16)
+    x = numpy.random.default_rng(22).normal(size=(1, 16, 16)).astype('f4')
+    ref = cases.oracle_forward(d, P, x)
+    y32 = net.forward(x)
+    assert rel_max(y32, ref) < cases.TOL
+    monkeypatch.setenv('RY_X3_MINM', '32')            # encoder c1 (8 x 8 rows) and decoder c5 / c6 split, encoder c2 (4 x 4) stays fp32
+    net.set_dtype('bf16x3')
+    y3 = net.forward(x)
+    st = net.profile(1, 16, 1)
+    split = [q['layer'] for q in st if q['name'].startswith('ry_igemm_ldsdma<') and q['name'][:-1].split(',')[5] == 'true']
+    exact = [q['layer'] for q in st if q['name'].startswith('ry_igemm_ldsdma<') and q['name'][:-1].split(',')[5] == 'false']
+    assert 'encoder/c1' in split and 'decoder/c6' in split and 'encoder/c2' in exact, (split, exact)
+    assert not numpy.array_equal(y3, y32)
+    assert rel_max(y3, ref) < 2e-5, rel_max(y3, ref)
+    monkeypatch.setenv('RY_X3_MINM', '1')             # every implicit-GEMM layer on the split path (mixed-format copies gone)
+    net.set_dtype('bf16x3')
+    assert rel_max(net.forward(x), ref) < 2e-5
+    net.set_dtype('f32')
+    assert numpy.array_equal(net.forward(x), y32)     # the exact path comes back bit for bit
+    net.close()
