@@ -6,7 +6,7 @@ import sys
 
 
 def main(db_glob, out_path, title):
-    db = sorted(glob.glob(db_glob))[0]
+    db = sorted(glob.glob(db_glob, recursive=True))[0]
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute('select name, total_calls, total_duration, average, percentage from top_kernels'))
     with open(out_path, 'w') as f:
