@@ -911,6 +911,11 @@ static int build_plan(ry_net* net, Plan& P) {
                 const int nk = t.ntaps * (l.cin() / 32);
                 lp.path = PATH_IGEMM; lp.tile = 0; lp.splits = 0; lp.kg = 0;
                 { lp.tile = g_force[i][0]; lp.splits = g_force[i][1]; lp.kg = g_force[i][2]; }
+                if (lp.tile != 0) {                                  // RY_PLAN: refuse a tile that does not divide the output channels
+                    int fbm, fbn; tile_dims(lp.tile, &fbm, &fbn);
+                    if (l.cout % fbn != 0) return fail(RY_EINVAL, "RY_PLAN: tile %dx%d does not divide the %d output channels of %s", fbm, fbn, l.cout, l.name);
+                    if (net->dtype != 0 && fbm > 128) return fail(RY_EINVAL, "RY_PLAN: no bf16 instantiation of the %dx%d tile (%s)", fbm, fbn, l.name);
+                }
                 // bf16 mode: a layer runs on bf16 operands when its filters were converted and every producer it reads can
                 // write a bf16 copy of its output (the first layer, implicit-GEMM layers and their reduce kernels can)
                 // split-bf16 mode: the same, for the layers with enough rows to be bound by the matrix pipe (the weight-streaming
@@ -1144,6 +1149,23 @@ int ry_device_count(void) {
 }
 
 // process-wide A/B and diagnostic switches, read when a context is created
+// RY_PLAN="layer:tile:splits:kgroups,...": read when a context is created and again at every ry_net_set_dtype (which drops
+// the launch plans), so that one process can sweep plans (scripts/gpu_x3_plansweep.py)
+static int read_plan_env() {
+    memset(g_force, 0, sizeof(g_force));
+    if (const char* e = getenv("RY_PLAN")) {
+        for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
+            int i = -1, t = 0, sp = 0, kg = 0;
+            if (sscanf(q, "%d:%d:%d:%d", &i, &t, &sp, &kg) >= 2 && i >= 0 && i < 16 && t >= 0 && t <= TILE_256x128 && sp >= 0 && kg >= 0 && kg <= 2) {
+                g_force[i][0] = t; g_force[i][1] = sp; g_force[i][2] = kg;
+            } else {
+                return fail(RY_EINVAL, "RY_PLAN: expected layer:tile:splits:kgroups[,...]");
+            }
+        }
+    }
+    return RY_OK;
+}
+
 static int read_env_switches() {
     if (const char* e = getenv("RY_ILV")) g_ilv = atoi(e);
     if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
@@ -1164,18 +1186,7 @@ static int read_env_switches() {
     }
 #endif
     if (const char* e = getenv("RY_TILE64")) g_tile64 = atoi(e) == 256 ? TILE_256x64 : TILE_128x64;
-    memset(g_force, 0, sizeof(g_force));
-    if (const char* e = getenv("RY_PLAN")) {
-        for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
-            int i = -1, t = 0, sp = 0, kg = 0;
-            if (sscanf(q, "%d:%d:%d:%d", &i, &t, &sp, &kg) >= 2 && i >= 0 && i < 16 && t >= 0 && t <= TILE_256x128 && sp >= 0 && kg >= 0 && kg <= 2) {
-                g_force[i][0] = t; g_force[i][1] = sp; g_force[i][2] = kg;
-            } else {
-                return fail(RY_EINVAL, "RY_PLAN: expected layer:tile:splits:kgroups[,...]");
-            }
-        }
-    }
-    return RY_OK;
+    return read_plan_env();
 }
 
 int ry_init(int device, ry_ctx** out) {
@@ -1353,6 +1364,7 @@ int ry_net_set_dtype(ry_net* net, int dtype) {
             l.wig16 = d;
         }
     }
+    RY_TRY(read_plan_env());
     if (dtype == 2) {
         if (const char* e = getenv("RY_X3_MINM")) g_x3_min_m = atoi(e);      // read again here so that a test / sweep can move it per call
         for (Layer& l : net->layers) {
