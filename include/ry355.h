@@ -136,6 +136,8 @@ int ry_debug_igemm_phases(ry_ctx* ctx, unsigned long long* out8);
  * one sub-pixel phase), Cout output channels, `nphases` phases (4 for the k4s2 deconvolution, else 1) and K = 32 * nk:
  * tile code (see ry_conv2d), external split-K count, K groups per workgroup, estimated microseconds.  No device work. */
 int ry_debug_plan_igemm(int M, int Cout, int nphases, int nk, int* tile, int* splits, int* kgroups, double* est_us);
+/* the same for the bf16 (mode 1) / split-bf16 (mode 2) kernels (nk in 64-channel chunks; non-zero tile / splits / kgroups on entry are kept) */
+int ry_debug_plan_igemm_bf16(int mode, int M, int Cout, int nphases, int nk, int* tile, int* splits, int* kgroups, double* est_us);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     'ry_init', 'ry_shutdown', 'ry_sync', 'ry_stream', 'ry_device_count', 'ry_last_error',
     'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_set_dtype', 'ry_net_forward',
     'ry_ac_convert', 'ry_sr_convert', 'ry_conv1d', 'ry_conv2d',
-    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_debug_igemm_phases', 'ry_debug_plan_igemm',
+    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_debug_igemm_phases', 'ry_debug_plan_igemm', 'ry_debug_plan_igemm_bf16',
     'ry_vc_create', 'ry_vc_destroy', 'ry_vc_convert', 'ry_mc2sp',
 )
 

@@ -540,6 +540,12 @@ static const char* tile_name(int tile, int kg, bool bf16, int patch) {
 // buffer, limited to 3 by its VGPR budget.
 static thread_local double g_plan_peak = 157.3e6;   // flop per microsecond the planner prices the main loop at (fp32 MFMA peak; bf16: see choose_igemm)
 static thread_local int g_plan_ck = 32;             // input channels per K chunk of the kernel being planned
+// split-bf16 kernels (measured, profiles/r01_n_x3_plansweep_n300.txt): the main-loop rate the planner prices them at (three times
+// the K of the bf16 mode per tile: the fixed costs weigh less, 128x128 tiles reach 730-800 TF of bf16 products = 0.7 x 1150),
+// and the price of two K groups in one 512-thread workgroup against two 256-thread workgroups on the same CU (the GEMM alone
+// ran 10-17 % slower: 69 vs 59 us on decoder c3, 73 vs 66 us on encoder c1).  RY_PLAN_X3_PEAK (TFLOP/s) / RY_PLAN_X3_KG2 override.
+static double g_x3_peak = 1.15e9, g_x3_kg2 = 1.15;
+static thread_local double g_plan_kg2 = 1.0;        // factor on the main loop of a two-K-group workgroup
 
 static int tile_occ(int tile, int kg) {
     int bm, bn; tile_dims(tile, &bm, &bn);
@@ -569,6 +575,7 @@ static double est_time(long blocks, int bm, int bn, int s, int occ, int kg, int 
     const double tile_us = 2.0 * bm * bn * ((double)g_plan_ck * nk) / (g_plan_peak / 256.0);   // one tile on one CU at the peak
     const double w = tile_us / (double)(s * kg);                              // work of one four-wave group
     double t = (double)full * occ * kg * w / cu_rate(occ * kg) + (rem ? (double)rem * kg * w / cu_rate((int)rem * kg) : 0.0);
+    if (kg > 1) t *= g_plan_kg2;
     t += 4.0 + (double)M * N * 4.0 / 5.0e6;                                     // launch + ramp, output stores at ~5 TB/s (exposed: one round)
     if (s > 1) t += 5.0 + (2.0 * s) * M * N * 4.0 / 4.0e6;                     // s slab writes + s slab reads at ~4 TB/s, reduce launch
     if (kg > 1) t += 1.0;                                                       // in-LDS sum, half of the waves idle in the epilogue
@@ -588,10 +595,11 @@ static int best_split(long blocks, int bm, int bn, int nk, bool tinyM, int occ, 
     return best;
 }
 
-static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits, int* kg, bool bf16 = false) {
+static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits, int* kg, int bf16 = 0 /* 1 bf16, 2 split-bf16 */) {
     // bf16: 64 channels per chunk; the kernel is bound by the operand movement, not the matrix pipe: price
     // the main loop at the measured rate so that the fixed costs (launch, stores, slabs) weigh as they do in the measurements
-    g_plan_peak = bf16 ? 0.86e9 : 157.3e6; g_plan_ck = bf16 ? 64 : 32;   // 128x128 bf16 tiles measured ~620 TF = 0.72 x 860
+    g_plan_peak = bf16 == 2 ? g_x3_peak : bf16 ? 0.86e9 : 157.3e6; g_plan_ck = bf16 ? 64 : 32;   // 128x128 bf16 tiles measured ~620 TF = 0.72 x 860
+    g_plan_kg2 = bf16 == 2 ? g_x3_kg2 : 1.0;
     // MFMA-bound layers: every CU should hold a full set of co-resident wave groups for the whole launch.  Candidate
     // M-tiles 128 / 96 / 64 (N-tile 128), with one or two K groups per workgroup and the best external split-K, are
     // compared by estimated time.
@@ -932,7 +940,7 @@ static int build_plan(ry_net* net, Plan& P) {
                 if (l.src_a < 0) want16 = false;
                 if (want16) {
                     lp.path = PATH_IGEMM_BF16; lp.x3 = x3;
-                    choose_igemm(l, M, t.nphases, t.ntaps * ((x3 ? 3 : 1) * l.cin() / 64), &lp.tile, &lp.splits, &lp.kg, true);
+                    choose_igemm(l, M, t.nphases, t.ntaps * ((x3 ? 3 : 1) * l.cin() / 64), &lp.tile, &lp.splits, &lp.kg, x3 ? 2 : 1);
                 } else {
                     choose_igemm(l, M, t.nphases, nk, &lp.tile, &lp.splits, &lp.kg);
                 }
@@ -1173,6 +1181,8 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_KGROUPS")) g_kgroups = atoi(e);
     if (const char* e = getenv("RY_PATCH")) g_patch = atoi(e);
     if (const char* e = getenv("RY_X3_MINM")) g_x3_min_m = atoi(e);
+    if (const char* e = getenv("RY_PLAN_X3_PEAK")) g_x3_peak = atof(e) * 1e6;
+    if (const char* e = getenv("RY_PLAN_X3_KG2")) g_x3_kg2 = atof(e);
     if (const char* e = getenv("RY_XCD_GROUPS")) g_xcd_groups = atoi(e);
     if (const char* e = getenv("RY_S1_WGS")) g_s1_wgs = atoi(e);
     if (const char* e = getenv("RY_S1_MAXS")) g_s1_maxs = atoi(e);
@@ -1594,6 +1604,23 @@ int ry_debug_plan_igemm(int M, int Cout, int nphases, int nk, int* tile, int* sp
     return RY_OK;
 }
 
+// the same for the bf16 (mode 1) / split-bf16 (mode 2) kernels (nk counts 64-channel chunks: taps x Cin / 64, three times that in
+// split-bf16 mode); non-zero *tile / *splits / *kgroups on entry are kept (the estimate of a given plan)
+int ry_debug_plan_igemm_bf16(int mode, int M, int Cout, int nphases, int nk, int* tile, int* splits, int* kgroups, double* est_us) {
+    if (mode != 1 && mode != 2) return fail(RY_EINVAL, "mode must be 1 (bf16) or 2 (split-bf16)");
+    if (!tile || !splits || !kgroups) return fail(RY_EINVAL, "null argument");
+    if (M < 1 || Cout < 64 || Cout % 64 != 0 || nphases < 1 || nk < 1) return fail(RY_EINVAL, "not an implicit-GEMM layer shape");
+    RY_TRY(read_env_switches());
+    Layer l; l.cout = Cout;
+    choose_igemm(l, M, nphases, nk, tile, splits, kgroups, mode);
+    if (est_us) {
+        int bm, bn; tile_dims(*tile, &bm, &bn);
+        *est_us = est_time((long)((M + bm - 1) / bm) * (Cout / bn) * nphases, bm, bn, *splits, tile_occ(*tile, *kgroups), *kgroups, M, Cout, nk)
+                  * (M > 64 && Cout % 128 == 0 ? (1.0 / bm + 1.0 / bn) * 64.0 : 1.0);
+    }
+    return RY_OK;
+}
+
 // diagnostics: read and reset the phase totals of the RY_TIMING=1 kernel variant (8 counters)
 int ry_debug_igemm_phases(ry_ctx* ctx, unsigned long long* out8) {
     if (!ctx || !out8) return fail(RY_EINVAL, "null argument");
@@ -1697,7 +1724,7 @@ int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const 
         if ((tile == TILE_256x64 || tile == TILE_128x64) ? Cout % 64 : (tile != 0 && Cout % 128)) return fail(RY_EINVAL, "tile does not divide Cout");
         const bool op16 = lp.path == PATH_IGEMM_BF16;
         if (op16 && (tile == TILE_256x64 || tile == TILE_256x128)) return fail(RY_EINVAL, "no bf16 instantiation of that tile");
-        choose_igemm(l, M, t.nphases, t.ntaps * (lp.x3 ? 3 * Cin / 64 : Cin / (op16 ? 64 : 32)), &lp.tile, &lp.splits, &lp.kg, op16);
+        choose_igemm(l, M, t.nphases, t.ntaps * (lp.x3 ? 3 * Cin / 64 : Cin / (op16 ? 64 : 32)), &lp.tile, &lp.splits, &lp.kg, lp.x3 ? 2 : (op16 ? 1 : 0));
         if (lp.x3) {
             std::vector<float> w32;
             relayout_igemm(l, Wt, w32);

@@ -42,13 +42,13 @@ for _ in range(2):
 lines.append('# split-bf16 plan sweep, SYN-64, %d frames (%d padded); microseconds per layer (GEMM + reduce launches), eager launches\n' % (N, T))
 lines.append('# planner total %.1f us\n' % (sum(q['ms'] for q in base) * 1e3))
 best_plan = []
-for layer in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14):
+for layer in (1, 2, 3, 4, 5, 10, 11, 12, 13, 14):
     t0, desc0, _ = layer_us('', layer)
     lines.append('%-11s planner            %8.2f  %s\n' % (NAMES[layer], t0, desc0))
     best = (t0, 'planner')
     for tile in ((5,) if cout[layer] % 128 else (1, 6, 3, 4)):
         for kg in (1, 2):
-            for sp in (1, 2, 3, 4, 6, 8, 16, 32):
+            for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32):
                 try:
                     t, desc, _ = layer_us('%d:%d:%d:%d' % (layer, tile, sp, kg), layer, 3)
                 except Exception as e:                      # an illegal combination is refused by the library, not run
@@ -57,7 +57,7 @@ for layer in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14):
                 lines.append('%-11s %-8s kg%d s%-3d %8.2f  %s\n' % (NAMES[layer], TILES[tile], kg, sp, t, desc))
                 if t < best[0]:
                     best = (t, '%d:%d:%d:%d' % (layer, tile, sp, kg))
-                if t > 3.0 * t0:
+                if sp >= 4 and t > 2.0 * t0:
                     break                                   # more splits only get worse from here
     lines.append('%-11s BEST %s %.2f us (planner %.2f)\n' % (NAMES[layer], best[1], best[0], t0))
     if best[1] != 'planner' and best[0] < 0.97 * t0:

@@ -87,6 +87,36 @@ def test_stage2_planner_picks_legal_launches(lib, frames, batch):
         assert e.value > 0.0
 
 
+@pytest.mark.parametrize('frames', [128, 384, 1024])
+@pytest.mark.parametrize('mode', [1, 2])
+def test_stage2_planner_picks_legal_launches_bf16(lib, frames, mode):
+    """The same for the bf16 (mode 1) and split-bf16 (mode 2: K three times as long) kernels: 64-channel chunks, tiles up to
+    128 rows only, and -- measured on MI355X -- the split-bf16 plans of the MFMA-bound layers keep one K group per workgroup."""
+    ch = [64, 128, 256, 512, 512, 512, 512, 512]
+    shapes = []
+    h, w = frames, 512
+    kmul = 3 if mode == 2 else 1
+    for i in range(1, 8):
+        h, w = h // 2, w // 2
+        shapes.append((h * w, ch[i], 1, kmul * 16 * ch[i - 1] // 64))
+    dec_in, dec_out = [512, 1024, 1024, 1024, 1024, 512, 256], [512, 512, 512, 512, 256, 128, 64]
+    for j in range(7):
+        shapes.append((h * w, dec_out[j], 4, kmul * 4 * dec_in[j] // 64))
+        h, w = h * 2, w * 2
+    f = lib.dll.ry_debug_plan_igemm_bf16
+    for M, N, nph, nk in shapes:
+        t, s, k, e = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        lib.check(f(mode, M, N, nph, nk, ctypes.byref(t), ctypes.byref(s), ctypes.byref(k), ctypes.byref(e)))
+        bm, bn = TILE_DIMS[t.value]
+        assert N % bn == 0 and bm <= 128
+        assert 1 <= s.value and k.value in (1, 2) and s.value * k.value <= nk
+        assert e.value > 0.0
+        t2, s2, k2 = ctypes.c_int(t.value), ctypes.c_int(s.value), ctypes.c_int(k.value)       # a given plan is kept as it is
+        lib.check(f(mode, M, N, nph, nk, ctypes.byref(t2), ctypes.byref(s2), ctypes.byref(k2), None))
+        assert (t2.value, s2.value, k2.value) == (t.value, s.value, k.value)
+    assert f(3, 100, 128, 1, 8, ctypes.byref(t), ctypes.byref(s), ctypes.byref(k), None) != 0
+
+
 def test_stage2_planner_rejects_non_igemm_shapes(lib):
     t, s, k = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.dll.ry_debug_plan_igemm(100, 48, 1, 8, ctypes.byref(t), ctypes.byref(s), ctypes.byref(k), None) != 0
