@@ -1055,6 +1055,7 @@ struct RySrLastParams {
     int rows_valid;             // rows >= rows_valid are padding and are not computed
     int out_cols;               // W, or W + 1 with the last bin repeated (pad mode 'edge')
     int do_exp;
+    int x3;                     // sources are split-bf16 copies [pixel][hi | lo] (rolling form only)
 };
 
 // Simple form: 32 lanes per output pixel, 9 taps gathered per pixel (any width).
@@ -1099,6 +1100,10 @@ RY_KERNEL(256) void ry_sr_last_gather(RySrLastParams p) {
 // lane = 4 channels.  Every input pixel vector of the 3 x 18 halo is loaded ONCE, multiplied by the three
 // kx taps of its row and accumulated into the outputs it touches; the 16 per-lane partial sums are then
 // reduced across the 32 lanes with a transposing (reduce-scatter) butterfly: 15 + 1 shuffles instead of 80.
+// X3 = true (split-bf16 mode): the two sources are the producers' split-bf16 copies [pixel][hi (Cs) | lo (Cs)] (ry_st4_bf16_x3) and a
+// lane rebuilds its four channels as hi + lo -- the same bytes per pixel as fp32, and neither producer has to write an fp32
+// copy for this layer alone.
+template <bool X3>
 RY_KERNEL(256, 2) void ry_sr_last(RySrLastParams p) {
     constexpr int SW = 16;
     const int l = (int)threadIdx.x & 31;
@@ -1112,8 +1117,21 @@ RY_KERNEL(256, 2) void ry_sr_last(RySrLastParams p) {
     const int b = (int)(ss / ((long long)strips * p.rows_valid));
     const int c = l * 4;
     const bool first = c < p.C1;
-    const float* src = first ? p.src1 + c : p.src2 + (c - p.C1);
     const int Cs = first ? p.C1 : p.C2;
+    const float* src = first ? p.src1 : p.src2;
+    const int cl = first ? c : c - p.C1;            // this lane's first channel inside its source
+    // four channels of pixel `px` of a source row: fp32 -> one 16-byte load; split-bf16 -> hi and lo halves, 8 bytes each
+    auto ldpx = [&](const float* row, int px) -> f32x4 {
+        if (X3) {
+            const unsigned short* q = reinterpret_cast<const unsigned short*>(row) + (size_t)px * (size_t)(2 * Cs) + cl;
+            const u16x4 h = *reinterpret_cast<const u16x4*>(q), lo = *reinterpret_cast<const u16x4*>(q + Cs);
+            f32x4 v;
+            v[0] = ry_bf2f(h[0]) + ry_bf2f(lo[0]); v[1] = ry_bf2f(h[1]) + ry_bf2f(lo[1]);
+            v[2] = ry_bf2f(h[2]) + ry_bf2f(lo[2]); v[3] = ry_bf2f(h[3]) + ry_bf2f(lo[3]);
+            return v;
+        }
+        return ry_ld4(row + (size_t)px * Cs + cl);
+    };
     float acc[SW + 2];                             // acc[j] = output column x0 - 1 + j (two halo slots are discarded)
 #pragma unroll
     for (int j = 0; j < SW + 2; ++j) acc[j] = 0.f;
@@ -1128,11 +1146,11 @@ RY_KERNEL(256, 2) void ry_sr_last(RySrLastParams p) {
             f32x4 w1 = ry_ld4(p.w + (size_t)(ky * 3 + 1) * 128 + c);
             f32x4 w2 = ry_ld4(p.w + (size_t)(ky * 3 + 2) * 128 + c);
             w0 *= rz; w1 *= rz; w2 *= rz;
-            const float* row = src + ((size_t)b * p.H + iyc) * p.W * Cs;
+            const float* row = src + ((size_t)b * p.H + iyc) * p.W * Cs;      // a split-bf16 pixel is 2 Cs bf16 = Cs floats too
             // interior columns x0 .. x0+SW-1 are always inside the image (W % SW == 0): no tests, loads batch freely
 #pragma unroll
             for (int j = 1; j <= SW; ++j) {
-                const f32x4 v = ry_ld4(row + (size_t)(x0 - 1 + j) * Cs);
+                const f32x4 v = ldpx(row, x0 - 1 + j);
                 // out[ox] += w[kx] . in[ox + kx - 1]  ->  input ix feeds ox = ix + 1 - kx, i.e. acc[j + 1 - kx]
                 acc[j + 1] += fmaf(v[3], w0[3], fmaf(v[2], w0[2], fmaf(v[1], w0[1], v[0] * w0[0])));
                 acc[j]     += fmaf(v[3], w1[3], fmaf(v[2], w1[2], fmaf(v[1], w1[1], v[0] * w1[0])));
@@ -1141,8 +1159,8 @@ RY_KERNEL(256, 2) void ry_sr_last(RySrLastParams p) {
             // the two halo columns x0-1 and x0+SW (zero outside the image)
             {
                 const bool lok = x0 > 0, rgt = x0 + SW < p.W;
-                const f32x4 vl = ry_ld4(row + (size_t)(lok ? x0 - 1 : x0) * Cs);
-                const f32x4 vr = ry_ld4(row + (size_t)(rgt ? x0 + SW : x0) * Cs);
+                const f32x4 vl = ldpx(row, lok ? x0 - 1 : x0);
+                const f32x4 vr = ldpx(row, rgt ? x0 + SW : x0);
                 const float zl = lok ? 1.f : 0.f, zr = rgt ? 1.f : 0.f;
                 acc[1]  += zl * fmaf(vl[3], w0[3], fmaf(vl[2], w0[2], fmaf(vl[1], w0[1], vl[0] * w0[0])));   // ix = x0-1 feeds ox = x0 via kx = 0
                 acc[SW] += zr * fmaf(vr[3], w2[3], fmaf(vr[2], w2[2], fmaf(vr[1], w2[1], vr[0] * w2[0])));   // ix = x0+SW feeds ox = x0+SW-1 via kx = 2

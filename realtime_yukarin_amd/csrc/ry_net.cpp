@@ -352,6 +352,7 @@ struct LayerPlan {
     bool o16x3 = false;                       // format of the out16 copy this layer writes: plain bf16 or split [hi | lo]
     float* slabs = nullptr;
     int last_rows = 0, last_cols = 0, last_exp = 0;   // PATH_LAST: fused exp / edge-pad / crop
+    bool last_x3 = false;                     // PATH_LAST in split-bf16 mode: reads the producers' [hi | lo] copies instead of fp32 ones
     double flops = 0, bytes = 0;
 };
 
@@ -505,7 +506,8 @@ static int g_ldsdma = 1;    // RY_LDSDMA=0: register-staged ry_igemm_f32 instead
 static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
 static unsigned long long* g_dbg = nullptr;
 static int g_force[16][3];   // RY_PLAN="layer:tile:splits:kgroups,...": tuning aid, fixes the stage-2 plan of single layers (0 = planner's choice)
-static int g_x3_min_m = 512;   // RY_X3_MINM: split-bf16 mode runs a layer on the bf16 pipe from this many GEMM rows (per phase) up
+static int g_x3_min_m = 128;   // RY_X3_MINM: split-bf16 mode runs a layer on the bf16 pipe from this many GEMM rows (per phase) up (measured at 300 frames: 1 / 32 / 64 / 128 / 512 / 2048 -> 0.861 / 0.865 / 0.867 / 0.864 vs 0.840 / 0.928 ms per step on two boxes; 128 beat 512 by 1 % in the same-box A/B)
+static int g_x3_last = 1;      // RY_X3_LAST=0: split-bf16 mode keeps fp32 copies for the last layer (A/B)
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
 // Kernel names as rocprofv3 prints them (template arguments, no spaces): bench.py matches them against profiles/*.
@@ -777,7 +779,8 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         }
     } else if (lp.path == PATH_FIRST) {
         RySrFirstParams p;
-        p.x = s1; p.w = l.wdir; p.scale = l.scale; p.shift = l.shift; p.out = lp.out; p.out16 = lp.w16 ? lp.out16 : nullptr;
+        p.x = s1; p.w = l.wdir; p.scale = l.scale; p.shift = l.shift; p.out16 = lp.w16 ? lp.out16 : nullptr;
+        p.out = (lp.w32 || !p.out16) ? lp.out : nullptr;          // split-bf16 mode: the fp32 copy only if a consumer reads it
         p.x3 = lp.o16x3 ? 1 : 0;
         p.B = B; p.H = lp.Hi; p.W = lp.Wi; p.N = l.cout; p.act = l.act; p.slope = slope;
         const long long total = (long long)B * lp.Hi * ((lp.Wi + 3) / 4) * (l.cout / 4);
@@ -795,8 +798,10 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         if (C1 + C2 == 128 && lp.Wi % 16 == 0) {
             const long long strips = (long long)B * p.rows_valid * (lp.Wi / 16);
             dim3 sg((unsigned)((strips + 7) / 8));
-            RY_TRY(Lc.begin("ry_sr_last", l.name, lp.flops, lp.bytes, sg));
-            RY_LAUNCH(ry_sr_last, sg, 256, Lc.stream, p);
+            RY_TRY(Lc.begin(lp.last_x3 ? "ry_sr_last<true>" : "ry_sr_last<false>", l.name, lp.flops, lp.bytes, sg));
+            p.x3 = lp.last_x3 ? 1 : 0;
+            if (lp.last_x3) RY_LAUNCH(ry_sr_last<true>, sg, 256, Lc.stream, p);
+            else RY_LAUNCH(ry_sr_last<false>, sg, 256, Lc.stream, p);
         } else {
             RY_TRY(Lc.begin("ry_sr_last_gather", l.name, lp.flops, lp.bytes, grid));
             RY_LAUNCH(ry_sr_last_gather, grid, 256, Lc.stream, p);
@@ -964,9 +969,23 @@ static int build_plan(ry_net* net, Plan& P) {
         const bool x3 = net->dtype == 2;
         std::vector<char> need32(16, 0), need16(16, 0);
         need32[15] = 1;
+        {   // split-bf16 mode: the last layer (rolling form) reads the [hi | lo] copies when both producers can write them, so
+            // that neither keeps an fp32 copy for this layer alone (encoder c0: 50 MB less to write per 384-frame window)
+            LayerPlan& ll = P.lp[15];
+            const Layer& l15 = net->layers[15];
+            bool ok = x3 && g_x3_last && ll.path == PATH_LAST && l15.cin() == 128 && ll.Wi % 16 == 0 && l15.src_a >= 0 && l15.src_b >= 0;
+            for (int src : {l15.src_a, l15.src_b}) {
+                if (!ok || src < 0) continue;
+                const LayerPlan& sp = P.lp[src];
+                const bool dma_kernel = sp.path == PATH_IGEMM_BF16 ||
+                                        (sp.path == PATH_IGEMM && g_ldsdma && !g_timing && sp.tile != TILE_256x64 && sp.tile != TILE_256x128);
+                if (sp.path != PATH_FIRST && !dma_kernel) ok = false;
+            }
+            ll.last_x3 = ok;
+        }
         for (int i = 0; i < 16; ++i)
             for (int src : {net->layers[i].src_a, net->layers[i].src_b})
-                if (src >= 0) (P.lp[i].path == PATH_IGEMM_BF16 ? need16 : need32)[src] = 1;
+                if (src >= 0) ((P.lp[i].path == PATH_IGEMM_BF16 || P.lp[i].last_x3) ? need16 : need32)[src] = 1;
         for (int i = 0; i < 16; ++i) {
             LayerPlan& lp = P.lp[i];
             lp.w32 = need32[i] || lp.path == PATH_DIRECT || lp.path == PATH_LAST; lp.w16 = need16[i];
@@ -1034,7 +1053,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
         if (nd == 1) {
             RY_TRY(launch_conv1d(Lc, l, lp, B, src1d_of(net, P, l.src_a), src1d_of(net, P, l.src_b), slope));
         } else {
-            const bool in16 = lp.path == PATH_IGEMM_BF16;       // bf16 consumers read the producers' bf16 copies
+            const bool in16 = lp.path == PATH_IGEMM_BF16 || lp.last_x3;       // bf16 consumers read the producers' bf16 copies
             const float* s1 = l.src_a < 0 ? (P.mode == 1 ? P.x_in : P.cur_in)
                                           : in16 ? reinterpret_cast<const float*>(P.lp[l.src_a].out16) : P.lp[l.src_a].out;
             const float* s2 = l.src_b < 0 ? nullptr : in16 ? reinterpret_cast<const float*>(P.lp[l.src_b].out16) : P.lp[l.src_b].out;
@@ -1181,6 +1200,7 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_KGROUPS")) g_kgroups = atoi(e);
     if (const char* e = getenv("RY_PATCH")) g_patch = atoi(e);
     if (const char* e = getenv("RY_X3_MINM")) g_x3_min_m = atoi(e);
+    if (const char* e = getenv("RY_X3_LAST")) g_x3_last = atoi(e);
     if (const char* e = getenv("RY_PLAN_X3_PEAK")) g_x3_peak = atof(e) * 1e6;
     if (const char* e = getenv("RY_PLAN_X3_KG2")) g_x3_kg2 = atof(e);
     if (const char* e = getenv("RY_XCD_GROUPS")) g_xcd_groups = atoi(e);

@@ -151,6 +151,7 @@ def test_stage2_x3_pipeline_emu(emu_ctx, monkeypatch):
     split = [q['layer'] for q in st if q['name'].startswith('ry_igemm_ldsdma<') and q['name'][:-1].split(',')[5] == 'true']
     exact = [q['layer'] for q in st if q['name'].startswith('ry_igemm_ldsdma<') and q['name'][:-1].split(',')[5] == 'false']
     assert 'encoder/c1' in split and 'decoder/c6' in split and 'encoder/c2' in exact, (split, exact)
+    assert [q['name'] for q in st if q['layer'] == 'decoder/c7'] == ['ry_sr_last<true>']     # the last layer reads the [hi | lo] copies
     assert not numpy.array_equal(y3, y32)
     assert rel_max(y3, ref) < 2e-5, rel_max(y3, ref)
     monkeypatch.setenv('RY_X3_MINM', '1')             # every implicit-GEMM layer on the split path (mixed-format copies gone)
