@@ -39,6 +39,7 @@ def parse():
                          "accumulation and end layers; 'bf16x3' = split-bf16: every fp32 product as hi*hi + lo*hi + hi*lo on the bf16 pipe, fp32 "
                          "accumulate, results within ~2e-6 of the fp32 path -- DESIGN.md 4.7)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-split-bf16', action='store_true', help="skip the extra 'split_bf16' measurement of an f32 run")
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--profile-reps', type=int, default=5)
     ap.add_argument('--profile-only', action='store_true', help='only print the per-kernel-family profile of stage-2 (tuning aid)')
@@ -147,21 +148,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    for _ in range(args.steps):
-        step()
-    dev_ms = ctx.timer_stop()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    assert bool(torch.isfinite(y2).all()) and bool(torch.isfinite(y1).all())
+    def timed():
+        # W untimed warm-up steps, then exactly K steps between barrier + synchronize fences; the maximum over the ranks
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        for _ in range(args.steps):
+            step()
+        dms = ctx.timer_stop()
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            te = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        assert bool(torch.isfinite(y2).all()) and bool(torch.isfinite(y1).all())
+        return el, dms
+
+    elapsed, dev_ms = timed()
 
     def time_only(fn, reps=20):
         for _ in range(3):
@@ -199,6 +205,25 @@ def main():
         s1_cold_ms = sorted(cold[1:])[len(cold[1:]) // 2]
         del scratch
 
+    # the same K steps with stage-2 in split-bf16 mode (three bf16 products per fp32 product on the bf16 matrix pipe, fp32
+    # accumulate) -- reported BESIDE the exact-fp32 headline, never as `value` of an f32 run
+    split = None
+    if args.dtype == 'f32' and not args.no_split_bf16:
+        y2_f32 = y2.clone()
+        net2.set_dtype('bf16x3')
+        el3, _ = timed()
+        s2x_ms = time_only(lambda: net2.convert_device(sp.data_ptr(), y2.data_ptr(), Wn, N))
+        torch.cuda.synchronize(); ctx.sync()
+        err = float(((y2 / y2_f32) - 1.0).abs().max().item())
+        lerr = float(((y2.log() - y2_f32.log()).abs().max() / y2_f32.log().abs().max()).item())
+        net2.set_dtype('f32')
+        split = {'dtype': 'bf16x3', 'value': round(world * Wn * N * args.steps / el3, 1), 'unit': 'frames/s',
+                 'ms_per_step': round(el3 / args.steps * 1e3, 4), 'stage2_alone_ms': round(s2x_ms, 4),
+                 'max_rel_diff_vs_f32_path': err, 'log_spectrum_diff_vs_f32_path': lerr, 'parity_bar': 1e-4,
+                 'note': 'stage-2 MFMA-bound layers as hi*hi + lo*hi + hi*lo bf16 products with fp32 accumulation (rank 0 output compared); '
+                         'opt-in mode (--dtype bf16x3 / ry_net_set_dtype(net, 2)); the headline value above is exact fp32'}
+        del y2_f32
+
     frames_total = world * Wn * N * args.steps
     value = frames_total / elapsed
     out = {
@@ -211,6 +236,7 @@ def main():
         'graph_replay_ms': {'stage1_alone': round(s1_ms, 4), 'stage2_alone': round(s2_ms, 4),
                             'stage1_alone_cold': None if s1_cold_ms is None else round(s1_cold_ms, 4)},
         'host_call_ms_per_window': None if host_ms is None else round(host_ms, 4),
+        'split_bf16': split,
         'config': {'workload': 'BASELINE config #3: stage-1 + stage-2 SR forward, buffer_time 0.5 s + 2x0.5 s convert_extra_time '
                                '@16 kHz / 5 ms -> %d real frames (%d padded) per window, %d window(s) per GPU per step, %s random-init weights'
                                % (N, T, Wn, args.model),

@@ -507,7 +507,7 @@ static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memt
 static unsigned long long* g_dbg = nullptr;
 static int g_force[16][3];   // RY_PLAN="layer:tile:splits:kgroups,...": tuning aid, fixes the stage-2 plan of single layers (0 = planner's choice)
 static int g_x3_min_m = 128;   // RY_X3_MINM: split-bf16 mode runs a layer on the bf16 pipe from this many GEMM rows (per phase) up (measured at 300 frames: 1 / 32 / 64 / 128 / 512 / 2048 -> 0.861 / 0.865 / 0.867 / 0.864 vs 0.840 / 0.928 ms per step on two boxes; 128 beat 512 by 1 % in the same-box A/B)
-static int g_x3_last = 1;      // RY_X3_LAST=0: split-bf16 mode keeps fp32 copies for the last layer (A/B)
+static int g_x3_last = 0;      // RY_X3_LAST=1: split-bf16 mode: the last layer reads the producers' [hi | lo] copies, no fp32 copies kept for it (measured: step 0.829 -> 0.826 ms, error 2.6e-6 -> 3.7e-6: off by default)
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
 // Kernel names as rocprofv3 prints them (template arguments, no spaces): bench.py matches them against profiles/*.
@@ -1397,6 +1397,7 @@ int ry_net_set_dtype(ry_net* net, int dtype) {
     RY_TRY(read_plan_env());
     if (dtype == 2) {
         if (const char* e = getenv("RY_X3_MINM")) g_x3_min_m = atoi(e);      // read again here so that a test / sweep can move it per call
+        if (const char* e = getenv("RY_X3_LAST")) g_x3_last = atoi(e);
         for (Layer& l : net->layers) {
             if (!l.wig || l.wigx3 || l.cin_a % 64 != 0 || l.cin_b % 64 != 0) continue;
             const TapTable t = make_taps(l);

@@ -151,12 +151,17 @@ def test_stage2_x3_pipeline_emu(emu_ctx, monkeypatch):
     split = [q['layer'] for q in st if q['name'].startswith('ry_igemm_ldsdma<') and q['name'][:-1].split(',')[5] == 'true']
     exact = [q['layer'] for q in st if q['name'].startswith('ry_igemm_ldsdma<') and q['name'][:-1].split(',')[5] == 'false']
     assert 'encoder/c1' in split and 'decoder/c6' in split and 'encoder/c2' in exact, (split, exact)
-    assert [q['name'] for q in st if q['layer'] == 'decoder/c7'] == ['ry_sr_last<true>']     # the last layer reads the [hi | lo] copies
+    assert [q['name'] for q in st if q['layer'] == 'decoder/c7'] == ['ry_sr_last<false>']
     assert not numpy.array_equal(y3, y32)
     assert rel_max(y3, ref) < 2e-5, rel_max(y3, ref)
     monkeypatch.setenv('RY_X3_MINM', '1')             # every implicit-GEMM layer on the split path (mixed-format copies gone)
     net.set_dtype('bf16x3')
     assert rel_max(net.forward(x), ref) < 2e-5
+    monkeypatch.setenv('RY_X3_LAST', '1')             # the last layer on the producers' [hi | lo] copies (opt-in A/B switch)
+    net.set_dtype('bf16x3')
+    assert rel_max(net.forward(x), ref) < 2e-5
+    assert [q['name'] for q in net.profile(1, 16, 1) if q['layer'] == 'decoder/c7'] == ['ry_sr_last<true>']
+    monkeypatch.setenv('RY_X3_LAST', '0')
     net.set_dtype('f32')
     assert numpy.array_equal(net.forward(x), y32)     # the exact path comes back bit for bit
     net.close()
