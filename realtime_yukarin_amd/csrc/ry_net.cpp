@@ -546,7 +546,7 @@ static thread_local int g_plan_ck = 32;             // input channels per K chun
 // the K of the bf16 mode per tile: the fixed costs weigh less, 128x128 tiles reach 730-800 TF of bf16 products = 0.7 x 1150),
 // and the price of two K groups in one 512-thread workgroup against two 256-thread workgroups on the same CU (the GEMM alone
 // ran 10-17 % slower: 69 vs 59 us on decoder c3, 73 vs 66 us on encoder c1).  RY_PLAN_X3_PEAK (TFLOP/s) / RY_PLAN_X3_KG2 override.
-static double g_x3_peak = 1.15e9, g_x3_kg2 = 1.15;
+static double g_x3_peak = 2.0e9, g_x3_kg2 = 1.15;
 static thread_local double g_plan_kg2 = 1.0;        // factor on the main loop of a two-K-group workgroup
 
 static int tile_occ(int tile, int kg) {
