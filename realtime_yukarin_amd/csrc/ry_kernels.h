@@ -12,6 +12,8 @@
 //                       or v_mfma_f32_32x32x16_bf16: operand tiles global -> LDS by DMA with scalar-base addressing, input
 //                       patches shared by the taps (PATCH), split-K inside the workgroup (KG), folded BN + activation
 //                       epilogue with 16-byte stores, optional split-K slabs; tiles 128x128 / 96x128 / 128x64 / 64x128 / 32x128
+//                       (the bf16 form also runs the split-bf16 mode: sources [pixel][hi | lo], K axis [hi | lo | hi] against
+//                       filters [w_hi | w_hi | w_lo] = three bf16 products per fp32 product, fp32 accumulate -- DESIGN.md 4.7)
 //   ry_igemm_f32        the register-staged predecessor: kept for 256-row tiles and as the RY_LDSDMA=0 A/B
 //   ry_splitk_reduce    sum of split-K slabs + folded BN + activation
 //   ry_sr_first / ry_sr_last   the 1 -> N and C -> 1 3x3 end layers of stage 2 (HBM / L2-bound)
