@@ -39,6 +39,13 @@ class SuperResolution(object):
             device = int(os.environ.get('RY_DEVICE', '0')) if self.gpu is None else int(self.gpu)
             ctx = engine.get_context(device)
             self._net = engine.Net(ctx, self.desc, flatten_params(self.desc, self._params), width=bins - 1)
+            # opt-in arithmetic of the MFMA-bound layers, for callers that cannot pass an argument (run.py / check.py unchanged):
+            # RY_SR_DTYPE = f32 (default, exact) | bf16x3 (split-bf16, ~2e-6 from fp32: DESIGN.md 4.7) | bf16 (BASELINE config #5)
+            dtype = os.environ.get('RY_SR_DTYPE', 'f32')
+            if dtype not in ('f32', 'bf16', 'bf16x3'):
+                raise ValueError("RY_SR_DTYPE must be 'f32', 'bf16' or 'bf16x3', not %r" % dtype)
+            if dtype != 'f32':
+                self._net.set_dtype(dtype)
             self._net_pid, self._bins = os.getpid(), bins
         return self._net
 

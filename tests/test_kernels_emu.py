@@ -164,4 +164,11 @@ def test_stage2_x3_pipeline_emu(emu_ctx, monkeypatch):
     monkeypatch.setenv('RY_X3_LAST', '0')
     net.set_dtype('f32')
     assert numpy.array_equal(net.forward(x), y32)     # the exact path comes back bit for bit
+    # the SuperResolution.convert wrapper (pad 'minimum' / log / drop bin ... exp / edge / crop fused around the predictor) in both modes
+    sp = numpy.exp(numpy.random.default_rng(23).normal(-6.0, 1.5, (11, 17))).astype('f4')
+    c32 = net.convert(sp)
+    net.set_dtype('bf16x3')
+    c3 = net.convert(sp)
+    assert c3.shape == (11, 17) and not numpy.array_equal(c3, c32)
+    assert float(numpy.abs(numpy.log(c3) - numpy.log(c32)).max() / numpy.abs(numpy.log(c32)).max()) < 2e-5
     net.close()

@@ -141,6 +141,22 @@ def test_mirror_voice_changer_end_to_end(models, on_emulator):
 
 
 @pytest.mark.skipif(not REF.exists(), reason='/root/reference is not mounted here')
+def test_super_resolution_dtype_is_selectable_from_the_environment(models, on_emulator, monkeypatch):
+    """RY_SR_DTYPE lets an unchanged run.py / check.py opt into the split-bf16 (or bf16) stage-2 arithmetic; anything else
+    is refused before the first convert.  (The base-8 test model has no MFMA-bound layer, so the result is the fp32 one.)"""
+    rng = numpy.random.default_rng(5)
+    sp = numpy.exp(rng.normal(-6.0, 1.5, (40, 513))).astype(numpy.float32)
+    _, sr = build_converters(models)
+    ref = sr.convert(sp)
+    monkeypatch.setenv('RY_SR_DTYPE', 'bf16x3')
+    _, sr3 = build_converters(models)
+    assert float(numpy.abs(sr3.convert(sp) / ref - 1).max()) < 1e-4
+    monkeypatch.setenv('RY_SR_DTYPE', 'fp16')
+    _, bad = build_converters(models)
+    with pytest.raises(ValueError, match='RY_SR_DTYPE'):
+        bad.convert(sp)
+
+
 def test_reference_voice_changer_and_convert_stream_run_unchanged_on_the_shims(models, on_emulator, monkeypatch):
     for p in (str(ROOT / 'tests' / 'stubs'), str(REF)):
         monkeypatch.syspath_prepend(p)
