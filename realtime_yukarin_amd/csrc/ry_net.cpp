@@ -507,6 +507,9 @@ static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memt
 static unsigned long long* g_dbg = nullptr;
 static int g_force[16][3];   // RY_PLAN="layer:tile:splits:kgroups,...": tuning aid, fixes the stage-2 plan of single layers (0 = planner's choice)
 static int g_x3_min_m = 128;   // RY_X3_MINM: split-bf16 mode runs a layer on the bf16 pipe from this many GEMM rows (per phase) up (measured at 300 frames: 1 / 32 / 64 / 128 / 512 / 2048 -> 0.861 / 0.865 / 0.867 / 0.864 vs 0.840 / 0.928 ms per step on two boxes; 128 beat 512 by 1 % in the same-box A/B)
+static int g_autotune = 0;     // RY_AUTOTUNE=1: time candidate launch plans of every stage-2 implicit-GEMM layer on the device when a plan is built (autotune_plan)
+static int g_autotune_reps = 3, g_autotune_max = 0;   // RY_AUTOTUNE_REPS timed rounds per candidate; RY_AUTOTUNE_MAX caps the candidates per layer (0 = all; tests)
+static int g_autotune_pick = -1;                      // RY_AUTOTUNE_PICK=k (tests only): take candidate k of every layer instead of the fastest
 static int g_x3_last = 0;      // RY_X3_LAST=1: split-bf16 mode: the last layer reads the producers' [hi | lo] copies, no fp32 copies kept for it (measured: step 0.829 -> 0.826 ms, error 2.6e-6 -> 3.7e-6: off by default)
 static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
 
@@ -1085,6 +1088,90 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
     return RY_OK;
 }
 
+// RY_AUTOTUNE=1 (opt-in): measure instead of estimate.  After a stage-2 plan is built, every implicit-GEMM layer is timed on the
+// device with its own buffers under a short list of (tile, K groups, external splits) candidates around the planner's pick --
+// GEMM + reduce launches, HIP events, the best of `reps` rounds -- and the fastest candidate replaces the pick.  The planner's
+// estimate is a model fitted to one window size; the sweeps (profiles/*plansweep*) show it 1-4 % off the per-layer optimum, more at
+// window sizes it was not fitted on.  Costs a few hundred launches per plan, once per (batch, frames, mode, dtype).  Split-K
+// sums are still taken in a fixed order, so results stay deterministic for a given plan -- but two processes may now pick
+// different plans and differ in the last bits, which is why this is not the default.
+static int autotune_plan(ry_net* net, Plan& P) {
+    ry_ctx* ctx = net->ctx;
+    const int B = P.B;
+    const float slope = net->desc.lrelu_slope;
+    rt::Event e0, e1;
+    RT_TRY(rt::event_create(&e0)); RT_TRY(rt::event_create(&e1));
+    Launcher Lc{nullptr, ctx, net->stream, nullptr, nullptr};
+    int rc = RY_OK;
+    for (int i = 0; i < 16 && rc == RY_OK; ++i) {
+        LayerPlan& lp = P.lp[i];
+        if (lp.path != PATH_IGEMM && lp.path != PATH_IGEMM_BF16) continue;
+        if (lp.path == PATH_IGEMM && (!g_ldsdma || g_timing)) continue;        // the register-staged A/B kernel is not tuned
+        if (g_force[i][0] || g_force[i][1] || g_force[i][2]) continue;         // RY_PLAN fixes this layer
+        const Layer& l = net->layers[i];
+        if (l.src_a < 0) continue;
+        const bool b16 = lp.path == PATH_IGEMM_BF16;
+        const TapTable t = make_taps(l);
+        const int M = B * (l.deconv ? lp.Hi * lp.Wi : lp.Ho * lp.Wo);
+        const int nk = t.ntaps * ((b16 && lp.x3 ? 3 : 1) * l.cin() / (b16 ? 64 : 32));
+        const size_t out_elems = (size_t)B * lp.Ho * lp.Wo * l.cout;
+        const float* s1 = b16 ? reinterpret_cast<const float*>(P.lp[l.src_a].out16) : P.lp[l.src_a].out;
+        const float* s2 = l.src_b < 0 ? nullptr : b16 ? reinterpret_cast<const float*>(P.lp[l.src_b].out16) : P.lp[l.src_b].out;
+        // candidates: the planner's pick first (ties keep it), then tiles x K groups x splits around it
+        struct Cand { int tile, kg, splits; };
+        std::vector<Cand> cands;
+        cands.push_back({lp.tile, lp.kg, lp.splits});
+        std::vector<int> tiles;
+        if (l.cout % 128 != 0) tiles = {TILE_128x64};
+        else if (M <= 64) tiles = {TILE_32x128, TILE_64x128};
+        else tiles = {TILE_128x128, TILE_96x128, TILE_64x128};
+        static const int split_list[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32, 48, 64, 96, 128};
+        for (int tile : tiles)
+            for (int kg = 1; kg <= ((g_kgroups && M > 64 && nk >= 16) ? 2 : 1); ++kg)
+                for (int sp : split_list) {
+                    if (sp * kg > nk || sp > (M <= 64 ? 128 : 32)) continue;
+                    int bm, bn; tile_dims(tile, &bm, &bn);
+                    const long tiles_n = (long)((M + bm - 1) / bm) * (l.cout / bn) * t.nphases;
+                    if (sp > 1 && tiles_n * sp > 4096) continue;                      // more than eight rounds of workgroups: never useful
+                    if (sp == 1 && tiles_n < 64) continue;                            // a quarter of the CUs: needs split-K
+                    if (tile == lp.tile && kg == lp.kg && sp == lp.splits) continue;
+                    cands.push_back({tile, kg, sp});
+                }
+        if (g_autotune_max > 0 && (int)cands.size() > g_autotune_max) cands.resize(g_autotune_max);
+        int max_sp = 1;
+        for (const Cand& c : cands) max_sp = c.splits > max_sp ? c.splits : max_sp;
+        float* tmp_slabs = nullptr;
+        if (max_sp > 1) {
+            void* q = nullptr;
+            if (rt::dmalloc(&q, out_elems * (size_t)max_sp * sizeof(float)) != 0) { (void)rt::last_error(); continue; }   // no room to tune this layer: keep the pick
+            tmp_slabs = (float*)q;
+        }
+        int best = 0; float best_ms = 1e30f;
+        for (size_t c = 0; c < cands.size() && rc == RY_OK; ++c) {
+            LayerPlan lq = lp;
+            lq.tile = cands[c].tile; lq.kg = cands[c].kg; lq.splits = cands[c].splits; lq.slabs = tmp_slabs;
+            float ms_best = 1e30f;
+            for (int r = 0; r < 1 + g_autotune_reps && rc == RY_OK; ++r) {             // round 0 warms the instruction cache and the L2
+                if (rt::event_record(e0, net->stream) != 0) { rc = fail(RY_EHIP, "autotune: event record failed"); break; }
+                rc = launch_conv2d(Lc, l, lq, B, s1, l.cin_a, s2, l.cin_b, slope);
+                if (rc != RY_OK) break;
+                float ms = 0.f;
+                if (rt::event_record(e1, net->stream) != 0 || rt::event_sync(e1) != 0 || rt::event_elapsed(&ms, e0, e1) != 0) { rc = fail(RY_EHIP, "autotune: timing failed"); break; }
+                if (r > 0 && ms < ms_best) ms_best = ms;
+            }
+            if (ms_best < best_ms) { best_ms = ms_best; best = (int)c; }
+        }
+        if (tmp_slabs) { (void)rt::stream_sync(net->stream); rt::dfree(tmp_slabs); }
+        if (rc != RY_OK) break;
+        if (g_autotune_pick >= 0) best = g_autotune_pick < (int)cands.size() ? g_autotune_pick : (int)cands.size() - 1;   // tests: exercise the replacement
+        const Cand& w = cands[best];
+        if (w.splits > 1 && w.splits > lp.splits) rc = P.arena.alloc(&lp.slabs, out_elems * (size_t)w.splits);
+        lp.tile = w.tile; lp.kg = w.kg; lp.splits = w.splits;
+    }
+    rt::event_destroy(e0); rt::event_destroy(e1);
+    return rc;
+}
+
 static int get_plan(ry_net* net, int B, int T, int mode, int n_frames, Plan** out) {
     if (B < 1 || T < 1) return fail(RY_EINVAL, "batch and frames must be positive (got %d, %d)", B, T);
     auto key = std::make_tuple(B, T, mode, 0);        // convert-mode plans are shared by every n_frames with the same padded length
@@ -1097,6 +1184,7 @@ static int get_plan(ry_net* net, int B, int T, int mode, int n_frames, Plan** ou
         std::unique_ptr<Plan> P(new Plan());
         P->B = B; P->T = T; P->mode = mode; P->n_frames = n_frames;
         RY_TRY(build_plan(net, *P));
+        if (g_autotune && net->desc.ndim == 2) RY_TRY(autotune_plan(net, *P));
         it = net->plans.emplace(key, std::move(P)).first;
     }
     it->second->n_frames = n_frames;
@@ -1201,6 +1289,12 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_PATCH")) g_patch = atoi(e);
     if (const char* e = getenv("RY_X3_MINM")) g_x3_min_m = atoi(e);
     if (const char* e = getenv("RY_X3_LAST")) g_x3_last = atoi(e);
+    g_autotune = 0; g_autotune_reps = 3; g_autotune_max = 0;      // (re-read by ry_debug_plan_igemm: absent variables mean the defaults)
+    if (const char* e = getenv("RY_AUTOTUNE")) g_autotune = atoi(e);
+    if (const char* e = getenv("RY_AUTOTUNE_REPS")) g_autotune_reps = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("RY_AUTOTUNE_MAX")) g_autotune_max = atoi(e);
+    g_autotune_pick = -1;
+    if (const char* e = getenv("RY_AUTOTUNE_PICK")) g_autotune_pick = atoi(e);
     if (const char* e = getenv("RY_PLAN_X3_PEAK")) g_x3_peak = atof(e) * 1e6;
     if (const char* e = getenv("RY_PLAN_X3_KG2")) g_x3_kg2 = atof(e);
     if (const char* e = getenv("RY_XCD_GROUPS")) g_xcd_groups = atoi(e);

@@ -172,3 +172,37 @@ def test_stage2_x3_pipeline_emu(emu_ctx, monkeypatch):
     assert c3.shape == (11, 17) and not numpy.array_equal(c3, c32)
     assert float(numpy.abs(numpy.log(c3) - numpy.log(c32)).max() / numpy.abs(numpy.log(c32)).max()) < 2e-5
     net.close()
+
+
+def test_autotuned_plans_stay_correct_emu(emu_ctx, monkeypatch):
+    """RY_AUTOTUNE=1 (opt-in): candidate launch plans of every implicit-GEMM layer are run on the device when a plan is built and
+    the fastest replaces the planner's pick.  The emulator has no clock, so RY_AUTOTUNE_PICK forces a non-default candidate per
+    layer (another tile / K-group / split-K combination, slabs re-allocated): results must not move beyond summation order,
+    in the exact fp32 mode and in the split-bf16 mode."""
+    import ctypes
+    d = NetDesc(2, 1, 1, 64, 2)
+    P = synthetic_params(d, 430, bias_std=0.05)
+    net = engine.Net(emu_ctx, d, flatten_params(d, P), width=16)
+    x = numpy.random.default_rng(31).normal(size=(1, 8, 16)).astype('f4')
+    ref = cases.oracle_forward(d, P, x)
+    reread = lambda: emu_ctx.lib.check(emu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    monkeypatch.setenv('RY_X3_MINM', '1')
+    base = {}
+    for mode in ('f32', 'bf16x3'):
+        net.set_dtype(mode)
+        base[mode] = [(q['layer'], q['name'], q['grid']) for q in net.profile(1, 8, 1)]
+    try:
+        monkeypatch.setenv('RY_AUTOTUNE', '1'); monkeypatch.setenv('RY_AUTOTUNE_REPS', '1'); monkeypatch.setenv('RY_AUTOTUNE_MAX', '3')
+        for pick in (0, 2):
+            monkeypatch.setenv('RY_AUTOTUNE_PICK', str(pick)); reread()
+            for mode in ('f32', 'bf16x3'):
+                net.set_dtype(mode)
+                assert rel_max(net.forward(x), ref) < (cases.TOL if mode == 'f32' else 2e-5), (pick, mode)
+                plan = [(q['layer'], q['name'], q['grid']) for q in net.profile(1, 8, 1)]
+                assert (plan == base[mode]) == (pick == 0), (pick, mode, plan)      # candidate 0 is the planner's pick
+    finally:
+        for k in ('RY_AUTOTUNE', 'RY_AUTOTUNE_REPS', 'RY_AUTOTUNE_MAX', 'RY_AUTOTUNE_PICK'):
+            monkeypatch.delenv(k, raising=False)
+        reread()                                                       # the session-wide context goes back to the defaults
+    net.set_dtype('f32')
+    net.close()
