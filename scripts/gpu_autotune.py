@@ -8,6 +8,7 @@ import time
 from pathlib import Path
 
 import numpy
+import torch
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
@@ -15,6 +16,7 @@ from realtime_yukarin_amd import engine, synth                      # noqa: E402
 from realtime_yukarin_amd.weights import flatten_params             # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+torch.cuda.init()                                                    # like bench.py: torch's HIP context first, then the library's
 (_, _), (d2, P2) = synth.model_params('SYN-64')
 ctx = engine.get_context(0)
 net = engine.Net(ctx, d2, flatten_params(d2, P2), width=synth.FFT_BINS - 1)
@@ -26,7 +28,6 @@ def reread():
 
 
 def replay_ms(reps=40):
-    import torch
     x = torch.from_numpy(sp[None]).cuda(); y = torch.empty_like(x)
     for _ in range(3):
         net.convert_device(x.data_ptr(), y.data_ptr(), 1, N)
