@@ -141,6 +141,17 @@ def run_conv2d_x3(ctx, rng, case, bn_params):
     return y, fin(r3), fin(r)
 
 
+def x3_scaling_property(ctx, rng, case):
+    """Size-independent exactness property of the split-bf16 path: scaling the input by a power of two commutes with the bf16
+    hi / lo split and with every fp32 accumulation, so y(4 x) == 4 y(x) BIT FOR BIT (no bias, no BN, ReLU), and so does
+    scaling the filters.  -> (y(x), y(4 x), y(x; W / 8))"""
+    B, H, W_, Cin, Cout, k, s, p, tr, act, tile, splits = case
+    x = rng.normal(size=(B, H, W_, Cin)).astype('f4')
+    Wt = rng.normal(0, 0.1, size=(Cin, Cout, k, k) if tr else (Cout, Cin, k, k)).astype('f4')
+    f = lambda xx, ww: ctx.conv2d(xx, ww, None, None, stride=s, pad=p, transposed=tr, act='relu', path='igemm_x3', tile=tile, splits=splits)
+    return f(x, Wt), f(4.0 * x, Wt), f(x, Wt / 8.0)
+
+
 def run_conv1d(ctx, rng, case, bn_params):
     B, L, Cin, Cout, k, s, p, d, tr, act, splits = case
     x = rng.normal(size=(B, L, Cin)).astype('f4')

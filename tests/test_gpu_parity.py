@@ -48,6 +48,21 @@ def test_conv2d_x3_gpu(gpu_ctx, case):
     assert rel_max(y, r) < 2e-5
 
 
+X3_FULL_SIZE = [
+    (1, 48, 64, 1024, 256, 4, 2, 1, True, 'relu', None, 0),        # decoder c4 of SYN-64 at the 300-frame window (planner's tile / splits)
+    (1, 96, 128, 256, 512, 4, 2, 1, False, 'relu', None, 0),       # encoder c3 at the same window
+]
+
+
+@pytest.mark.parametrize('case', cases.CONV2D_X3_CASES[:2] + X3_FULL_SIZE, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_x3_power_of_two_scaling_is_exact_gpu(gpu_ctx, case):
+    """Size-independent property at BASELINE layer sizes (no oracle needed): scaling the input or the filters by a power of two
+    commutes with the bf16 hi / lo split and with every fp32 accumulation, so the split-bf16 result scales bit for bit."""
+    y, y4, yw = cases.x3_scaling_property(gpu_ctx, numpy.random.default_rng(18), case)
+    assert numpy.array_equal(y4, 4.0 * y) and numpy.array_equal(yw, y / 8.0)
+    assert float(numpy.abs(y).max()) > 0.1
+
+
 def test_mfma_fragment_map_is_transpose_detecting(gpu_ctx):
     """Asymmetric 1x1 'conv' = plain GEMM with A = identity rows: catches a swapped C/D row/col map."""
     Cin, Cout = 32, 128

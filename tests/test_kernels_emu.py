@@ -41,6 +41,13 @@ def test_conv2d_x3_emu(emu_ctx, case):
     assert rel_max(y, r) < 1e-5            # and against the fp32-operand oracle: the dropped lo*lo term and the 16-bit split
 
 
+@pytest.mark.parametrize('case', cases.CONV2D_X3_CASES[:3], ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_x3_power_of_two_scaling_is_exact_emu(emu_ctx, case):
+    y, y4, yw = cases.x3_scaling_property(emu_ctx, numpy.random.default_rng(18), case)
+    assert numpy.array_equal(y4, 4.0 * y) and numpy.array_equal(yw, y / 8.0)
+    assert float(numpy.abs(y).max()) > 0.1
+
+
 NETS = [
     # ndim, in, out, base, e, T, width, batch
     (1, 9, 9, 8, 8, 128, 1, 1),
