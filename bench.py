@@ -280,9 +280,9 @@ def main():
                            'alg_flops_per_launch': dv['flops'] / dv['launches']}
         if args.dtype == 'bf16x3' and is_bf16:      # the matrix pipe executes three bf16 products per algorithmic (fp32) product
             out['roofline']['mfma_flops_per_alg_flop'] = 3
-        c1 = [s for s in st1 if s['name'].startswith('ry_conv1d_ws')]
+        c1 = [s for s in st1 if s['name'].startswith(('ry_c1d_os', 'ry_conv1d_ws'))]
         ms1 = sum(s['ms'] for s in c1); by1 = sum(s['bytes'] for s in c1)
-        out['roofline_stage1'] = {'kernel': 'ry_conv1d_ws<*> (16 launches)', 'bound': 'hbm', 'achieved': round(by1 / (ms1 * 1e-3) / 1e9, 1),
+        out['roofline_stage1'] = {'kernel': '%s<*> (%d launches)' % (c1[0]['name'].split('<')[0], len(c1)), 'bound': 'hbm', 'achieved': round(by1 / (ms1 * 1e-3) / 1e9, 1),
                                   'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                   'traffic': None, 'alg_bytes_per_forward': by1, 'kernel_ms_per_forward': round(ms1, 4),
                                   'frac_graph_warm': round(by1 / (s1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

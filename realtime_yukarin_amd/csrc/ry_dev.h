@@ -53,6 +53,8 @@ RY_DEV void ry_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// the instruction scheduler does not move anything across this point
+RY_DEV void ry_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 RY_DEV float ry_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 RY_DEV float ry_shfl(float v, int src) { return __shfl(v, src, 64); }
 RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }

@@ -1457,6 +1457,176 @@ RY_KERNEL(256) void ry_conv1d_ws(RyConv1dParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ry_c1d_os<MODE, CB, TP> -- stage-1 layer, OUTPUT-STATIONARY form (the predictor's default since round 2).
+// The weight-streaming kernel above splits the input channels over workgroups and leaves up to 32 raw slabs per layer for the
+// consumer to re-sum: 17.8 MB of slab traffic per forward against 0.03 MB of activations, and a chain of dependent slab loads
+// in front of every layer's first FMA (11-15 us per layer at a 3.4 us launch floor).  Here the LANES run over the input
+// channels instead: a workgroup owns CB output channels x (PG x TP) positions, thread (ci lane, position group) loads its
+// input column x[pos][ci] (4-byte loads, coalesced over the lanes) and the CB filter taps of its channel (16 bytes each,
+// filters stored [co][ci][4]) -- every load of the layer is independent and issued up front: ONE memory round trip -- then
+// CB x TP x 4 FMAs per channel, a reduce-scatter butterfly over the 64 lanes (A - 1 + log2(64 / A) shuffles for A = CB x TP
+// sums), a fixed-order sum over the waves through the LDS, folded BN + activation, and a dense activated store.  No slabs, no
+// deferred epilogue, no second pass; the last layer crops to the real frames as it stores (no ry_materialize node).
+//   MODE S2: k4 s2 p1 conv; S1: stride-1 conv, k <= 4 (taps beyond k are zero in the filter), any pad <= 3; DECONV: k4 s2 p1
+//   transposed conv in sub-pixel form (TP input positions -> 2 TP outputs).
+//   kt_waves = waves that share one position group (1 / 2 / 4 for <= 64 / <= 128 / more input channels); PG = 4 / kt_waves.
+// ---------------------------------------------------------------------------------------------
+struct RyC1dOsParams {
+    const float* sa;            // [B][Lin][Ca] dense, activated
+    const float* sb;            // [B][Lin][Cb] second source of a skip concat, or null (Cb = 0)
+    int Ca, Cb;
+    const float* w;             // [N][Ca + Cb][4]
+    const float* scale;         // [N] folded BN scale
+    const float* shift;         // [N]
+    float* out;                 // [B][keep][N]
+    int B, Lin, Lout, N;
+    int keep;                   // rows stored per window (Lout, or the real frames of the convert wrapper for the last layer)
+    int pad;                    // MODE S1 only
+    int act;
+    float slope;
+    int tiles;                  // position tiles per window (one tile = PG x TP rows)
+    int kt_waves;
+};
+
+// Keeps two values in separate registers: without it the compiler rewrites `c ? v[a] : v[b]` on a register array into a
+// select over an INDEX and then emulates the dynamic register index with a chain of A compare / v_cndmask pairs per access
+// (measured: the 31-shuffle reduction of 32 sums grew to ~5000 instructions and a layer from 8 to 26-65 us).
+RY_DEV void ry_keep2(float& a, float& b) {
+#ifndef RY_HOST_EMU
+    asm volatile("" : "+v"(a), "+v"(b));
+#endif
+}
+
+// Reduce-scatter over the 64 lanes of a wave: every lane brings N partial sums, lane L returns the 64-lane total of sum number
+// L >> (6 - log2 N) (lanes that share the upper bits hold the same total).  N - 1 + (6 - log2 N) shuffles, fixed order.
+template <int N>
+struct RyReduceScatter64 {
+    static RY_DEV float run(const float (&v)[N], int lane, int mask) {
+        float h[N / 2];
+        const bool up = (lane & mask) != 0;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            float lo = v[i], hi = v[i + N / 2];
+            ry_keep2(lo, hi);
+            const float recv = ry_shfl_xor(up ? lo : hi, mask);
+            h[i] = (up ? hi : lo) + recv;
+        }
+        return RyReduceScatter64<N / 2>::run(h, lane, mask >> 1);
+    }
+};
+template <>
+struct RyReduceScatter64<1> {
+    static RY_DEV float run(const float (&v)[1], int, int mask) {
+        float r = v[0];
+        for (; mask >= 1; mask >>= 1) r += ry_shfl_xor(r, mask);
+        return r;
+    }
+};
+
+template <int MODE, int CB, int TP>
+RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
+    constexpr int TPO = MODE == RY_C1D_DECONV ? 2 * TP : TP;                       // outputs per position group
+    constexpr int NP = MODE == RY_C1D_S2 ? 2 * TP + 2 : MODE == RY_C1D_DECONV ? TP + 2 : TP + 3;
+    constexpr int A = CB * TPO;
+    constexpr int LOG2A = A == 32 ? 5 : A == 16 ? 4 : A == 8 ? 3 : A == 4 ? 2 : A == 2 ? 1 : 0;
+    static_assert(A <= 32 && (A & (A - 1)) == 0, "at most 32 sums per thread, a power of two");
+    __shared__ float red[4 * 32];
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = ry_uniform(tid >> 6);
+    const int ktw = p.kt_waves, PG = 4 / ktw;
+    const int pg = wave / ktw, kw = wave - pg * ktw;
+    const int Ctot = p.Ca + p.Cb;
+    const int co0 = (int)blockIdx.x * CB;
+    const int b = (int)blockIdx.y / p.tiles, tile = (int)blockIdx.y - b * p.tiles;
+    const int r0 = (tile * PG + pg) * TP;                                            // first row of this position group
+    const int pos0 = MODE == RY_C1D_S2 ? 2 * r0 - 1 : MODE == RY_C1D_DECONV ? r0 - 1 : r0 - p.pad;
+
+    float acc[A];
+#pragma unroll
+    for (int i = 0; i < A; ++i) acc[i] = 0.f;
+    // one input channel of this lane: its NP input rows and the taps of the CB output channels
+    auto load = [&](int c0, float (&x)[NP], f32x4 (&w)[CB]) {
+        const bool cok = c0 < Ctot;
+        const int ci = cok ? c0 : Ctot - 1;
+        const bool fa = ci < p.Ca;
+        const float* src = fa ? p.sa : p.sb;
+        const int Cs = fa ? p.Ca : p.Cb, cl = fa ? ci : ci - p.Ca;
+        const float* col = src + (size_t)b * (size_t)p.Lin * (size_t)Cs + cl;
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const int co = co0 + u < p.N ? co0 + u : p.N - 1;
+            w[u] = ry_ld4(p.w + ((size_t)co * (size_t)Ctot + ci) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {                                               // out-of-range rows read row 0; `zero_pad` clears them
+            const int pos = pos0 + j;
+            const bool ok = pos >= 0 && pos < p.Lin;
+            x[j] = col[(size_t)(ok ? pos : 0) * (size_t)Cs];
+        }
+    };
+    // applied after the scheduling fence, so that no select sits between the loads (the scheduler otherwise waits for the first
+    // eight loads before it issues the rest)
+    auto zero_pad = [&](int c0, float (&x)[NP]) {
+        const bool cok = c0 < Ctot;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int pos = pos0 + j;
+            x[j] = (cok && pos >= 0 && pos < p.Lin) ? x[j] : 0.f;
+        }
+    };
+    auto fma_all = [&](const float (&x)[NP], const f32x4 (&w)[CB]) {
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                if (MODE == RY_C1D_S2) {
+                    acc[u * TPO + j] = fmaf(w[u][3], x[2 * j + 3], fmaf(w[u][2], x[2 * j + 2], fmaf(w[u][1], x[2 * j + 1], fmaf(w[u][0], x[2 * j], acc[u * TPO + j]))));
+                } else if (MODE == RY_C1D_S1) {
+                    acc[u * TPO + j] = fmaf(w[u][3], x[j + 3], fmaf(w[u][2], x[j + 2], fmaf(w[u][1], x[j + 1], fmaf(w[u][0], x[j], acc[u * TPO + j]))));
+                } else {        // out[2q] = w1 x[q] + w3 x[q-1];  out[2q+1] = w0 x[q+1] + w2 x[q]   (x[j] = in[r0 - 1 + j])
+                    acc[u * TPO + 2 * j] = fmaf(w[u][3], x[j], fmaf(w[u][1], x[j + 1], acc[u * TPO + 2 * j]));
+                    acc[u * TPO + 2 * j + 1] = fmaf(w[u][2], x[j + 1], fmaf(w[u][0], x[j + 2], acc[u * TPO + 2 * j + 1]));
+                }
+            }
+        }
+    };
+    // the channels of a lane are walked two at a time: both sets of loads are in flight before the first FMA (layers with more
+    // than 256 input channels would otherwise pay one memory round trip per 256 channels)
+    const int cstep = ktw * 64;
+    for (int cb0 = kw * 64; cb0 < Ctot; cb0 += 2 * cstep) {                          // wave-uniform
+        float xa[NP], xb[NP];
+        f32x4 wa[CB], wb[CB];
+        if (cb0 + cstep < Ctot) {
+            load(cb0 + lane, xa, wa);
+            load(cb0 + cstep + lane, xb, wb);
+            ry_sched_fence();                                                        // every load is issued before the first FMA
+            zero_pad(cb0 + lane, xa); zero_pad(cb0 + cstep + lane, xb);
+            fma_all(xa, wa);
+            fma_all(xb, wb);
+        } else {
+            load(cb0 + lane, xa, wa);
+            ry_sched_fence();
+            zero_pad(cb0 + lane, xa);
+            fma_all(xa, wa);
+        }
+    }
+    const float tot = RyReduceScatter64<A>::run(acc, lane, 32);
+    if ((lane & ((64 >> LOG2A) - 1)) == 0) red[wave * 32 + (lane >> (6 - LOG2A))] = tot;
+    __syncthreads();
+    if (tid < PG * A) {
+        const int pq = tid / A, idx = tid - pq * A;
+        float s = red[(pq * ktw) * 32 + idx];
+        for (int k = 1; k < ktw; ++k) s += red[(pq * ktw + k) * 32 + idx];          // fixed order over the ci waves
+        const int u = idx / TPO, j = idx - u * TPO;
+        const int co = co0 + u;
+        const int rg = (tile * PG + pq) * TP;
+        const int l = (MODE == RY_C1D_DECONV ? 2 * rg : rg) + j;
+        if (co < p.N && l < p.Lout && l < p.keep)
+            p.out[((size_t)b * (size_t)p.keep + l) * (size_t)p.N + co] = ry_act(fmaf(s, p.scale[co], p.shift[co]), p.act, p.slope);
+    }
+}
+
 struct RyMaterializeParams {
     RySrc1d s;
     long long npix;             // B*keep: rows written

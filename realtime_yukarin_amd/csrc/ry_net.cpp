@@ -154,7 +154,8 @@ struct Layer {
     // device parameters
     float* scale = nullptr;
     float* shift = nullptr;
-    float* w1d = nullptr;                // stage-1 [Ctot][N][4]
+    float* w1d = nullptr;                // stage-1 [Ctot][N][4] (weight-streaming kernel ry_conv1d_ws: lanes = output channels)
+    float* w1os = nullptr;               // stage-1 [N][Ctot][4] (output-stationary kernel ry_c1d_os: lanes = input channels)
     float* wig = nullptr;                // stage-2 implicit-GEMM blocks [phase][N/64][tap][Ctot/32][fragment order], see wig_inblock()
     float* wdir = nullptr;               // stage-2 direct [phase][tap][Ctot][N]
     float* wig16 = nullptr;              // stage-2 implicit-GEMM bf16 blocks [phase][N/64][tap][Ctot/64][fragment order], see wig16_inblock() (ry_net_set_dtype)
@@ -242,6 +243,16 @@ static void relayout_1d(const Layer& l, const float* W, std::vector<float>& out)
         for (int n = 0; n < N; ++n)
             for (int k = 0; k < K; ++k)
                 out[((size_t)c * N + n) * 4 + k] = l.deconv ? W[((size_t)c * N + n) * K + k] : W[((size_t)n * C + c) * K + k];
+}
+
+// the same taps as [N][Ctot][4] for ry_c1d_os (a lane walks the input channels of one output channel: 16 bytes per lane, coalesced)
+static void relayout_1d_os(const Layer& l, const float* W, std::vector<float>& out) {
+    const int C = l.cin(), N = l.cout, K = l.k;
+    out.assign((size_t)C * N * 4, 0.f);
+    for (int c = 0; c < C; ++c)
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < K; ++k)
+                out[((size_t)n * C + c) * 4 + k] = l.deconv ? W[((size_t)c * N + n) * K + k] : W[((size_t)n * C + c) * K + k];
 }
 
 struct TapTable {
@@ -341,6 +352,7 @@ struct LayerPlan {
     int splits = 1;
     long long slab_stride = 0;
     float* raw = nullptr;                     // [splits][B*Lo][N] raw sums
+    int os_cb = 0, os_tp = 0, os_kt = 0;      // output-stationary stage-1 kernel (ry_c1d_os): output channels / rows per workgroup slice, ci waves per position group
     // stage-2
     int path = 0, tile = 0;
     bool any_m_patch = false;                 // op-level calls (tests): take the input-patch variants whatever the row count
@@ -367,6 +379,7 @@ struct Plan {
     float* x_in = nullptr;                    // padded predictor input
     size_t user_in_floats = 0, user_out_floats = 0;
     int graph_n = -1, last_n = -1;            // convert mode: n_frames the graph was captured for / of the previous call
+    bool s1_os = false;                       // stage-1 plan runs the output-stationary kernels (dense activated buffers in lp.out, no slabs)
     const float* cur_in = nullptr;            // where the forward reads the caller's block (staging, or the caller's device buffer)
     float* cur_out = nullptr;                 // where it writes the result
 #ifndef RY_HOST_EMU
@@ -417,6 +430,8 @@ static int prepare_layer(ry_ctx* ctx, Arena& arena, Layer& l, int ndim, float ep
         if (l.k > 4) return fail(RY_EINVAL, "%s: 1-D kernels wider than 4 taps are not supported", l.name);
         relayout_1d(l, W, w);
         RY_TRY(upload(arena, ctx, w, &l.w1d));
+        relayout_1d_os(l, W, w);
+        RY_TRY(upload(arena, ctx, w, &l.w1os));
     } else {
         if (l.k * l.k > 16) return fail(RY_EINVAL, "%s: 2-D kernels larger than 4x4 are not supported", l.name);
         if (igemm_eligible(l)) { relayout_igemm(l, W, w); RY_TRY(upload(arena, ctx, w, &l.wig)); }
@@ -875,6 +890,72 @@ static int choose_splits_1d(const Layer& l, int B, int rows, int mode) {
     return s;
 }
 
+
+// ---- stage-1, output-stationary form (ry_c1d_os) ----
+static int g_s1_os = 1;            // RY_S1_OS=0: the round-1 weight-streaming kernels with split-K slabs (A/B)
+static int g_s1_units = 256;       // RY_S1_UNITS: smallest workgroup count a layer should reach before it takes a larger slice per workgroup
+static int g_s1_force[16][2];      // RY_S1_CFG="layer:cb:tp,...": tuning aid, fixes the (output channels, rows) slice of single layers
+
+static bool c1d_os_capable(const Layer& l) {
+    const int mode = c1d_mode(l);
+    return mode != RY_C1D_GEN && l.act != RY_ACT_GLU && l.k <= 4;
+}
+
+static int c1d_os_ktw(int ctot) { return ctot <= 64 ? 1 : ctot <= 128 ? 2 : 4; }
+
+// slice (cb output channels x tp rows per position group) of one layer: the largest one that still gives g_s1_units workgroups
+static void choose_os(const Layer& l, int B, int rows, int* cb, int* tp) {
+    const bool dec = l.deconv;
+    static const int CF[4][2] = {{4, 8}, {4, 4}, {2, 8}, {2, 4}};
+    const int PG = 4 / c1d_os_ktw(l.cin());
+    int best = -1; long best_units = -1; double best_waste = 1e30;
+    for (int c = 0; c < 4; ++c) {
+        const int b_ = CF[c][0], t_ = CF[c][1];
+        if (dec && b_ * t_ * 2 > 32) continue;                                    // 2 tp outputs per input row
+        const long tiles = (rows + PG * t_ - 1) / (PG * t_);
+        const long units = (long)((l.cout + b_ - 1) / b_) * B * tiles;
+        const double waste = (double)tiles * PG * t_ / rows * ((l.cout + b_ - 1) / b_ * b_) / (double)l.cout;
+        if (units >= g_s1_units && waste <= 1.34) { best = c; break; }             // candidates are ordered by decreasing slice
+        if (units > best_units || (units == best_units && waste < best_waste)) { best = c; best_units = units; best_waste = waste; }
+    }
+    *cb = CF[best][0]; *tp = CF[best][1];
+}
+
+static int launch_c1d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int B, const float* sa, int Ca, const float* sb, int Cb,
+                         float* out, int keep, float slope) {
+    RyC1dOsParams p;
+    memset(&p, 0, sizeof p);
+    p.sa = sa; p.sb = sb; p.Ca = Ca; p.Cb = Cb; p.w = l.w1os; p.scale = l.scale; p.shift = l.shift; p.out = out;
+    p.B = B; p.Lin = lp.Wi; p.Lout = lp.Wo; p.N = l.cout; p.keep = keep; p.pad = l.pad; p.act = l.act; p.slope = slope;
+    p.kt_waves = lp.os_kt;
+    const int mode = c1d_mode(l);
+    const int rows = mode == RY_C1D_DECONV ? lp.Wi : lp.Wo;
+    const int PG = 4 / lp.os_kt;
+    p.tiles = (rows + PG * lp.os_tp - 1) / (PG * lp.os_tp);
+    dim3 grid((unsigned)((l.cout + lp.os_cb - 1) / lp.os_cb), (unsigned)(B * p.tiles));
+    if (grid.y > 65535u) return fail(RY_EINVAL, "%s: batch*tiles = %u exceeds the grid limit", l.name, grid.y);
+    char nm[48];
+    snprintf(nm, sizeof nm, "ry_c1d_os<%s,%d,%d>", mode == RY_C1D_DECONV ? "deconv" : mode == RY_C1D_S2 ? "s2" : "s1", lp.os_cb, lp.os_tp);
+    RY_TRY(Lc.begin(nm, l.name, lp.flops, lp.bytes, grid));
+#define RY_OS_CASE(MODE_, CB_, TP_) if (lp.os_cb == CB_ && lp.os_tp == TP_) { RY_LAUNCH((ry_c1d_os<MODE_, CB_, TP_>), grid, 256, Lc.stream, p); } else
+    switch (mode) {
+        case RY_C1D_S2:
+            RY_OS_CASE(RY_C1D_S2, 4, 8) RY_OS_CASE(RY_C1D_S2, 4, 4) RY_OS_CASE(RY_C1D_S2, 2, 8) RY_OS_CASE(RY_C1D_S2, 2, 4)
+            return fail(RY_EINVAL, "%s: no ry_c1d_os instantiation for slice %dx%d", l.name, lp.os_cb, lp.os_tp);
+            break;
+        case RY_C1D_S1:
+            RY_OS_CASE(RY_C1D_S1, 4, 8) RY_OS_CASE(RY_C1D_S1, 4, 4) RY_OS_CASE(RY_C1D_S1, 2, 8) RY_OS_CASE(RY_C1D_S1, 2, 4)
+            return fail(RY_EINVAL, "%s: no ry_c1d_os instantiation for slice %dx%d", l.name, lp.os_cb, lp.os_tp);
+            break;
+        default:
+            RY_OS_CASE(RY_C1D_DECONV, 4, 4) RY_OS_CASE(RY_C1D_DECONV, 2, 8) RY_OS_CASE(RY_C1D_DECONV, 2, 4)
+            return fail(RY_EINVAL, "%s: no ry_c1d_os instantiation for slice %dx%d", l.name, lp.os_cb, lp.os_tp);
+            break;
+    }
+#undef RY_OS_CASE
+    return Lc.end();
+}
+
 // ------------------------------------------------------------------------------------------------
 // plan construction
 // ------------------------------------------------------------------------------------------------
@@ -910,11 +991,21 @@ static int build_plan(ry_net* net, Plan& P) {
             return fail(RY_EINVAL, "%s: activation exceeds 4 GB (32-bit byte offsets of the implicit GEMM); lower the batch", l.name);
     }
     // buffers
+    if (nd == 1) {
+        P.s1_os = g_s1_os != 0;
+        for (int i = 0; i < 16; ++i) if (!c1d_os_capable(net->layers[i]) || !net->layers[i].w1os) P.s1_os = false;
+    }
     for (int i = 0; i < 16; ++i) {
         const Layer& l = net->layers[i];
         LayerPlan& lp = P.lp[i];
         const size_t out_elems = (size_t)B * lp.Ho * lp.Wo * l.cout;
-        if (nd == 1) {
+        if (nd == 1 && P.s1_os) {
+            const int mode = c1d_mode(l);
+            lp.os_kt = c1d_os_ktw(l.cin());
+            choose_os(l, B, mode == RY_C1D_DECONV ? lp.Wi : lp.Wo, &lp.os_cb, &lp.os_tp);
+            if (g_s1_force[i][0] > 0) { lp.os_cb = g_s1_force[i][0]; lp.os_tp = g_s1_force[i][1]; }
+            if (i < 15) RY_TRY(P.arena.alloc(&lp.out, out_elems));          // the last layer stores straight into the caller's block
+        } else if (nd == 1) {
             const int mode = c1d_mode(l);
             lp.splits = choose_splits_1d(l, B, mode == RY_C1D_DECONV ? lp.Wi : lp.Wo, mode);
             lp.slab_stride = (long long)out_elems;
@@ -1053,7 +1144,12 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
     for (int i = 0; i < 16; ++i) {
         const Layer& l = net->layers[i];
         const LayerPlan& lp = P.lp[i];
-        if (nd == 1) {
+        if (nd == 1 && P.s1_os) {
+            const float* sa = l.src_a < 0 ? (P.mode == 1 ? P.x_in : P.cur_in) : P.lp[l.src_a].out;
+            const float* sb = l.src_b < 0 ? nullptr : P.lp[l.src_b].out;
+            const int keep = (i == 15 && P.mode == 1) ? P.n_frames : lp.Wo;      // the last layer crops to the real frames as it stores
+            RY_TRY(launch_c1d_os(Lc, l, lp, B, sa, l.cin_a, sb, l.cin_b, i == 15 ? P.cur_out : lp.out, keep, slope));
+        } else if (nd == 1) {
             RY_TRY(launch_conv1d(Lc, l, lp, B, src1d_of(net, P, l.src_a), src1d_of(net, P, l.src_b), slope));
         } else {
             const bool in16 = lp.path == PATH_IGEMM_BF16 || lp.last_x3;       // bf16 consumers read the producers' bf16 copies
@@ -1066,7 +1162,9 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
             RY_TRY(launch_conv2d(Lc, l, lq, B, s1, l.cin_a, s2, l.cin_b, slope));
         }
     }
-    if (nd == 1) {
+    if (nd == 1 && P.s1_os) {
+        // nothing left to do: decoder c7 wrote the cropped, dense result
+    } else if (nd == 1) {
         // decoder c7 keeps raw slabs like every stage-1 layer: sum them here, cropping to the real frames in convert mode
         RyMaterializeParams m;
         m.s = src1d_of(net, P, 15); m.L = P.T; m.keep = P.mode == 1 ? P.n_frames : P.T;
@@ -1298,6 +1396,16 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_PLAN_X3_PEAK")) g_x3_peak = atof(e) * 1e6;
     if (const char* e = getenv("RY_PLAN_X3_KG2")) g_x3_kg2 = atof(e);
     if (const char* e = getenv("RY_XCD_GROUPS")) g_xcd_groups = atoi(e);
+    if (const char* e = getenv("RY_S1_OS")) g_s1_os = atoi(e);
+    if (const char* e = getenv("RY_S1_UNITS")) g_s1_units = atoi(e) > 0 ? atoi(e) : 1;
+    memset(g_s1_force, 0, sizeof(g_s1_force));
+    if (const char* e = getenv("RY_S1_CFG")) {
+        for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
+            int i = -1, cb = 0, tp = 0;
+            if (sscanf(q, "%d:%d:%d", &i, &cb, &tp) == 3 && i >= 0 && i < 16 && (cb == 2 || cb == 4) && (tp == 4 || tp == 8)) { g_s1_force[i][0] = cb; g_s1_force[i][1] = tp; }
+            else return fail(RY_EINVAL, "RY_S1_CFG: expected layer:cb:tp[,...] with cb in {2,4}, tp in {4,8}");
+        }
+    }
     if (const char* e = getenv("RY_S1_WGS")) g_s1_wgs = atoi(e);
     if (const char* e = getenv("RY_S1_MAXS")) g_s1_maxs = atoi(e);
     if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);
