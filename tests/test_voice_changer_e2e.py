@@ -12,6 +12,7 @@ from pathlib import Path
 import numpy
 import pytest
 
+from oracle import effective_frame as oef
 from oracle import unet
 from realtime_yukarin_amd import compat, engine, sptk
 from realtime_yukarin_amd.netspec import NetDesc
@@ -77,7 +78,7 @@ def build_converters(models):
 def expected(models, ac, wave, feat):
     """Oracle CNNs + the same host glue, written out step by step (voice_changer.py:24-42)."""
     (_, P1), (_, P2) = models[1], models[2]
-    eff = wave.get_effective_frame(threshold_db=60, fft_length=1024, frame_period=FRAME_PERIOD)[:N]
+    eff = oef.separate_effective_mask(wave.wave, FS, N, 60, 1024, FRAME_PERIOD)      # the independent loop-per-frame gate (A1)
     mc = numpy.zeros((N, 9), numpy.float32)
     mc[eff] = unet.stage1_convert_core(feat['mc'][eff], P1)
     f0 = numpy.zeros((N, 1), numpy.float32)
@@ -138,6 +139,36 @@ def test_mirror_voice_changer_end_to_end(models, on_emulator):
     f_b = Wrapped(**{k: v.copy() for k, v in feat.items()}); f_b.wave = wave
     both = vc.convert_windows([f_a, f_b])
     assert numpy.allclose(both[0].sp, out.sp, rtol=1e-6) and numpy.allclose(both[1].sp, out.sp, rtol=1e-6)
+
+
+def test_all_silent_window_skips_the_stage1_cnn_through_the_wave_gate(models, on_emulator, monkeypatch):
+    """voice_changer.py:32-35: no effective frame -> `f_out = f_in_effective` (the CNN is not called), mc stays all-silent zeros,
+    sp = SuperResolution(mc2sp(0) + 1e-16).  Reached through the wave gate itself (an all-zero and a very quiet window), on the
+    mirror class in both its fused and step-by-step forms."""
+    from realtime_yukarin_amd.voice_changer import VoiceChanger
+    from yukarin import AcousticFeature, Wave
+    ac, sr = build_converters(models)
+    rng = numpy.random.default_rng(8)
+    _, feat = make_input(rng)
+    calls = []
+    real_convert = type(ac).convert
+    monkeypatch.setattr(type(ac), 'convert', lambda self, f: calls.append(len(f.f0)) or real_convert(self, f))
+    want_sp = unet.stage2_convert(numpy.ones((N, 513), numpy.float32), models[2][1])
+
+    class Wrapped(AcousticFeature):
+        pass
+    for amp in (0.0, 3e-6):                                                   # digital silence / -110 dB noise: below the 60 dB gate
+        wave = Wave(wave=(amp * rng.normal(size=N * FS * FRAME_PERIOD // 1000)).astype(numpy.float32), sampling_rate=FS)
+        assert not oef.separate_effective_mask(wave.wave, FS, N, 60, 1024, FRAME_PERIOD).any()
+        for fused in (True, False):
+            vc = VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60)
+            if not fused:
+                vc._fused_core = lambda: None
+            f_in = Wrapped(**{k: v.copy() for k, v in feat.items()}); f_in.wave = wave
+            out = vc.convert_from_acoustic_feature(f_in)
+            assert out.mc.shape == (N, 9) and not out.mc.any() and not out.f0.any() and not out.ap.any() and not out.voiced.any()
+            assert float(numpy.abs(out.sp / want_sp - 1).max()) < 1e-4
+    assert calls == []                                                        # AcousticConverter.convert never ran
 
 
 @pytest.mark.skipif(not REF.exists(), reason='/root/reference is not mounted here')
