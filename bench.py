@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- stage-1 + stage-2 forward throughput of the convert hot path on N MI355X.
+"""bench.py -- throughput of the convert hot path on N MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under
-torch.distributed.run (one rank per GPU, RCCL).  One "step" = one pass of the hot path over one batch of
-synthetic windows already resident in HBM: `AcousticConverter.convert` array part (stage-1) followed by
-`SuperResolution.convert` (stage-2) for `--windows` windows of `--frames` real frames per GPU
-(default: 1 window of 300 frames = buffer_time 0.5 s + 2 x convert_extra_time 0.5 s at 5 ms frames, the
-window /root/reference/config.yaml:14 gives BASELINE config #3).  Windows are independent, so N GPUs take
-N times the windows (weak scaling) with one RCCL broadcast of the weight blobs at start-up and no
-collective in the timed region.  Prints ONE JSON line on rank 0.
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under torch.distributed.run (one rank per
+GPU, RCCL).  One "step" = one pass of the hot path over one window already resident in HBM, CHAINED as
+`VoiceChanger.convert_from_acoustic_feature` chains it (/root/reference/realtime_voice_conversion/yukarin_wrapper/voice_changer.py:
+33-41): effective frames -> stage-1 CNN -> combine_silent -> mc2sp (+1e-16) -> stage-2 CNN -> spectrogram in HBM
+(`ry_vc_enqueue_device`).  Consecutive steps pipeline two deep by themselves: stage-1 of window i + 1 runs on its stream under stage-2
+of window i, as it does for consecutive buffers of a live stream.  Default window: 300 frames = buffer_time 0.5 s + 2 x
+convert_extra_time 0.5 s at 5 ms frames (/root/reference/config.yaml:14; BASELINE config #3).  Windows are independent, so N GPUs take
+N times the windows (weak scaling) with one RCCL broadcast of each weight blob at start-up and no collective in the timed region.
+Prints ONE JSON line on rank 0.
+
+`--force-dist` runs the N > 1 code path (process group, broadcast, barrier, all-reduce of the elapsed time) with ONE rank on one GPU;
+`--comm native` takes RCCL through the C ABI (ry_comm_*) instead of torch.distributed; `--emulator` (tests only) runs the same script on
+the host-side emulator build with gloo -- its numbers mean nothing.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,97 +30,143 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 measured copy
 F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+SP_FLOOR = 1e-16               # voice_changer.py:39
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--frames', type=int, default=300, help='real frames per window (N)')
-    ap.add_argument('--windows', type=int, default=1, help='windows per GPU per step')
-    ap.add_argument('--model', default='SYN-64')
+    ap.add_argument('--extra-frames', type=int, default=None,
+                    help='overlap frames on EACH side of the window that ConvertStream throws away (convert_stream.py:40-42); default 100 '
+                         '(= convert_extra_time 0.5 s) for the 300-frame window, else 0')
+    ap.add_argument('--windows', type=int, default=1, help='windows per GPU per step (converted one after the other)')
+    ap.add_argument('--model', default=None)
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'bf16x3'],
-                    help="stage-2 MFMA operand type ('bf16' = BASELINE config #5: bf16 filters and activations between the implicit-GEMM layers, fp32 "
-                         "accumulation and end layers; 'bf16x3' = split-bf16: every fp32 product as hi*hi + lo*hi + hi*lo on the bf16 pipe, fp32 "
-                         "accumulate, results within ~2e-6 of the fp32 path -- DESIGN.md 4.7)")
+                    help="stage-2 MFMA operand type ('bf16' = BASELINE config #5; 'bf16x3' = split-bf16, DESIGN.md 4.7); the headline is f32")
+    ap.add_argument('--comm', default='torch', choices=['torch', 'native'], help='transport of the weight broadcast / barrier when N > 1')
+    ap.add_argument('--force-dist', action='store_true', help='run the N > 1 code path with one rank (real RCCL init on one GPU)')
+    ap.add_argument('--emulator', action='store_true', help='TESTS ONLY: emulator build of the kernels on the CPU, gloo; numbers are meaningless')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-split-bf16', action='store_true', help="skip the extra 'split_bf16' measurement of an f32 run")
-    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--no-extras', action='store_true', help='headline + roofline only (no host-path, cold-cache, batch or gate measurements)')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--profile-reps', type=int, default=5)
     ap.add_argument('--profile-only', action='store_true', help='only print the per-kernel-family profile of stage-2 (tuning aid)')
     ap.add_argument('--layers-out', default=None, help='write the per-launch profile (layer, kernel, ms, TFLOP/s, GB/s) to this file')
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/*pmc_summary.txt):
-    2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half size, MI355X_MICROARCH.md) + WRITE_SIZE.  None if absent."""
+def source_hash():
+    """Identifies the kernel build a PMC summary belongs to (profiles/*pmc_summary.txt carry it in their header)."""
+    h = hashlib.sha1()
+    for f in ('ry_kernels.h', 'ry_net.cpp', 'ry_dev.h'):
+        h.update((ROOT / 'realtime_yukarin_amd' / 'csrc' / f).read_bytes())
+    return h.hexdigest()[:12]
+
+
+def pmc_table():
+    """{kernel name: (HBM bytes per launch, average us)} from the newest committed PMC summary made from THIS source (2 x FETCH_SIZE +
+    WRITE_SIZE in KB per dispatch: gfx950 counts wide coalesced reads at half size, MI355X_MICROARCH.md).  Empty when no summary of
+    the current kernels exists -- traffic is then reported as null rather than read from an older build."""
     import glob
-    key = kernel_name.replace(' ', '')
+    want = source_hash()
     for path in sorted(glob.glob(str(ROOT / 'profiles' / '*pmc_summary.txt')), reverse=True):
-        for line in open(path):
+        lines = open(path).read().splitlines()
+        if not any(('source ' + want) in ln for ln in lines[:6]):
+            continue
+        tab = {}
+        for line in lines:
             if line.startswith('#') or line.startswith('kernel'):
                 continue
             cols = line.split()
-            if cols and cols[0] == key:                     # the summary writes kernel names as one token without spaces
-                try:
-                    return (2.0 * float(cols[-2]) + float(cols[-1])) * 1024.0, Path(path).name
-                except (ValueError, IndexError):
-                    return None, None
-    return None, None
+            try:
+                tab[cols[0]] = ((2.0 * float(cols[-2]) + float(cols[-1])) * 1024.0, float(cols[2]))
+            except (ValueError, IndexError):
+                pass
+        return tab, Path(path).name
+    return {}, None
 
 
-def main():
-    args = parse()
-    import torch
-    from realtime_yukarin_amd import engine, synth
-    from realtime_yukarin_amd.netspec import flops as net_flops, pad_frames
-
+def main(argv=None):
+    args = parse(argv)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d' % (args.gpus, args.gpus))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU path)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 ... bench.py --gpus %d' % (args.gpus, args.gpus))
+    use_dist = world > 1 or args.force_dist
+    emu = args.emulator
+    model = args.model or ('SYN-8' if emu else 'SYN-64')
 
-    N, Wn = args.frames, args.windows
-    T = N + pad_frames(N)
-    d1, d2 = synth.model_descs(args.model)
-    # ---- weights: rank 0 builds the blobs, one RCCL broadcast each over xGMI, every rank adopts the device buffer
+    from realtime_yukarin_amd import _lib, engine, sptk, synth
     from realtime_yukarin_amd import dist as rdist
+    from realtime_yukarin_amd.netspec import flops as net_flops, pad_frames
     from realtime_yukarin_amd.weights import synthetic_params
-    ctx = engine.get_context(local_rank)
+
+    torch = None
+    if not emu or (use_dist and args.comm == 'torch'):
+        import torch                                            # before the first HIP context: both then share one HIP runtime (INTEGRATION.md 5.2)
+    if emu:
+        from realtime_yukarin_amd import build
+        ctx = engine.Context(0, _lib.Ry355Lib(build.build_emu()))
+        dev = None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU path)')
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+        ctx = engine.get_context(local_rank)
+
+    # ---- process group: one rank per GPU; weights travel once, rank 0 -> everyone, over RCCL
+    comm = None
+    if use_dist:
+        if args.comm == 'native':
+            comm = rdist.NativeComm(ctx, rank, world)
+        else:
+            comm = rdist.TorchComm('gloo' if emu else 'nccl', rank, world, dev)
+    N, Wn = args.frames, args.windows
+    extra = args.extra_frames if args.extra_frames is not None else (100 if N == 300 else 0)
+    T = N + pad_frames(N)
+    d1, d2 = synth.model_descs(model)
     P1 = synthetic_params(d1, synth.SEED_STAGE1) if rank == 0 else None
     P2 = synthetic_params(d2, synth.SEED_STAGE2) if rank == 0 else None
-    net1 = rdist.make_net(ctx, d1, rdist.broadcast_blob(d1, P1, dev))
-    net2 = rdist.make_net(ctx, d2, rdist.broadcast_blob(d2, P2, dev), width=synth.FFT_BINS - 1)
-    del P1, P2
+    if comm is not None:
+        net1 = comm.broadcast_net(ctx, d1, P1)
+        net2 = comm.broadcast_net(ctx, d2, P2, width=synth.FFT_BINS - 1)
+    else:
+        from realtime_yukarin_amd.weights import flatten_params
+        net1 = engine.Net(ctx, d1, flatten_params(d1, P1))
+        net2 = engine.Net(ctx, d2, flatten_params(d2, P2), width=synth.FFT_BINS - 1)
     if args.dtype != 'f32':
         net2.set_dtype(args.dtype)
+    mtx = sptk.mc2sp_matrix(d1.out_ch - 1, sptk.mcepalpha(16000), 2 * (synth.FFT_BINS - 1))
+    core = engine.VcCore(net1, net2, mtx)
 
-    # ---- synthetic windows, resident in HBM before the timed region (different data per rank)
-    x1 = torch.from_numpy(synth.stage1_input(N, Wn, seed=synth.SEED_INPUT + 10 * rank)).to(dev)
-    sp = torch.from_numpy(synth.stage2_input(N, Wn, seed=synth.SEED_INPUT + 10 * rank + 1)).to(dev)
-    y1 = torch.empty(Wn, N, d1.out_ch, dtype=torch.float32, device=dev)
-    y2 = torch.empty_like(sp)
-    torch.cuda.synchronize()
+    def sync_all():
+        ctx.sync()
+        if torch is not None and not emu:
+            torch.cuda.synchronize()
+
+    # ---- synthetic windows, resident in HBM before the timed region (different data per rank); every frame effective (SURVEY.md 8(d))
+    xs_host = synth.stage1_input(N, Wn, seed=synth.SEED_INPUT + 10 * rank)
+    rows_host = numpy.arange(N, dtype=numpy.int32)
+    d_x = [ctx.dev_alloc(N * d1.in_ch) for _ in range(Wn)]
+    for w in range(Wn):
+        ctx.dev_upload(d_x[w], xs_host[w])
+    d_rows = ctx.dev_alloc(N)
+    ctx.dev_upload(d_rows, rows_host)
+    d_mc = [ctx.dev_alloc(N * d1.out_ch) for _ in range(Wn)]
+    d_sp = [ctx.dev_alloc(N * synth.FFT_BINS) for _ in range(Wn)]
+    sync_all()
 
     if args.profile_only:
-        xin = torch.randn(Wn, T, synth.FFT_BINS - 1, device=dev); yout = torch.empty_like(xin)
+        d_in = ctx.dev_alloc(Wn * T * (synth.FFT_BINS - 1)); d_out = ctx.dev_alloc(Wn * T * (synth.FFT_BINS - 1))
+        ctx.dev_upload(d_in, numpy.random.default_rng(0).normal(size=Wn * T * (synth.FFT_BINS - 1)).astype('f4'))
         for _ in range(3):
-            net2.forward_device(xin.data_ptr(), yout.data_ptr(), Wn, T)
+            net2.forward_device(d_in, d_out, Wn, T)
         ctx.sync()
         st = net2.profile(Wn, T, args.profile_reps)
         if args.layers_out:
@@ -127,26 +179,17 @@ def main():
             f = fam.setdefault(q['name'], [0.0, 0.0])
             f[0] += q['ms']; f[1] += q['flops']
         print('total %.1fus | ' % (sum(q['ms'] for q in st) * 1e3) + ' | '.join('%s %.1fus %.1fTF' % (k, v[0] * 1e3, v[1] / max(v[0], 1e-9) / 1e9) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:5]), flush=True)
-        if os.environ.get('RY_TIMING'):
-            import ctypes
-            buf = (ctypes.c_ulonglong * 8)()
-            ctx.lib.dll.ry_debug_igemm_phases.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
-            ctx.lib.check(ctx.lib.dll.ry_debug_igemm_phases(ctx.handle, buf))
-            tot = float(sum(buf[:7])) or 1.0
-            names = ['barrier1', 'lds_write(+vmcnt)', 'barrier2', 'setup/loads', 'mfma steps', 'prologue', 'epilogue']
-            print('   phases: ' + ' '.join('%s=%.1f%%' % (n, 100.0 * buf[i] / tot) for i, n in enumerate(names)) + '  waves=%d cyc/wave=%.0f' % (buf[7], tot / max(buf[7], 1)), flush=True)
-        return
+        return None
 
     def step():
-        net1.convert_device(x1.data_ptr(), y1.data_ptr(), Wn, N)
-        net2.convert_device(sp.data_ptr(), y2.data_ptr(), Wn, N)
+        for w in range(Wn):
+            core.enqueue_device(d_x[w], d_rows, N, N, d_mc[w], d_sp[w], SP_FLOOR)
 
     def fence():
-        ctx.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sync_all()
+        if comm is not None:
+            comm.barrier()
+        sync_all()
 
     def timed():
         # W untimed warm-up steps, then exactly K steps between barrier + synchronize fences; the maximum over the ranks
@@ -160,14 +203,39 @@ def main():
         dms = ctx.timer_stop()
         fence()
         el = time.perf_counter() - t0
-        if dist is not None:
-            te = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            el = float(te.item())
-        assert bool(torch.isfinite(y2).all()) and bool(torch.isfinite(y1).all())
+        if comm is not None:
+            el = comm.max(el)
         return el, dms
 
     elapsed, dev_ms = timed()
+    sp_gpu = numpy.empty((N, synth.FFT_BINS), numpy.float32); ctx.dev_download(d_sp[0], sp_gpu)
+    mc_gpu = numpy.empty((N, d1.out_ch), numpy.float32); ctx.dev_download(d_mc[0], mc_gpu)
+    assert numpy.isfinite(sp_gpu).all() and numpy.isfinite(mc_gpu).all() and (sp_gpu > 0).all()
+
+    frames_total = world * Wn * N * args.steps
+    value = frames_total / elapsed
+    ms_step = elapsed / args.steps * 1e3
+    ms_window = ms_step / Wn
+    out = {
+        'metric': 'acoustic frames/s (stage1+stage2 fwd) @16kHz/5ms',
+        'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic' if not emu else 'synthetic (EMULATOR: CPU test mode, the numbers mean nothing)',
+        # every frame handed to convert counts in `value`; ConvertStream keeps only the buffer in the middle of a
+        # window with extra_time (convert_stream.py:40-42): effective x real-time = buffer_time / t_wall
+        'x_realtime': round(value * 0.005, 1), 'x_realtime_per_gpu': round(value * 0.005 / world, 1),
+        'effective_x_realtime': round((N - 2 * extra) * 0.005 / (ms_window * 1e-3), 1),
+        'effective_x_realtime_note': '%d of the %d frames of a window are overlap context that ConvertStream discards; buffer_time %.2f s / %.4f ms per window'
+                                     % (2 * extra, N, (N - 2 * extra) * 0.005, ms_window),
+        'device_ms_per_step_rank0': round(dev_ms / args.steps, 4),
+        'step': 'chained device-resident core (ry_vc_enqueue_device): stage-1 -> combine_silent -> mc2sp + 1e-16 -> stage-2, two windows in flight',
+        'comm': None if comm is None else comm.kind,
+        'config': {'workload': 'BASELINE config #3: stage-1 + stage-2 SR forward, buffer_time 0.5 s + 2x0.5 s convert_extra_time '
+                               '@16 kHz / 5 ms -> %d real frames (%d padded) per window, %d window(s) per GPU per step, %s random-init weights'
+                               % (N, T, Wn, model),
+                   'model': model, 'frames': N, 'padded_frames': T, 'windows_per_gpu': Wn,
+                   'parallelism': 'chunk-dp%d (independent windows, RCCL weight broadcast at init, no steady-state collective)' % world},
+    }
 
     def time_only(fn, reps=20):
         for _ in range(3):
@@ -176,146 +244,187 @@ def main():
         for _ in range(reps):
             fn()
         return ctx.timer_stop() / reps
-    # PCIe-inclusive single-window latency of the drop-in call path (host arrays in, host arrays out; never the headline value)
-    host_ms = None
-    if rank == 0:
-        from realtime_yukarin_amd import sptk
-        core = engine.VcCore(net1, net2, sptk.mc2sp_matrix(d1.out_ch - 1, sptk.mcepalpha(16000), 2 * (synth.FFT_BINS - 1)))
-        xh = synth.stage1_input(N)[0]; eff = numpy.ones(N, bool)
-        for _ in range(3):
-            core.convert(xh, eff)
-        th = time.perf_counter()
-        for _ in range(20):
-            core.convert(xh, eff)
-        host_ms = (time.perf_counter() - th) / 20 * 1e3
-        core.close()
-    s1_ms = time_only(lambda: net1.convert_device(x1.data_ptr(), y1.data_ptr(), Wn, N))
-    s2_ms = time_only(lambda: net2.convert_device(sp.data_ptr(), y2.data_ptr(), Wn, N))
-    # live per-launch profile (HIP events around every launch of both predictors) for the roofline objects: taken straight after
-    # the timed region, before the cold-cache and split-bf16 extras below change what is resident and how warm the chip is
-    st2 = st1 = None
-    if rank == 0:
-        st2 = net2.profile(Wn, T, args.profile_reps)
-        st1 = net1.profile(Wn, T, args.profile_reps)
-    # stage-1 with its filters evicted (cold next to warm): 512 MiB of scratch is rewritten before every replay,
-    # which pushes the 54 MB of filters out of the L2s and the 256 MB MALL, so this replay streams them from HBM
-    s1_cold_ms = None
-    if rank == 0:
-        scratch = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
-        cold = []
-        for i in range(6):
-            scratch.fill_(i & 1); torch.cuda.synchronize(); ctx.sync()
-            ctx.timer_start()
-            net1.convert_device(x1.data_ptr(), y1.data_ptr(), Wn, N)
-            cold.append(ctx.timer_stop())
-        s1_cold_ms = sorted(cold[1:])[len(cold[1:]) // 2]
-        del scratch
 
-    # the same K steps with stage-2 in split-bf16 mode (three bf16 products per fp32 product on the bf16 matrix pipe, fp32
-    # accumulate) -- reported BESIDE the exact-fp32 headline, never as `value` of an f32 run
-    split = None
-    if args.dtype == 'f32' and not args.no_split_bf16:
-        y2_f32 = y2.clone()
-        net2.set_dtype('bf16x3')
-        el3, _ = timed()
-        s2x_ms = time_only(lambda: net2.convert_device(sp.data_ptr(), y2.data_ptr(), Wn, N))
-        torch.cuda.synchronize(); ctx.sync()
-        err = float(((y2 / y2_f32) - 1.0).abs().max().item())
-        lerr = float(((y2.log() - y2_f32.log()).abs().max() / y2_f32.log().abs().max()).item())
-        net2.set_dtype('f32')
-        split = {'dtype': 'bf16x3', 'value': round(world * Wn * N * args.steps / el3, 1), 'unit': 'frames/s',
-                 'ms_per_step': round(el3 / args.steps * 1e3, 4), 'stage2_alone_ms': round(s2x_ms, 4),
-                 'max_rel_diff_vs_f32_path': err, 'log_spectrum_diff_vs_f32_path': lerr, 'parity_bar': 1e-4,
-                 'note': 'stage-2 MFMA-bound layers as hi*hi + lo*hi + hi*lo bf16 products with fp32 accumulation (rank 0 output compared); '
-                         'opt-in mode (--dtype bf16x3 / ry_net_set_dtype(net, 2)); the headline value above is exact fp32'}
-        del y2_f32
+    if rank == 0 and not emu:
+        d_y1 = ctx.dev_alloc(N * d1.out_ch); d_s2in = ctx.dev_alloc(N * synth.FFT_BINS); d_s2out = ctx.dev_alloc(N * synth.FFT_BINS)
+        ctx.dev_upload(d_s2in, synth.stage2_input(N)[0])
+        s1_ms = time_only(lambda: net1.convert_device(d_x[0], d_y1, 1, N))
+        s2_ms = time_only(lambda: net2.convert_device(d_s2in, d_s2out, 1, N))
+        chain_ms = time_only(lambda: (core.enqueue_device(d_x[0], d_rows, N, N, d_mc[0], d_sp[0], SP_FLOOR), ctx.sync()))   # one window at a time: no overlap
+        out['graph_replay_ms'] = {'stage1_alone': round(s1_ms, 4), 'stage2_alone': round(s2_ms, 4), 'chain_one_window_synced': round(chain_ms, 4)}
+        # live per-launch profile (HIP events around every launch of both predictors) for the roofline objects
+        st2 = net2.profile(1, T, args.profile_reps)
+        st1 = net1.profile(1, T, args.profile_reps)
 
-    frames_total = world * Wn * N * args.steps
-    value = frames_total / elapsed
-    out = {
-        'metric': 'acoustic frames/s (stage1+stage2 fwd) @16kHz/5ms',
-        'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-        'x_realtime': round(value * 0.005, 1), 'x_realtime_per_gpu': round(value * 0.005 / world, 1),
-        'device_ms_per_step_rank0': round(dev_ms / args.steps, 4),
-        'graph_replay_ms': {'stage1_alone': round(s1_ms, 4), 'stage2_alone': round(s2_ms, 4),
-                            'stage1_alone_cold': None if s1_cold_ms is None else round(s1_cold_ms, 4)},
-        'host_call_ms_per_window': None if host_ms is None else round(host_ms, 4),
-        'split_bf16': split,
-        'config': {'workload': 'BASELINE config #3: stage-1 + stage-2 SR forward, buffer_time 0.5 s + 2x0.5 s convert_extra_time '
-                               '@16 kHz / 5 ms -> %d real frames (%d padded) per window, %d window(s) per GPU per step, %s random-init weights'
-                               % (N, T, Wn, args.model),
-                   'model': args.model, 'frames': N, 'padded_frames': T, 'windows_per_gpu': Wn,
-                   'parallelism': 'chunk-dp%d (independent windows, RCCL weight broadcast at init, no steady-state collective)' % world},
-    }
+        if not args.no_extras:
+            # stage-1 with its filters evicted (cold next to warm): 512 MiB of scratch is rewritten before every replay
+            scratch = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+            cold = []
+            for i in range(6):
+                scratch.fill_(i & 1); sync_all()
+                ctx.timer_start()
+                net1.convert_device(d_x[0], d_y1, 1, N)
+                cold.append(ctx.timer_stop())
+            out['graph_replay_ms']['stage1_alone_cold'] = round(sorted(cold[1:])[len(cold[1:]) // 2], 4)
+            del scratch
+            # host windows (PCIe inclusive; never the headline): one at a time, and a stream with windows in flight through the pinned ring
+            xh = xs_host[0]; eff = numpy.ones(N, bool)
+            for _ in range(3):
+                core.convert(xh, eff)
+            th = time.perf_counter()
+            for _ in range(20):
+                core.convert(xh, eff)
+            host_ms = (time.perf_counter() - th) / 20 * 1e3
+            for _ in core.convert_stream([(xh, eff)] * 6, depth=3):
+                pass
+            th = time.perf_counter()
+            for _ in core.convert_stream([(xh, eff)] * 60, depth=3):
+                pass
+            stream_ms = (time.perf_counter() - th) / 60 * 1e3
+            out['host_path'] = {'call_ms_per_window': round(host_ms, 4), 'stream_ms_per_window': round(stream_ms, 4),
+                                'stream_frames_per_s': round(N / (stream_ms * 1e-3), 1),
+                                'note': 'host arrays in, host arrays out through the pinned ring of ry_vc_submit / ry_vc_wait (PCIe inclusive): one window '
+                                        'at a time, and a stream with three windows in flight'}
+            # 8 windows per stage-1 call: the regime in which the filters are amortised (bytes per frame / 8)
+            d_x8 = ctx.dev_alloc(8 * N * d1.in_ch); d_y8 = ctx.dev_alloc(8 * N * d1.out_ch)
+            ctx.dev_upload(d_x8, synth.stage1_input(N, 8))
+            s1x8_ms = time_only(lambda: net1.convert_device(d_x8, d_y8, 8, N))
+            out['stage1_batch8'] = {'ms_per_call': round(s1x8_ms, 4), 'frames_per_s': round(8 * N / (s1x8_ms * 1e-3), 1)}
+            # the silence gate on this box's host (is it worth a kernel?)
+            compat_dir = ROOT / 'realtime_yukarin_amd' / 'compat'
+            sys.path.insert(0, str(compat_dir))
+            from yukarin.wave import Wave
+            wv = Wave((0.1 * numpy.random.default_rng(1).normal(size=N * 80)).astype(numpy.float32), 16000)
+            wv.get_effective_frame(60, 1024, 5)
+            tg = time.perf_counter()
+            for _ in range(20):
+                wv.get_effective_frame(60, 1024, 5)
+            gate_ms = (time.perf_counter() - tg) / 20 * 1e3
+            out['silence_gate_host'] = {'ms_per_window': round(gate_ms, 4), 'fraction_of_window': round(gate_ms / ms_window, 4),
+                                        'note': 'separate_effective mask (numpy, one host thread); it overlaps the GPU work of the previous window'}
 
-    if rank == 0:
-        # ---- roofline of the dominant kernel: HIP events around every launch of the stage-2 predictor, live
+        # the same K steps with stage-2 in split-bf16 mode -- reported BESIDE the exact-fp32 headline, never as `value` of an f32 run
+        if args.dtype == 'f32' and not args.no_split_bf16 and not args.no_extras and world == 1:
+            net2.set_dtype('bf16x3')
+            el3, _ = timed()
+            sp3 = numpy.empty_like(sp_gpu); ctx.dev_download(d_sp[0], sp3)
+            net2.set_dtype('f32')
+            step(); sync_all()
+            out['split_bf16'] = {'dtype': 'bf16x3', 'value': round(world * Wn * N * args.steps / el3, 1), 'unit': 'frames/s',
+                                 'ms_per_step': round(el3 / args.steps * 1e3, 4),
+                                 'max_rel_diff_vs_f32_path': float(numpy.abs(sp3.astype(numpy.float64) / sp_gpu - 1.0).max()), 'parity_bar': 1e-4,
+                                 'note': 'stage-2 MFMA-bound layers as hi*hi + lo*hi + hi*lo bf16 products, fp32 accumulate; opt-in (--dtype bf16x3); the headline is exact fp32'}
+
+        # ---- roofline of the dominant kernel
         if args.layers_out:
             with open(args.layers_out, 'w') as f:
                 for tag, st in (('stage1', st1), ('stage2', st2)):
                     for s in st:
-                        f.write('%-7s %-12s %-26s grid=%-16s %9.2f us %8.2f TFLOP/s %9.1f GB/s\n' % (
+                        f.write('%-7s %-12s %-40s grid=%-16s %9.2f us %8.2f TFLOP/s %9.1f GB/s\n' % (
                             tag, s['layer'], s['name'], 'x'.join(map(str, s['grid'])), s['ms'] * 1e3,
                             s['flops'] / max(s['ms'], 1e-9) / 1e9, s['bytes'] / max(s['ms'], 1e-9) / 1e6))
         fam = {}
         for s in st2 + st1:
             f = fam.setdefault(s['name'], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             f['ms'] += s['ms']; f['flops'] += s['flops']; f['bytes'] += s['bytes']; f['launches'] += 1
-        # dominant kernel = the family with the most time in the stage that bounds the step (stage 2; stage 1 overlaps on its own
-        # stream and has its own HBM roofline object below)
+        # dominant kernel = the family with the most time in the stage that bounds the step (stage 2; stage 1 overlaps on its own stream)
         st2_names = set(s['name'] for s in st2)
-        dom = max(((k, v) for k, v in fam.items() if k in st2_names), key=lambda kv: kv[1]['ms'])
-        dname, dv = dom
+        dname, dv = max(((k, v) for k, v in fam.items() if k in st2_names), key=lambda kv: kv[1]['ms'])
         ach = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(dname)
+        pmc, pmc_file = pmc_table()
         targs = dname[dname.find('<') + 1:-1].split(',') if dname.startswith('ry_igemm_ldsdma<') else []
-        is_bf16 = len(targs) > 5 and targs[5] == 'true'                # ry_igemm_ldsdma<BM,BN,WM,WN,KG,BF16,PATCH>
-        peak_tf = 2500.0 if is_bf16 else F32_MFMA_PEAK_TF             # dense bf16 MFMA peak, else fp32-input MFMA peak
+        is_bf16 = len(targs) > 5 and targs[5] == 'true'
+        peak_tf = 2500.0 if is_bf16 else F32_MFMA_PEAK_TF
         out['roofline'] = {'kernel': dname, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
-                           'frac': round(ach / peak_tf, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
-                           'traffic_source': traffic_src,
+                           'frac': round(ach / peak_tf, 4), 'traffic': pmc.get(dname.replace(' ', ''), (None,))[0],
+                           'traffic_unit': 'HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)',
+                           'traffic_source': pmc_file, 'source_hash': source_hash(),
                            'launches': dv['launches'], 'avg_launch_ms': round(dv['ms'] / dv['launches'], 4),
-                           'alg_flops_per_launch': dv['flops'] / dv['launches']}
-        if args.dtype == 'bf16x3' and is_bf16:      # the matrix pipe executes three bf16 products per algorithmic (fp32) product
+                           'alg_flops_per_launch': dv['flops'] / dv['launches'], 'alg_bytes_per_launch': dv['bytes'] / dv['launches']}
+        if args.dtype == 'bf16x3' and is_bf16:
             out['roofline']['mfma_flops_per_alg_flop'] = 3
+        alg2 = net_flops(d2, T, synth.FFT_BINS - 1)
+        pk2 = F32_MFMA_PEAK_TF if args.dtype == 'f32' else 2500.0
+        out['roofline_stage2_forward'] = {'bound': 'mfma', 'achieved': round(alg2 / (s2_ms * 1e-3) / 1e12, 2), 'peak': pk2,
+                                          'unit': 'TFLOP/s', 'frac': round(alg2 / (s2_ms * 1e-3) / 1e12 / pk2, 4),
+                                          'note': 'all algorithmic FLOPs of the stage-2 forward / graph replay time of the whole forward (end layers, reduces and launches included)'}
         c1 = [s for s in st1 if s['name'].startswith(('ry_c1d_os', 'ry_conv1d_ws'))]
         ms1 = sum(s['ms'] for s in c1); by1 = sum(s['bytes'] for s in c1)
-        out['roofline_stage1'] = {'kernel': '%s<*> (%d launches)' % (c1[0]['name'].split('<')[0], len(c1)), 'bound': 'hbm', 'achieved': round(by1 / (ms1 * 1e-3) / 1e9, 1),
-                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                  'traffic': None, 'alg_bytes_per_forward': by1, 'kernel_ms_per_forward': round(ms1, 4),
+        t1 = [pmc[s['name']][0] for s in c1 if s['name'] in pmc]
+        out['roofline_stage1'] = {'kernel': '%s<*> (%d launches)' % (c1[0]['name'].split('<')[0], len(c1)), 'bound': 'hbm',
+                                  'achieved': round(by1 / (s1_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                  'frac': round(by1 / (s1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  'traffic': sum(t1) if len(t1) == len(c1) else None, 'traffic_unit': 'HBM bytes per forward (sum over the launches)',
+                                  'alg_bytes_per_forward': by1, 'kernel_ms_per_forward': round(s1_ms, 4),
+                                  'kernel_ms_sum_of_eager_launches': round(ms1, 4),
                                   'frac_graph_warm': round(by1 / (s1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                  'frac_graph_cold': None if not s1_cold_ms else round(by1 / (s1_cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                  'note': 'achieved = algorithmic bytes (filters + input + output once) / graph replay time of the whole stage-1 forward'}
+        if 'stage1_alone_cold' in out['graph_replay_ms']:
+            out['roofline_stage1']['frac_graph_cold'] = round(by1 / (out['graph_replay_ms']['stage1_alone_cold'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if 'stage1_batch8' in out:
+            b8 = by1 + 7 * (N * (d1.in_ch + d1.out_ch) * 4)
+            out['stage1_batch8']['alg_bytes_per_frame'] = round(b8 / (8 * N), 1)
+            out['stage1_batch8']['hbm_frac'] = round(b8 / (out['stage1_batch8']['ms_per_call'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out['kernels'] = {k: {'ms': round(v['ms'], 4), 'launches': v['launches'], 'tflops': round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 2)}
                           for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])}
-        out['stage_ms'] = {'stage1_kernels': round(sum(s['ms'] for s in st1), 4), 'stage2_kernels': round(sum(s['ms'] for s in st2), 4)}
-        out['alg'] = {'stage1_gflop': net_flops(d1, T) * Wn / 1e9, 'stage2_gflop': net_flops(d2, T, synth.FFT_BINS - 1) * Wn / 1e9}
+        out['alg'] = {'stage1_gflop': net_flops(d1, T) / 1e9, 'stage2_gflop': alg2 / 1e9}
 
-        # ---- CPU baseline beside it: the oracle's torch/oneDNN restatement on this box's host cores (bounded sample)
+        # ---- CPU baseline beside it: the oracle's torch/oneDNN restatement of the SAME chained window on this box's host cores
         if not args.no_cpu_baseline and world == 1:
-            from oracle import torch_ref
-            from realtime_yukarin_amd.weights import synthetic_params
-            import torch as _t
-            P1 = synthetic_params(d1, synth.SEED_STAGE1); P2 = synthetic_params(d2, synth.SEED_STAGE2)
-            t1n, t2n = torch_ref.TorchUNet(P1), torch_ref.TorchUNet(P2)
-            xs = synth.stage1_input(N)[0]; sps = synth.stage2_input(N)[0]
-            torch_ref.stage1_convert_core(t1n, xs); torch_ref.stage2_convert(t2n, sps)   # warm-up
-            reps, tb = 0, time.perf_counter()
-            while True:
-                torch_ref.stage1_convert_core(t1n, xs); torch_ref.stage2_convert(t2n, sps)
-                reps += 1
-                if time.perf_counter() - tb > args.cpu_seconds or reps >= 50:
-                    break
-            cpu_s = (time.perf_counter() - tb) / reps
-            out['cpu_baseline'] = {'value': round(N / cpu_s, 1), 'unit': 'frames/s', 'cores': _t.get_num_threads(), 'kind': 'port',
-                                   'sample': '%d x (stage-1 + stage-2 convert of one %d-frame window), CPU restatement (torch/oneDNN fp32), not Chainer; host has %d logical cpus'
-                                             % (reps, N, os.cpu_count())}
+            out['cpu_baseline'] = cpu_baseline(args, torch, d1, d2, xs_host[0], mc_gpu, sp_gpu, N, value)
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    net1.close(); net2.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    core.close(); net1.close(); net2.close()
+    if comm is not None:
+        comm.close()
+    return out
+
+
+def cpu_baseline(args, torch, d1, d2, x, mc_gpu, sp_gpu, N, gpu_value):
+    """Bounded sample of the same workload on the host cores: the torch/oneDNN restatement (oracle/torch_ref.py) of stage-1 -> mc2sp ->
+    stage-2 on the window the GPU just converted -- all threads, then one thread -- and the GPU result checked against it."""
+    from oracle import torch_ref
+    from realtime_yukarin_amd import sptk, synth
+    from realtime_yukarin_amd.weights import synthetic_params
+    P1 = synthetic_params(d1, synth.SEED_STAGE1); P2 = synthetic_params(d2, synth.SEED_STAGE2)
+    t1n, t2n = torch_ref.TorchUNet(P1), torch_ref.TorchUNet(P2)
+    alpha = sptk.mcepalpha(16000)
+
+    def chain(xw):
+        mc = torch_ref.stage1_convert_core(t1n, xw)
+        sp_mid = (sptk.mc2sp_fast(mc, alpha, 1024) + SP_FLOOR).astype(numpy.float32)
+        return mc, torch_ref.stage2_convert(t2n, sp_mid)
+    mc_ref, sp_ref = chain(x)                                  # warm-up + the check
+    err_sp = float(numpy.abs(sp_gpu.astype(numpy.float64) / sp_ref - 1).max())
+    err_mc = float(numpy.abs(mc_gpu - mc_ref).max() / numpy.abs(mc_ref).max())
+    reps, tb = 0, time.perf_counter()
+    while True:
+        chain(x); reps += 1
+        if time.perf_counter() - tb > args.cpu_seconds or reps >= 50:
+            break
+    cpu_s = (time.perf_counter() - tb) / reps
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)
+    t1 = time.perf_counter(); chain(x); one_s = time.perf_counter() - t1
+    torch.set_num_threads(nthr)
+    res = {'value': round(N / cpu_s, 1), 'unit': 'frames/s', 'cores': nthr, 'kind': 'port',
+           'sample': '%d x (stage-1 -> mc2sp -> stage-2 of one %d-frame window), CPU restatement (torch/oneDNN fp32), not Chainer; host has %d logical cpus'
+                     % (reps, N, os.cpu_count()),
+           'value_1_thread': round(N / one_s, 1), 'sample_1_thread': '1 x the same window with torch.set_num_threads(1)',
+           'gpu_over_cpu': round(gpu_value / (N / cpu_s), 1),
+           'gpu_result_vs_this_baseline': {'sp_max_rel': err_sp, 'mc_max_norm': err_mc, 'bar': 1e-4}}
+    assert err_sp < 1e-4 and err_mc < 1e-4, 'GPU result of the timed region differs from the CPU restatement: %g %g' % (err_sp, err_mc)
+    # BASELINE config #1, the plumbing baseline: check.py's schedule (/root/reference/check.py:96-125) = 5 windows of 1 s + 2 x 1 s
+    # extra = 600 frames each, converted one after the other; here with the same restatement, one pass
+    x6 = synth.stage1_input(600, 5, seed=synth.SEED_INPUT + 7)
+    t6 = time.perf_counter()
+    for w in range(5):
+        chain(x6[w])
+    c1 = time.perf_counter() - t6
+    res['config1_check_py_schedule'] = {'cpu_s_for_5_windows_of_600_frames': round(c1, 3), 'input_seconds': 5.0, 'cpu_x_realtime': round(5.0 / c1, 2),
+                                        'note': 'convert stage of check.py (5 x 1 s buffers, extra_time 1 s -> 600-frame windows) on the host cores, one pass; '
+                                                'the GPU runs the same schedule in `python bench.py --frames 600 --extra-frames 200`'}
+    return res
 
 
 if __name__ == '__main__':

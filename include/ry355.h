@@ -112,15 +112,58 @@ void ry_vc_destroy(ry_vc* vc);
  * mc_out [n_frames][order+1] (zeros on silent frames), sp_out [n_frames][bins].  n_eff may be 0 (all silent). */
 int ry_vc_convert(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, int n_frames, float sp_floor,
                   float* mc_out, float* sp_out);
+/* The same in two halves, for a convert loop that keeps several windows in flight (the live caller is the worker loop of
+ * realtime_voice_conversion/worker/convert_worker.py:45-59: get -> convert -> put).  ry_vc_submit copies the window into a pinned
+ * ring slot (three slots), queues H2D -> stage-1 -> combine_silent -> mc2sp -> stage-2 -> D2H on the two predictor streams and returns
+ * a ticket WITHOUT waiting; ry_vc_wait blocks for that ticket and copies the results out.  H2D of window i + 1 and D2H of window i - 1
+ * run under the kernels of window i.  ry_vc_convert == submit + wait.  RY_ESTATE when all slots are in flight. */
+int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, int n_frames, float sp_floor, int* ticket);
+int ry_vc_wait(ry_vc* vc, int ticket, float* mc_out, float* sp_out);
+/* All pointers on the device, nothing waited for (ry_sync / your own event): consecutive calls pipeline by themselves -- stage-1 of
+ * window i + 1 runs on its stream under stage-2 of window i.  bench.py times this. */
+int ry_vc_enqueue_device(ry_vc* vc, const float* x_eff_dev, const int* row_of_dev, int n_eff, int n_frames, float sp_floor,
+                         float* mc_out_dev, float* sp_out_dev);
+/* The chain cut where the reference's own class cuts it, so that its unchanged step-by-step calls (voice_changer.py:33-41) keep
+ * the data on the device between the two CNNs:
+ *   ry_vc_stage1         `acoustic_converter.convert(f_in_effective)`: x_eff [n_eff][in_ch] -> y1_out [n_eff][order+1]; the rows
+ *                        also stay on the device;
+ *   ry_vc_stage2_from_mc `combine_silent` + `decode_spectrogram` + `sp += floor` + `super_resolution.convert` from those rows:
+ *                        sp_out [n_frames][bins]; the intermediate spectrogram never visits the host;
+ *   ry_vc_mid_sp         the intermediate spectrogram exp(mc @ mtx) + floor, for a caller that does read it. */
+int ry_vc_stage1(ry_vc* vc, const float* x_eff, int n_eff, float* y1_out);
+int ry_vc_stage2_from_mc(ry_vc* vc, const int* row_of, int n_eff, int n_frames, float sp_floor, float* sp_out);
+int ry_vc_mid_sp(ry_vc* vc, const int* row_of, int n_eff, int n_frames, float sp_floor, float* sp_mid_out);
+int ry_vc_reserve_frames(ry_vc* vc, int n_frames);   /* optional: size the ring ahead of the first window */
 /* `AcousticConverter.decode_spectrogram` alone (host pointers): sp [n][bins] = exp(mc [n][m] @ mtx [m][bins]) + floor. */
 int ry_mc2sp(ry_ctx* ctx, const float* mc, const float* mtx, int n, int m, int bins, float floor, float* sp);
+
+/* ---- chunk parallelism over the GPUs of one node: one RCCL broadcast of each predictor's weight blob from rank 0
+ * at start-up, no collective in the steady state; results are re-ordered by window index on the host exactly as run.py:171-183
+ * re-orders its `Item.index`.  RCCL is bound at run time (dlopen of librccl.so.1, RY_RCCL_LIB overrides), so the library has no
+ * link-time dependency on it and no tensor library is needed: rank 0 calls ry_comm_unique_id and hands the 128 bytes to the other
+ * ranks by any host channel (a file, a socket, MPI, a torch.distributed store -- realtime_yukarin_amd/dist.py uses a file next to
+ * MASTER_PORT), every rank calls ry_comm_init, ry_dev_alloc, (rank 0: ry_dev_upload,) ry_comm_bcast_weights and
+ * ry_net_create(..., weights_on_device = 1). */
+typedef struct ry_comm ry_comm;
+#define RY_COMM_ID_BYTES 128
+int ry_comm_unique_id(void* id128);                                   /* ncclGetUniqueId */
+int ry_comm_init(ry_ctx* ctx, const void* id128, int rank, int world, ry_comm** out);   /* ncclCommInitRank on the context's GPU */
+void ry_comm_destroy(ry_comm* comm);
+int ry_comm_bcast_weights(ry_comm* comm, float* blob_dev, size_t n_floats, int root);  /* in place; returns when it has arrived */
+int ry_comm_allreduce_max(ry_comm* comm, double* value);              /* max over the ranks (timing) */
+int ry_comm_barrier(ry_comm* comm);
+/* device buffers for callers without a tensor library */
+int ry_dev_alloc(ry_ctx* ctx, size_t n_floats, float** out);
+int ry_dev_free(ry_ctx* ctx, float* p);
+int ry_dev_upload(ry_ctx* ctx, float* dst_dev, const float* src_host, size_t n_floats);
+int ry_dev_download(ry_ctx* ctx, float* dst_host, const float* src_dev, size_t n_floats);
 
 /* ---- measurement ---- */
 int ry_timer_start(ry_ctx* ctx);              /* hipEventRecord on the context stream */
 int ry_timer_stop(ry_ctx* ctx, float* ms);    /* record + synchronize + elapsed */
 
 typedef struct ry_kernel_stat {
-    char name[48];          /* kernel family, e.g. "ry_igemm_f32<128,128>" */
+    char name[48];          /* kernel family as rocprofv3 prints it, e.g. "ry_igemm_ldsdma<96,128,1,4,2,false,1>" */
     char layer[24];         /* e.g. "encoder/c3" */
     float ms;               /* average duration over `reps` launches (hipEvents on the context stream) */
     double flops;           /* algorithmic FLOPs of this launch */

@@ -9,7 +9,7 @@ from pathlib import Path
 
 import numpy
 
-from realtime_yukarin_amd import engine
+from realtime_yukarin_amd import engine, fusion
 from realtime_yukarin_amd.netspec import NetDesc
 from realtime_yukarin_amd.weights import flatten_params, load_npz
 
@@ -27,6 +27,7 @@ class SuperResolution(object):
         self._net = None
         self._net_pid = None
         self._bins = None
+        fusion.register_sr(self)
 
     def __getstate__(self):
         d = dict(self.__dict__)
@@ -34,10 +35,22 @@ class SuperResolution(object):
         d['_net_pid'] = None
         return d
 
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        fusion.register_sr(self)
+
+    def device(self) -> int:
+        return int(os.environ.get('RY_DEVICE', '0')) if self.gpu is None else int(self.gpu)
+
+    def close(self) -> None:
+        if self._net is not None and self._net_pid == os.getpid():
+            self._net.close()
+        self._net = None
+
     def _get_net(self, bins: int) -> engine.Net:
         if self._net is None or self._net_pid != os.getpid() or self._bins != bins:
-            device = int(os.environ.get('RY_DEVICE', '0')) if self.gpu is None else int(self.gpu)
-            ctx = engine.get_context(device)
+            self.close()                                       # a predictor for another bin count (or another process) is being replaced: free it
+            ctx = engine.get_context(self.device())
             self._net = engine.Net(ctx, self.desc, flatten_params(self.desc, self._params), width=bins - 1)
             # opt-in arithmetic of the MFMA-bound layers, for callers that cannot pass an argument (run.py / check.py unchanged):
             # RY_SR_DTYPE = f32 (default, exact) | bf16x3 (split-bf16, ~2e-6 from fp32: DESIGN.md 4.7) | bf16 (BASELINE config #5)
@@ -51,5 +64,9 @@ class SuperResolution(object):
 
     def convert(self, input: numpy.ndarray) -> numpy.ndarray:
         """(N, fft_size/2 + 1) float32 spectrogram -> same shape."""
-        sp = numpy.ascontiguousarray(input, dtype=numpy.float32)
+        if isinstance(input, fusion.LazySpectrogram):          # the spectrogram is still on the GPU (fusion.py): continue there
+            out = input.convert_with(self)
+            if out is not None:
+                return out
+        sp = numpy.ascontiguousarray(numpy.asarray(input), dtype=numpy.float32)
         return self._get_net(sp.shape[1]).convert(sp)

@@ -12,7 +12,7 @@ from pathlib import Path
 
 import numpy
 
-from realtime_yukarin_amd import engine, sptk
+from realtime_yukarin_amd import engine, fusion, sptk
 from realtime_yukarin_amd.netspec import NetDesc
 from realtime_yukarin_amd.weights import flatten_params, load_npz
 
@@ -41,20 +41,35 @@ class AcousticConverter(object):
         self._net = None
         self._net_pid = None
         self._alpha_out = None
+        self._link = None
 
     # ---- pickling / fork safety: never carry a live HIP handle across processes
     def __getstate__(self):
         d = dict(self.__dict__)
         d['_net'] = None
         d['_net_pid'] = None
+        d['_link'] = None
         return d
+
+    def device(self) -> int:
+        return _device_of(self.gpu)
 
     def _get_net(self) -> engine.Net:
         if self._net is None or self._net_pid != os.getpid():
             ctx = engine.get_context(_device_of(self.gpu))
             self._net = engine.Net(ctx, self.desc, flatten_params(self.desc, self._params))
             self._net_pid = os.getpid()
+            self._link = None
         return self._net
+
+    def close(self) -> None:
+        """Free the device-resident predictor (and the fused link built on it) in the process that created it."""
+        if self._link is not None and self._link.pid == os.getpid():
+            self._link.close()
+        self._link = None
+        if self._net is not None and self._net_pid == os.getpid():
+            self._net.close()
+        self._net = None
 
     # ---- feature <-> array
     def _sizes(self):
@@ -99,7 +114,12 @@ class AcousticConverter(object):
 
     def convert(self, in_feature: AcousticFeature) -> AcousticFeature:
         x = self._encode_feature(in_feature)
-        y = self._get_net().convert(x)                              # ry_ac_convert: the stage-1 CNN on the MI355X
+        link = fusion.link_for(self) if len(x) else None
+        if link is not None:                                        # ry_vc_stage1: the same CNN; the converted rows also stay on the device
+            y = link.core.convert_stage1(x)
+            link.generation += 1
+        else:
+            y = self._get_net().convert(x)                          # ry_ac_convert: the stage-1 CNN on the MI355X
         d = self._decode_feature(y)
         f0 = in_feature.f0
         if self.f0_converter is not None:
@@ -107,17 +127,30 @@ class AcousticConverter(object):
         out = AcousticFeature(f0=f0, ap=in_feature.ap, voiced=in_feature.voiced)
         for k, v in d.items():
             setattr(out, k, v)
+        if link is not None:
+            out._ry_token = fusion.Token(link, y.copy())
         return out
 
     def combine_silent(self, effective: numpy.ndarray, feature: AcousticFeature) -> AcousticFeature:
         silent = AcousticFeature.silent(len(effective), sizes=self._sizes(), keys=('mc', 'ap', 'f0', 'voiced'))
         silent.indexing_set(effective, feature)
+        tok = getattr(feature, '_ry_token', None)
+        if tok is not None and tok.current() and numpy.array_equal(feature.mc, tok.rows):   # the rows convert() returned, untouched since
+            tok.effective = numpy.array(effective, dtype=bool)
+            silent._ry_token = tok
+            silent._ry_mc = silent.mc
         return silent
 
     def decode_spectrogram(self, feature: AcousticFeature) -> AcousticFeature:
         if self._alpha_out is None:
             self._alpha_out = sptk.mcepalpha(self.out_sampling_rate)
         fftlen = cheaptrick_fft_size(self.out_sampling_rate)
+        tok = getattr(feature, '_ry_token', None)
+        if (tok is not None and tok.effective is not None and tok.current() and feature.mc is getattr(feature, '_ry_mc', None)
+                and numpy.array_equal(feature.mc[tok.effective], tok.rows) and not feature.mc[~tok.effective].any()):
+            # the mc of this feature is still what stage 1 left on the device: the spectrogram is formed there when somebody needs it
+            feature.sp = fusion.LazySpectrogram(tok, feature.mc, self._alpha_out, fftlen, fftlen // 2 + 1)
+            return feature
         # pysptk.mc2sp == exp(mc @ M): every step before the exp is linear (sptk.mc2sp_matrix); float64 on the host like SPTK
         feature.sp = sptk.mc2sp_fast(numpy.asarray(feature.mc, dtype=numpy.float32), alpha=self._alpha_out, fftlen=fftlen)
         return feature

@@ -51,6 +51,9 @@ static err_t event_record(Event&, ry_stream_t) { return 0; }
 static err_t event_sync(Event&) { return 0; }
 static err_t event_elapsed(float* ms, Event&, Event&) { *ms = 0.f; return 0; }
 static err_t stream_wait_event(ry_stream_t, Event&) { return 0; }
+static err_t hmalloc(void** p, size_t bytes) { *p = aligned_alloc(256, (bytes + 255) / 256 * 256); return *p ? 0 : 1; }
+static err_t hfree(void* p) { free(p); return 0; }
+static err_t event_create_fast(Event*) { return 0; }
 #else
 typedef hipError_t err_t;
 static const char* err_str(err_t e) { return hipGetErrorString(e); }
@@ -73,6 +76,9 @@ static err_t event_record(Event& e, ry_stream_t s) { return hipEventRecord(e, s)
 static err_t event_sync(Event& e) { return hipEventSynchronize(e); }
 static err_t event_elapsed(float* ms, Event& a, Event& b) { return hipEventElapsedTime(ms, a, b); }
 static err_t stream_wait_event(ry_stream_t s, Event& e) { return hipStreamWaitEvent(s, e, 0); }
+static err_t hmalloc(void** p, size_t bytes) { return hipHostMalloc(p, bytes ? bytes : 256, hipHostMallocDefault); }   // pinned: async copies really are asynchronous
+static err_t hfree(void* p) { return hipHostFree(p); }
+static err_t event_create_fast(Event* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming); }
 #endif
 }  // namespace rt
 
@@ -378,14 +384,17 @@ struct Plan {
     float* user_out = nullptr;
     float* x_in = nullptr;                    // padded predictor input
     size_t user_in_floats = 0, user_out_floats = 0;
-    int graph_n = -1, last_n = -1;            // convert mode: n_frames the graph was captured for / of the previous call
     bool s1_os = false;                       // stage-1 plan runs the output-stationary kernels (dense activated buffers in lp.out, no slabs)
     const float* cur_in = nullptr;            // where the forward reads the caller's block (staging, or the caller's device buffer)
     float* cur_out = nullptr;                 // where it writes the result
 #ifndef RY_HOST_EMU
-    hipGraphExec_t gexec = nullptr;
-    bool graph_tried = false;
-    ~Plan() { if (gexec) hipGraphExecDestroy(gexec); }
+    // one captured graph per (input, output) address pair the plan has been run with: host callers (plan staging), device callers
+    // and the ring slots of ry_vc each keep their own, so switching between them neither re-captures nor destroys an exec that
+    // may still be in flight
+    struct GraphSlot { const float* in; float* out; hipGraphExec_t gexec; bool tried; int graph_n, last_n; unsigned long long used; };
+    std::vector<GraphSlot> gslots;
+    unsigned long long gclock = 0;
+    ~Plan() { for (GraphSlot& g : gslots) if (g.gexec) hipGraphExecDestroy(g.gexec); }
 #endif
 };
 
@@ -935,7 +944,7 @@ static int launch_c1d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     dim3 grid((unsigned)((l.cout + lp.os_cb - 1) / lp.os_cb), (unsigned)(B * p.tiles));
     if (grid.y > 65535u) return fail(RY_EINVAL, "%s: batch*tiles = %u exceeds the grid limit", l.name, grid.y);
     char nm[48];
-    snprintf(nm, sizeof nm, "ry_c1d_os<%s,%d,%d>", mode == RY_C1D_DECONV ? "deconv" : mode == RY_C1D_S2 ? "s2" : "s1", lp.os_cb, lp.os_tp);
+    snprintf(nm, sizeof nm, "ry_c1d_os<%d,%d,%d>", mode, lp.os_cb, lp.os_tp);        // as rocprofv3 prints it (MODE: 0 = k4 s2 conv, 1 = stride-1 conv, 2 = k4 s2 deconv)
     RY_TRY(Lc.begin(nm, l.name, lp.flops, lp.bytes, grid));
 #define RY_OS_CASE(MODE_, CB_, TP_) if (lp.os_cb == CB_ && lp.os_tp == TP_) { RY_LAUNCH((ry_c1d_os<MODE_, CB_, TP_>), grid, 256, Lc.stream, p); } else
     switch (mode) {
@@ -1296,44 +1305,52 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
     const int rows_now = P.mode == 1 ? P.n_frames : P.T;
     const size_t in_bytes = P.user_in_floats / P.T * rows_now * sizeof(float), out_bytes = P.user_out_floats / P.T * rows_now * sizeof(float);
     // device callers: kernels read / write the caller's buffers directly (no staging copies); the graph is
-    // re-captured only when those addresses change.  host callers: pinned-size staging buffers of the plan.
+    // captured once per address pair (Plan::gslots).  host callers: the plan's device staging buffers.
     const float* want_in = on_device ? x : P.user_in;
     float* want_out = on_device ? y : P.user_out;
-    if (want_in != P.cur_in || want_out != P.cur_out) {
-        P.cur_in = want_in; P.cur_out = want_out;
-#ifndef RY_HOST_EMU
-        if (P.gexec) { hipGraphExecDestroy(P.gexec); P.gexec = nullptr; }
-        P.graph_tried = false;
-#endif
-    }
+    P.cur_in = want_in; P.cur_out = want_out;
     if (!on_device) RT_TRY(rt::h2d(P.user_in, x, in_bytes, net->stream));
     Launcher Lc{net, ctx, net->stream, nullptr, nullptr};
 #ifndef RY_HOST_EMU
+    Plan::GraphSlot* G = nullptr;
+    for (Plan::GraphSlot& g : P.gslots) if (g.in == want_in && g.out == want_out) G = &g;
+    if (!G) {
+        if (P.gslots.size() >= 8) {                       // bounded: evict the least recently used pair (its exec may be in flight: drain first)
+            size_t lru = 0;
+            for (size_t i = 1; i < P.gslots.size(); ++i) if (P.gslots[i].used < P.gslots[lru].used) lru = i;
+            RT_TRY(rt::stream_sync(net->stream));
+            if (P.gslots[lru].gexec) hipGraphExecDestroy(P.gslots[lru].gexec);
+            P.gslots.erase(P.gslots.begin() + (long)lru);
+        }
+        P.gslots.push_back(Plan::GraphSlot{want_in, want_out, nullptr, false, -1, -1, 0});
+        G = &P.gslots.back();
+    }
+    G->used = ++P.gclock;
     // the captured graph bakes n_frames into the wrapper kernels: replay only for the same n; a new n runs eagerly once and is
     // captured when it repeats (live windows have a constant n; windows cut by the silence gate vary)
-    if (P.gexec && P.graph_n != P.n_frames) {
-        if (P.last_n == P.n_frames) { hipGraphExecDestroy(P.gexec); P.gexec = nullptr; P.graph_tried = false; }
+    if (G->gexec && G->graph_n != P.n_frames && G->last_n == P.n_frames) {
+        RT_TRY(rt::stream_sync(net->stream));             // the exec being replaced may still be running
+        hipGraphExecDestroy(G->gexec); G->gexec = nullptr; G->tried = false;
     }
-    const bool replay_ok = P.gexec && P.graph_n == P.n_frames;
-    const bool capture_now = net->use_graph && !P.graph_tried && (P.mode == 0 || P.last_n == P.n_frames || P.last_n < 0);
-    P.last_n = P.n_frames;
+    const bool capture_now = net->use_graph && !G->tried && (P.mode == 0 || G->last_n == P.n_frames || G->last_n < 0);
+    G->last_n = P.n_frames;
     if (capture_now) {
-        P.graph_tried = true;
-        P.graph_n = P.n_frames;
+        G->tried = true;
+        G->graph_n = P.n_frames;
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(net->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int r = enqueue_forward(net, P, Lc);
             hipError_t e = hipStreamEndCapture(net->stream, &graph);
             if (r == RY_OK && e == hipSuccess && graph) {
-                if (hipGraphInstantiate(&P.gexec, graph, nullptr, nullptr, 0) != hipSuccess) P.gexec = nullptr;
+                if (hipGraphInstantiate(&G->gexec, graph, nullptr, nullptr, 0) != hipSuccess) G->gexec = nullptr;
             }
             if (graph) hipGraphDestroy(graph);
             (void)hipGetLastError();
             if (r != RY_OK) return r;
         }
     }
-    if (P.gexec && (replay_ok || P.graph_n == P.n_frames)) {
-        RT_TRY(hipGraphLaunch(P.gexec, net->stream));
+    if (G->gexec && G->graph_n == P.n_frames) {
+        RT_TRY(hipGraphLaunch(G->gexec, net->stream));
     } else
 #endif
     {
@@ -1690,7 +1707,22 @@ int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat*
 // ---- device-resident VoiceChanger core -----------------------------------------------------------
 }  // extern "C"
 
+// One window in flight = one ring slot: pinned host staging (so that hipMemcpyAsync really is asynchronous and H2D of window
+// i + 1 / D2H of window i - 1 run under the kernels of window i), the device intermediates, and two events.
+struct VcSlot {
+    float *h_x = nullptr, *h_mc = nullptr, *h_sp = nullptr;   // pinned
+    int* h_row = nullptr;                                       // pinned
+    float *d_x = nullptr, *d_y1 = nullptr, *d_mc = nullptr, *d_sp = nullptr, *d_out = nullptr;
+    int* d_row = nullptr;
+    rt::Event ev_mid;        // stage-1 stream: the spectrogram of this window is in d_sp (and mc in h_mc)
+    rt::Event ev_done;       // stage-2 stream: everything of this window is done (sp in h_sp / the caller's device block)
+    bool used = false;       // ev_done has been recorded at least once
+    int ticket = -1;         // ticket of the window occupying the slot (submit .. wait), -1 = free
+    int n_eff = 0, n_frames = 0;
+};
+
 struct ry_vc {
+    static const int RING = 3;
     ry_net* s1 = nullptr;
     ry_net* s2 = nullptr;
     int M = 0, F = 0;
@@ -1698,28 +1730,82 @@ struct ry_vc {
     float* d_mtx = nullptr;
     // per-shape buffers (re-allocated when a larger window arrives)
     Arena bufs;
+    std::vector<void*> pinned;
     int cap_eff = 0, cap_frames = 0;
-    float *d_x = nullptr, *d_y1 = nullptr, *d_mc = nullptr, *d_sp = nullptr, *d_out = nullptr;
-    int* d_row = nullptr;
-    rt::Event ev;
+    VcSlot slot[RING];
     bool has_ev = false;
+    int next_ticket = 0;
+    int dev_count = 0;       // device-pointer calls (ry_vc_enqueue_device) take the slots round robin
+    int split_eff = -1;      // ry_vc_stage1 left the converted rows of this many effective frames in slot 0's d_y1 (-1: nothing)
+    void free_pinned() { for (void* q : pinned) rt::hfree(q); pinned.clear(); }
 };
+
+static int vc_halloc(ry_vc* vc, void** p, size_t bytes) {
+    rt::err_t e = rt::hmalloc(p, bytes);
+    if (e != 0) return fail(RY_ENOMEM, "pinned host allocation of %zu bytes failed: %s", bytes, rt::err_str(e));
+    vc->pinned.push_back(*p);
+    return RY_OK;
+}
 
 static int vc_reserve(ry_vc* vc, int n_eff, int n_frames) {
     if (n_eff <= vc->cap_eff && n_frames <= vc->cap_frames) return RY_OK;
+    for (VcSlot& sl : vc->slot)
+        if (sl.ticket >= 0) return fail(RY_ESTATE, "a larger window arrived while ticket %d is still in flight: ry_vc_wait it first", sl.ticket);
     rt::stream_sync(vc->s1->stream); rt::stream_sync(vc->s2->stream);
-    vc->bufs.release();
+    vc->bufs.release(); vc->free_pinned();
     const int ce = n_eff > vc->cap_eff ? n_eff : vc->cap_eff, cf = n_frames > vc->cap_frames ? n_frames : vc->cap_frames;
     const int cin = vc->s1->desc.in_ch;
-    float* rowbuf = nullptr;
-    RY_TRY(vc->bufs.alloc(&vc->d_x, (size_t)(ce > 0 ? ce : 1) * cin));
-    RY_TRY(vc->bufs.alloc(&vc->d_y1, (size_t)(ce > 0 ? ce : 1) * vc->M));
-    RY_TRY(vc->bufs.alloc(&rowbuf, (size_t)(ce > 0 ? ce : 1)));
-    RY_TRY(vc->bufs.alloc(&vc->d_mc, (size_t)cf * vc->M));
-    RY_TRY(vc->bufs.alloc(&vc->d_sp, (size_t)cf * vc->F));
-    RY_TRY(vc->bufs.alloc(&vc->d_out, (size_t)cf * vc->F));
-    vc->d_row = (int*)rowbuf;
+    const size_t e1 = (size_t)(ce > 0 ? ce : 1);
+    for (VcSlot& sl : vc->slot) {
+        float* rowbuf = nullptr;
+        RY_TRY(vc->bufs.alloc(&sl.d_x, e1 * cin));
+        RY_TRY(vc->bufs.alloc(&sl.d_y1, e1 * vc->M));
+        RY_TRY(vc->bufs.alloc(&rowbuf, e1));
+        RY_TRY(vc->bufs.alloc(&sl.d_mc, (size_t)cf * vc->M));
+        RY_TRY(vc->bufs.alloc(&sl.d_sp, (size_t)cf * vc->F));
+        RY_TRY(vc->bufs.alloc(&sl.d_out, (size_t)cf * vc->F));
+        sl.d_row = (int*)rowbuf;
+        RY_TRY(vc_halloc(vc, (void**)&sl.h_x, e1 * cin * sizeof(float)));
+        RY_TRY(vc_halloc(vc, (void**)&sl.h_row, e1 * sizeof(int)));
+        RY_TRY(vc_halloc(vc, (void**)&sl.h_mc, (size_t)cf * vc->M * sizeof(float)));
+        RY_TRY(vc_halloc(vc, (void**)&sl.h_sp, (size_t)cf * vc->F * sizeof(float)));
+        sl.used = false;
+    }
     vc->cap_eff = ce; vc->cap_frames = cf;
+    vc->split_eff = -1;
+    return RY_OK;
+}
+
+// scatter the converted rows into the all-silent block, then sp = exp(mc @ M) + floor   (stage-1 stream)
+static int vc_enqueue_mid(ry_vc* vc, const float* y1, const int* row_of, int n_eff, int n_frames, float sp_floor, float* mc, float* sp) {
+    ry_net* s1 = vc->s1;
+    ry_stream_t st1 = s1->stream;
+    Launcher Lc{s1, s1->ctx, st1, nullptr, nullptr};
+    const int M = vc->M, F = vc->F;
+    RT_TRY(rt::dmemset(mc, 0, (size_t)n_frames * M * sizeof(float), st1));            // silent frames: zeros (AcousticFeature.silent)
+    if (n_eff > 0) {
+        RyScatterParams sc;
+        sc.src = y1; sc.row_of = row_of; sc.dst = mc; sc.n_src = n_eff; sc.cols = M;
+        dim3 sg((unsigned)(((long long)n_eff * M + 255) / 256));
+        RY_TRY(Lc.begin("ry_scatter_rows", "combine_silent", 0, 0, sg));
+        RY_LAUNCH(ry_scatter_rows, sg, 256, st1, sc);
+        RY_TRY(Lc.end());
+    }
+    RyMc2spParams mp;
+    mp.mc = mc; mp.mtx = vc->d_mtx; mp.sp = sp; mp.n = n_frames; mp.m = M; mp.f = F; mp.floor = sp_floor;
+    dim3 mg((unsigned)(((long long)n_frames * F + 255) / 256));
+    RY_TRY(Lc.begin("ry_mc2sp", "decode_spectrogram", 0, 0, mg));
+    RY_LAUNCH(ry_mc2sp, mg, 256, st1, mp);
+    RY_TRY(Lc.end());
+    return RY_OK;
+}
+
+static int vc_check(const ry_vc* vc, const int* row_of, int n_eff, int n_frames, bool host_rows) {
+    if (!vc) return fail(RY_EINVAL, "null argument");
+    if (n_frames < 1 || n_eff < 0 || n_eff > n_frames) return fail(RY_EINVAL, "bad frame counts (%d effective of %d)", n_eff, n_frames);
+    if (host_rows)
+        for (int i = 0; i < n_eff; ++i)
+            if (row_of[i] < 0 || row_of[i] >= n_frames) return fail(RY_EINVAL, "row_of[%d] = %d is outside the window", i, row_of[i]);
     return RY_OK;
 }
 
@@ -1737,7 +1823,7 @@ int ry_vc_create(ry_net* s1, ry_net* s2, const float* mtx, int M, int F, ry_vc**
     vc->s1 = s1; vc->s2 = s2; vc->M = M; vc->F = F;
     std::vector<float> h(mtx, mtx + (size_t)M * F);
     RY_TRY(upload(vc->arena, s1->ctx, h, &vc->d_mtx));
-    RT_TRY(rt::event_create(&vc->ev));
+    for (VcSlot& sl : vc->slot) { RT_TRY(rt::event_create_fast(&sl.ev_mid)); RT_TRY(rt::event_create_fast(&sl.ev_done)); }
     vc->has_ev = true;
     *out = vc.release();
     return RY_OK;
@@ -1747,49 +1833,186 @@ void ry_vc_destroy(ry_vc* vc) {
     if (!vc) return;
     rt::set_device(vc->s1->ctx->device);
     rt::stream_sync(vc->s1->stream); rt::stream_sync(vc->s2->stream);
-    if (vc->has_ev) rt::event_destroy(vc->ev);
+    if (vc->has_ev) for (VcSlot& sl : vc->slot) { rt::event_destroy(sl.ev_mid); rt::event_destroy(sl.ev_done); }
+    vc->free_pinned();
     delete vc;
+}
+
+// Host window in, ticket out: returns as soon as the copies and kernels are queued (nothing is waited for).
+int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, int n_frames, float sp_floor, int* ticket) {
+    if (!vc || !ticket || (n_eff > 0 && (!x_eff || !row_of))) return fail(RY_EINVAL, "null argument");
+    RY_TRY(vc_check(vc, row_of, n_eff, n_frames, true));
+    ry_net *s1 = vc->s1, *s2 = vc->s2;
+    RT_TRY(rt::set_device(s1->ctx->device));
+    RY_TRY(vc_reserve(vc, n_eff, n_frames));
+    const int t = vc->next_ticket;
+    VcSlot& sl = vc->slot[t % ry_vc::RING];
+    if (sl.ticket >= 0) return fail(RY_ESTATE, "all %d ring slots are in flight: ry_vc_wait ticket %d first", ry_vc::RING, sl.ticket);
+    const int cin = s1->desc.in_ch, M = vc->M, F = vc->F;
+    ry_stream_t st1 = s1->stream, st2 = s2->stream;
+    if (sl.used) RT_TRY(rt::stream_wait_event(st1, sl.ev_done));                        // (a device-pointer call may have used the slot last)
+    if (n_eff > 0) {
+        memcpy(sl.h_x, x_eff, (size_t)n_eff * cin * sizeof(float));
+        memcpy(sl.h_row, row_of, (size_t)n_eff * sizeof(int));
+        RT_TRY(rt::h2d(sl.d_x, sl.h_x, (size_t)n_eff * cin * sizeof(float), st1));
+        RT_TRY(rt::h2d(sl.d_row, sl.h_row, (size_t)n_eff * sizeof(int), st1));
+        RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1));                       // stage-1 CNN on the effective frames
+    }
+    RY_TRY(vc_enqueue_mid(vc, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp));
+    RT_TRY(rt::d2h(sl.h_mc, sl.d_mc, (size_t)n_frames * M * sizeof(float), st1));
+    RT_TRY(rt::event_record(sl.ev_mid, st1));
+    RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));                                      // stage-2 starts when the spectrogram is ready
+    RY_TRY(ry_sr_convert(s2, sl.d_sp, sl.d_out, 1, n_frames, 1));
+    RT_TRY(rt::d2h(sl.h_sp, sl.d_out, (size_t)n_frames * F * sizeof(float), st2));
+    RT_TRY(rt::event_record(sl.ev_done, st2));
+    sl.used = true; sl.ticket = t; sl.n_eff = n_eff; sl.n_frames = n_frames;
+    vc->split_eff = -1;
+    vc->next_ticket = t + 1;
+    *ticket = t;
+    return RY_OK;
+}
+
+int ry_vc_wait(ry_vc* vc, int ticket, float* mc_out, float* sp_out) {
+    if (!vc || !mc_out || !sp_out) return fail(RY_EINVAL, "null argument");
+    if (ticket < 0) return fail(RY_EINVAL, "bad ticket %d", ticket);
+    VcSlot& sl = vc->slot[ticket % ry_vc::RING];
+    if (sl.ticket != ticket) return fail(RY_ESTATE, "ticket %d is not in flight (already waited for, or never submitted)", ticket);
+    RT_TRY(rt::set_device(vc->s1->ctx->device));
+    RT_TRY(rt::event_sync(sl.ev_done));            // ev_done follows ev_mid in stream order (stage-2 waited for it)
+    memcpy(mc_out, sl.h_mc, (size_t)sl.n_frames * vc->M * sizeof(float));
+    memcpy(sp_out, sl.h_sp, (size_t)sl.n_frames * vc->F * sizeof(float));
+    sl.ticket = -1;
+    return RY_OK;
 }
 
 int ry_vc_convert(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, int n_frames, float sp_floor,
                   float* mc_out, float* sp_out) {
-    if (!vc || !mc_out || !sp_out || (n_eff > 0 && (!x_eff || !row_of))) return fail(RY_EINVAL, "null argument");
-    if (n_frames < 1 || n_eff < 0 || n_eff > n_frames) return fail(RY_EINVAL, "bad frame counts (%d effective of %d)", n_eff, n_frames);
-    for (int i = 0; i < n_eff; ++i)
-        if (row_of[i] < 0 || row_of[i] >= n_frames) return fail(RY_EINVAL, "row_of[%d] = %d is outside the window", i, row_of[i]);
+    if (!vc || !mc_out || !sp_out) return fail(RY_EINVAL, "null argument");
+    int t = -1;
+    RY_TRY(ry_vc_submit(vc, x_eff, row_of, n_eff, n_frames, sp_floor, &t));
+    return ry_vc_wait(vc, t, mc_out, sp_out);
+}
+
+// Everything on the device, nothing waited for: consecutive calls pipeline by themselves (stage-1 of window i + 1 runs on
+// its stream under stage-2 of window i); the intermediates rotate through the ring slots, ordered by events.
+int ry_vc_enqueue_device(ry_vc* vc, const float* x_eff_dev, const int* row_of_dev, int n_eff, int n_frames, float sp_floor,
+                         float* mc_out_dev, float* sp_out_dev) {
+    if (!vc || !mc_out_dev || !sp_out_dev || (n_eff > 0 && (!x_eff_dev || !row_of_dev))) return fail(RY_EINVAL, "null argument");
+    RY_TRY(vc_check(vc, nullptr, n_eff, n_frames, false));
     ry_net *s1 = vc->s1, *s2 = vc->s2;
-    ry_ctx* ctx = s1->ctx;
-    RT_TRY(rt::set_device(ctx->device));
+    RT_TRY(rt::set_device(s1->ctx->device));
     RY_TRY(vc_reserve(vc, n_eff, n_frames));
-    const int cin = s1->desc.in_ch, M = vc->M, F = vc->F;
-    ry_stream_t st1 = s1->stream;
-    Launcher Lc{s1, ctx, st1, nullptr, nullptr};
-    RT_TRY(rt::dmemset(vc->d_mc, 0, (size_t)n_frames * M * sizeof(float), st1));      // silent frames: zeros (AcousticFeature.silent)
-    if (n_eff > 0) {
-        RT_TRY(rt::h2d(vc->d_x, x_eff, (size_t)n_eff * cin * sizeof(float), st1));
-        RT_TRY(rt::h2d(vc->d_row, row_of, (size_t)n_eff * sizeof(int), st1));
-        RY_TRY(ry_ac_convert(s1, vc->d_x, vc->d_y1, 1, n_eff, 1));                     // stage-1 CNN on the effective frames
-        RyScatterParams sc;
-        sc.src = vc->d_y1; sc.row_of = vc->d_row; sc.dst = vc->d_mc; sc.n_src = n_eff; sc.cols = M;
-        dim3 sg((unsigned)(((long long)n_eff * M + 255) / 256));
-        RY_TRY(Lc.begin("ry_scatter_rows", "combine_silent", 0, 0, sg));
-        RY_LAUNCH(ry_scatter_rows, sg, 256, st1, sc);
-        RY_TRY(Lc.end());
-    }
-    RyMc2spParams mp;
-    mp.mc = vc->d_mc; mp.mtx = vc->d_mtx; mp.sp = vc->d_sp; mp.n = n_frames; mp.m = M; mp.f = F; mp.floor = sp_floor;
-    dim3 mg((unsigned)(((long long)n_frames * F + 255) / 256));
-    RY_TRY(Lc.begin("ry_mc2sp", "decode_spectrogram", 0, 0, mg));
-    RY_LAUNCH(ry_mc2sp, mg, 256, st1, mp);
-    RY_TRY(Lc.end());
-    RT_TRY(rt::d2h(mc_out, vc->d_mc, (size_t)n_frames * M * sizeof(float), st1));
-    RT_TRY(rt::event_record(vc->ev, st1));
-    RT_TRY(rt::stream_wait_event(s2->stream, vc->ev));                                  // stage-2 starts when the spectrogram is ready
-    RY_TRY(ry_sr_convert(s2, vc->d_sp, vc->d_out, 1, n_frames, 1));
-    RT_TRY(rt::d2h(sp_out, vc->d_out, (size_t)n_frames * F * sizeof(float), s2->stream));
-    RT_TRY(rt::stream_sync(st1));
-    RT_TRY(rt::stream_sync(s2->stream));
+    VcSlot& sl = vc->slot[vc->dev_count % ry_vc::RING];
+    if (sl.ticket >= 0) return fail(RY_ESTATE, "ring slot %d is held by ticket %d: ry_vc_wait it first", vc->dev_count % ry_vc::RING, sl.ticket);
+    ++vc->dev_count;
+    ry_stream_t st1 = s1->stream, st2 = s2->stream;
+    if (sl.used) RT_TRY(rt::stream_wait_event(st1, sl.ev_done));                        // the slot's previous window has left d_sp
+    if (n_eff > 0) RY_TRY(ry_ac_convert(s1, x_eff_dev, sl.d_y1, 1, n_eff, 1));
+    RY_TRY(vc_enqueue_mid(vc, sl.d_y1, row_of_dev, n_eff, n_frames, sp_floor, mc_out_dev, sl.d_sp));
+    RT_TRY(rt::event_record(sl.ev_mid, st1));
+    RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));
+    RY_TRY(ry_sr_convert(s2, sl.d_sp, sp_out_dev, 1, n_frames, 1));
+    RT_TRY(rt::event_record(sl.ev_done, st2));
+    sl.used = true;
+    vc->split_eff = -1;
     return RY_OK;
+}
+
+// ---- the same chain cut where the reference's own VoiceChanger cuts it (voice_changer.py:33-41), so that its unchanged
+// step-by-step calls still keep the data on the device between the two CNNs:
+//   ry_vc_stage1          = AcousticConverter.convert            : H2D of the effective frames, stage-1, D2H of the converted rows
+//   ry_vc_stage2_from_mc  = combine_silent + decode_spectrogram + `+ floor` + SuperResolution.convert, from the rows stage 1 left
+//                           on the device: one D2H of the spectrogram; the intermediate spectrogram never visits the host
+//   ry_vc_mid_sp          = the intermediate spectrogram, for a caller that does read it
+int ry_vc_stage1(ry_vc* vc, const float* x_eff, int n_eff, float* y1_out) {
+    if (!vc || !x_eff || !y1_out || n_eff < 1) return fail(RY_EINVAL, "bad argument");
+    ry_net* s1 = vc->s1;
+    RT_TRY(rt::set_device(s1->ctx->device));
+    RY_TRY(vc_reserve(vc, n_eff, n_eff));
+    VcSlot& sl = vc->slot[0];
+    if (sl.ticket >= 0) return fail(RY_ESTATE, "ring slot 0 is held by ticket %d: ry_vc_wait it first", sl.ticket);
+    const int cin = s1->desc.in_ch;
+    if (sl.used) RT_TRY(rt::stream_wait_event(s1->stream, sl.ev_done));
+    memcpy(sl.h_x, x_eff, (size_t)n_eff * cin * sizeof(float));
+    RT_TRY(rt::h2d(sl.d_x, sl.h_x, (size_t)n_eff * cin * sizeof(float), s1->stream));
+    RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1));
+    RT_TRY(rt::d2h(sl.h_mc, sl.d_y1, (size_t)n_eff * vc->M * sizeof(float), s1->stream));
+    RT_TRY(rt::stream_sync(s1->stream));
+    memcpy(y1_out, sl.h_mc, (size_t)n_eff * vc->M * sizeof(float));
+    vc->split_eff = n_eff;
+    return RY_OK;
+}
+
+// the window is longer than the ring was sized for: grow it without losing the rows stage 1 left in slot 0
+static int vc_grow_keep_rows(ry_vc* vc, int n_frames) {
+    if (n_frames <= vc->cap_frames) return RY_OK;
+    const int keep = vc->split_eff;
+    if (keep <= 0) return vc_reserve(vc, vc->cap_eff, n_frames);
+    Arena tmp;
+    float* t = nullptr;
+    RY_TRY(tmp.alloc(&t, (size_t)keep * vc->M));
+    RT_TRY(rt::d2d(t, vc->slot[0].d_y1, (size_t)keep * vc->M * sizeof(float), vc->s1->stream));
+    RT_TRY(rt::stream_sync(vc->s1->stream));
+    RY_TRY(vc_reserve(vc, vc->cap_eff, n_frames));
+    RT_TRY(rt::d2d(vc->slot[0].d_y1, t, (size_t)keep * vc->M * sizeof(float), vc->s1->stream));
+    RT_TRY(rt::stream_sync(vc->s1->stream));
+    vc->split_eff = keep;
+    return RY_OK;
+}
+
+static int vc_split_mid(ry_vc* vc, const int* row_of, int n_eff, int n_frames, float sp_floor) {
+    RY_TRY(vc_check(vc, row_of, n_eff, n_frames, true));
+    if (n_eff > 0 && !row_of) return fail(RY_EINVAL, "null argument");
+    if (n_eff > 0 && vc->split_eff != n_eff)
+        return fail(RY_ESTATE, "ry_vc_stage1 left %d converted rows on the device, this call asks for %d", vc->split_eff, n_eff);
+    RT_TRY(rt::set_device(vc->s1->ctx->device));
+    RY_TRY(vc_grow_keep_rows(vc, n_frames));
+    VcSlot& sl = vc->slot[0];
+    if (n_eff > 0) {
+        memcpy(sl.h_row, row_of, (size_t)n_eff * sizeof(int));
+        RT_TRY(rt::h2d(sl.d_row, sl.h_row, (size_t)n_eff * sizeof(int), vc->s1->stream));
+    } else if (sl.used) {
+        RT_TRY(rt::stream_wait_event(vc->s1->stream, sl.ev_done));
+    }
+    return vc_enqueue_mid(vc, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp);
+}
+
+int ry_vc_stage2_from_mc(ry_vc* vc, const int* row_of, int n_eff, int n_frames, float sp_floor, float* sp_out) {
+    if (!vc || !sp_out) return fail(RY_EINVAL, "null argument");
+    RY_TRY(vc_split_mid(vc, row_of, n_eff, n_frames, sp_floor));
+    const int keep = vc->split_eff;
+    VcSlot& sl = vc->slot[0];
+    ry_net* s2 = vc->s2;
+    RT_TRY(rt::event_record(sl.ev_mid, vc->s1->stream));
+    RT_TRY(rt::stream_wait_event(s2->stream, sl.ev_mid));
+    RY_TRY(ry_sr_convert(s2, sl.d_sp, sl.d_out, 1, n_frames, 1));
+    RT_TRY(rt::d2h(sl.h_sp, sl.d_out, (size_t)n_frames * vc->F * sizeof(float), s2->stream));
+    RT_TRY(rt::event_record(sl.ev_done, s2->stream));
+    sl.used = true;
+    RT_TRY(rt::event_sync(sl.ev_done));
+    memcpy(sp_out, sl.h_sp, (size_t)n_frames * vc->F * sizeof(float));
+    vc->split_eff = keep;                                     // the rows stay valid until the next stage-1 call
+    return RY_OK;
+}
+
+int ry_vc_mid_sp(ry_vc* vc, const int* row_of, int n_eff, int n_frames, float sp_floor, float* sp_mid_out) {
+    if (!vc || !sp_mid_out) return fail(RY_EINVAL, "null argument");
+    RY_TRY(vc_split_mid(vc, row_of, n_eff, n_frames, sp_floor));
+    const int keep = vc->split_eff;
+    VcSlot& sl = vc->slot[0];
+    RT_TRY(rt::d2h(sl.h_sp, sl.d_sp, (size_t)n_frames * vc->F * sizeof(float), vc->s1->stream));
+    RT_TRY(rt::stream_sync(vc->s1->stream));
+    memcpy(sp_mid_out, sl.h_sp, (size_t)n_frames * vc->F * sizeof(float));
+    vc->split_eff = keep;
+    return RY_OK;
+}
+
+// Reserve the ring for windows of up to n_frames (all effective) ahead of time (optional: every call grows it on demand, the
+// split calls at the price of a copy of the rows stage 1 left on the device).
+int ry_vc_reserve_frames(ry_vc* vc, int n_frames) {
+    if (!vc || n_frames < 1) return fail(RY_EINVAL, "bad argument");
+    RT_TRY(rt::set_device(vc->s1->ctx->device));
+    return vc_reserve(vc, n_frames, n_frames);
 }
 
 int ry_mc2sp(ry_ctx* ctx, const float* mc, const float* mtx, int n, int m, int bins, float floor_, float* sp) {
@@ -1810,6 +2033,160 @@ int ry_mc2sp(ry_ctx* ctx, const float* mc, const float* mtx, int n, int m, int b
     RT_TRY(rt::d2h(sp, dsp, (size_t)n * bins * sizeof(float), ctx->stream));
     RT_TRY(rt::stream_sync(ctx->stream));
     return RY_OK;
+}
+
+
+// ---- device buffers for callers without a tensor library (weights for ry_comm_bcast_weights / ry_net_create) ----
+int ry_dev_alloc(ry_ctx* ctx, size_t n_floats, float** out) {
+    if (!ctx || !out) return fail(RY_EINVAL, "null argument");
+    RT_TRY(rt::set_device(ctx->device));
+    RY_TRY(ctx->alloc(out, n_floats));
+    return RY_OK;
+}
+int ry_dev_free(ry_ctx* ctx, float* p) {
+    if (!ctx) return fail(RY_EINVAL, "null argument");
+    RT_TRY(rt::set_device(ctx->device));
+    RT_TRY(rt::stream_sync(ctx->stream));
+    if (p) RT_TRY(rt::dfree(p));
+    return RY_OK;
+}
+int ry_dev_upload(ry_ctx* ctx, float* dst_dev, const float* src_host, size_t n_floats) {
+    if (!ctx || !dst_dev || !src_host) return fail(RY_EINVAL, "null argument");
+    RT_TRY(rt::set_device(ctx->device));
+    RT_TRY(rt::h2d(dst_dev, src_host, n_floats * sizeof(float), ctx->stream));
+    RT_TRY(rt::stream_sync(ctx->stream));
+    return RY_OK;
+}
+int ry_dev_download(ry_ctx* ctx, float* dst_host, const float* src_dev, size_t n_floats) {
+    if (!ctx || !dst_host || !src_dev) return fail(RY_EINVAL, "null argument");
+    RT_TRY(rt::set_device(ctx->device));
+    RT_TRY(rt::d2h(dst_host, src_dev, n_floats * sizeof(float), ctx->stream));
+    RT_TRY(rt::stream_sync(ctx->stream));
+    return RY_OK;
+}
+
+}  // extern "C"
+
+// ---- RCCL, bound at run time (dlopen: libry355.so carries no link-time dependency on it; a process that already loaded an RCCL
+// -- torch's -- gets that one back by soname).  Only what chunk parallelism needs: one broadcast of each weight blob at start-up
+// (SURVEY.md 8(e)), and a max / barrier for timing.  No collective ever runs in the steady state.
+#ifndef RY_HOST_EMU
+#include <dlfcn.h>
+struct RyNcclId { char internal[128]; };
+typedef struct ncclComm* RyNcclComm;
+struct RyNccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(RyNcclId*) = nullptr;
+    int (*CommInitRank)(RyNcclComm*, int, RyNcclId, int) = nullptr;
+    int (*CommDestroy)(RyNcclComm) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int /*dtype*/, int /*root*/, RyNcclComm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, RyNcclComm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static RyNccl g_nccl;
+static int load_rccl() {
+    if (g_nccl.h) return RY_OK;
+    const char* names[] = {getenv("RY_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) { if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break; }
+    if (!h) return fail(RY_ESTATE, "librccl.so not found (set RY_RCCL_LIB): %s", dlerror());
+#define RY_SYM(field, name) do { *(void**)(&g_nccl.field) = dlsym(h, name); if (!g_nccl.field) return fail(RY_ESTATE, "librccl lacks %s", name); } while (0)
+    RY_SYM(GetUniqueId, "ncclGetUniqueId"); RY_SYM(CommInitRank, "ncclCommInitRank"); RY_SYM(CommDestroy, "ncclCommDestroy");
+    RY_SYM(Broadcast, "ncclBroadcast"); RY_SYM(AllReduce, "ncclAllReduce"); RY_SYM(GetErrorString, "ncclGetErrorString");
+#undef RY_SYM
+    g_nccl.h = h;
+    return RY_OK;
+}
+#define NCCL_TRY(expr) do { int e__ = (expr); if (e__ != 0) return fail(RY_EHIP, "%s failed: %s", #expr, g_nccl.GetErrorString(e__)); } while (0)
+enum { RY_NCCL_FLOAT32 = 7, RY_NCCL_FLOAT64 = 8, RY_NCCL_MAX = 2 };     // ncclDataType_t / ncclRedOp_t values (nccl.h)
+#endif
+
+struct ry_comm {
+    ry_ctx* ctx = nullptr;
+    int rank = 0, world = 1;
+    double* d_scalar = nullptr;
+#ifndef RY_HOST_EMU
+    RyNcclComm comm = nullptr;
+#endif
+};
+
+extern "C" {
+
+int ry_comm_unique_id(void* id128) {
+    if (!id128) return fail(RY_EINVAL, "null argument");
+#ifdef RY_HOST_EMU
+    memset(id128, 0, 128);
+    return RY_OK;
+#else
+    RY_TRY(load_rccl());
+    RyNcclId id;
+    NCCL_TRY(g_nccl.GetUniqueId(&id));
+    memcpy(id128, &id, 128);
+    return RY_OK;
+#endif
+}
+
+int ry_comm_init(ry_ctx* ctx, const void* id128, int rank, int world, ry_comm** out) {
+    if (!ctx || !id128 || !out) return fail(RY_EINVAL, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(RY_EINVAL, "bad rank %d of %d", rank, world);
+    RT_TRY(rt::set_device(ctx->device));
+    std::unique_ptr<ry_comm> c(new ry_comm());
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    float* q = nullptr;
+    RY_TRY(ctx->alloc(&q, 4));
+    c->d_scalar = reinterpret_cast<double*>(q);
+#ifdef RY_HOST_EMU
+    if (world != 1) return fail(RY_ESTATE, "the emulator build has no RCCL: world must be 1");
+#else
+    RY_TRY(load_rccl());
+    RyNcclId id;
+    memcpy(&id, id128, 128);
+    NCCL_TRY(g_nccl.CommInitRank(&c->comm, world, id, rank));
+#endif
+    *out = c.release();
+    return RY_OK;
+}
+
+void ry_comm_destroy(ry_comm* c) {
+    if (!c) return;
+    rt::set_device(c->ctx->device);
+    rt::stream_sync(c->ctx->stream);
+#ifndef RY_HOST_EMU
+    if (c->comm) g_nccl.CommDestroy(c->comm);
+#endif
+    if (c->d_scalar) rt::dfree(c->d_scalar);
+    delete c;
+}
+
+// in-place broadcast of a flat weight blob (device memory on this context's GPU) from `root`; returns when it has arrived
+int ry_comm_bcast_weights(ry_comm* c, float* blob_dev, size_t n_floats, int root) {
+    if (!c || !blob_dev) return fail(RY_EINVAL, "null argument");
+    if (root < 0 || root >= c->world) return fail(RY_EINVAL, "bad root %d of %d", root, c->world);
+    RT_TRY(rt::set_device(c->ctx->device));
+#ifndef RY_HOST_EMU
+    NCCL_TRY(g_nccl.Broadcast(blob_dev, blob_dev, n_floats, RY_NCCL_FLOAT32, root, c->comm, c->ctx->stream));
+#endif
+    RT_TRY(rt::stream_sync(c->ctx->stream));
+    return RY_OK;
+}
+
+// *value = max over the ranks (an all-reduce of one double: doubles as the barrier of the timed region)
+int ry_comm_allreduce_max(ry_comm* c, double* value) {
+    if (!c || !value) return fail(RY_EINVAL, "null argument");
+    RT_TRY(rt::set_device(c->ctx->device));
+    RT_TRY(rt::h2d(c->d_scalar, value, sizeof(double), c->ctx->stream));
+#ifndef RY_HOST_EMU
+    NCCL_TRY(g_nccl.AllReduce(c->d_scalar, c->d_scalar, 1, RY_NCCL_FLOAT64, RY_NCCL_MAX, c->comm, c->ctx->stream));
+#endif
+    RT_TRY(rt::d2h(value, c->d_scalar, sizeof(double), c->ctx->stream));
+    RT_TRY(rt::stream_sync(c->ctx->stream));
+    return RY_OK;
+}
+
+int ry_comm_barrier(ry_comm* c) {
+    double one = 1.0;
+    return ry_comm_allreduce_max(c, &one);
 }
 
 // diagnostics: the plan (tile, external splits, K groups, estimated time) the stage-2 planner picks for one layer shape

@@ -4,31 +4,46 @@ Each `ConvertStream.process` window is a pure function of its fetched block (ove
 window by `fetch(extra_time)`: /root/reference/realtime_voice_conversion/stream/base_stream.py:38-40, and dropped
 afterwards: stream/convert_stream.py:40-42), so windows shard across ranks with NO data-path collective:
 window i -> rank i mod world.  The only communication is one broadcast of each predictor's flat weight blob from
-rank 0 at start-up (RCCL over xGMI with backend "nccl"; gloo on CPU in the tests), and an optional gather of the
-results in window order -- the order run.py re-establishes with `Item.index` (/root/reference/run.py:171-183).
-One process per GPU; `torch.distributed` is plumbing only.
+rank 0 at start-up (RCCL over xGMI), and an optional gather of the results in window order -- the order run.py
+re-establishes with `Item.index` (/root/reference/run.py:171-183).  One process per GPU.
+
+Two interchangeable transports for that broadcast:
+* `TorchComm`  -- `torch.distributed` (backend "nccl" = RCCL on ROCm; "gloo" on CPU in the tests): what `bench.py` uses under
+  `python -m torch.distributed.run`; torch is plumbing only (process group + one device buffer per blob);
+* `NativeComm` -- RCCL through the C ABI (`ry_comm_*` of include/ry355.h, bound with dlopen inside libry355.so): no tensor library
+  at all; the 128-byte RCCL id travels from rank 0 to the others through a file next to MASTER_PORT (same node).
 """
+import os
+import time
 from typing import List, Optional, Sequence
 
 import numpy
-import torch
-import torch.distributed as dist
 
-from . import engine
+from . import _lib, engine
 from .netspec import NetDesc, param_count
 from .weights import flatten_params
 
 
+# ------------------------------------------------------------------------------------------------ torch.distributed transport
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
 def world() -> int:
+    dist = _dist()
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def rank() -> int:
+    dist = _dist()
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
-def broadcast_blob(desc: NetDesc, params: Optional[dict], device: torch.device) -> torch.Tensor:
+def broadcast_blob(desc: NetDesc, params: Optional[dict], device):
     """Flat weight blob on `device` on every rank; only rank 0 needs `params`.  One collective per predictor."""
+    import torch
+    dist = _dist()
     n = param_count(desc)
     if rank() == 0:
         if params is None:
@@ -36,19 +51,126 @@ def broadcast_blob(desc: NetDesc, params: Optional[dict], device: torch.device) 
         t = torch.from_numpy(flatten_params(desc, params)).to(device)
     else:
         t = torch.empty(n, dtype=torch.float32, device=device)
-    if world() > 1:
+    if dist.is_available() and dist.is_initialized():        # also with ONE rank: the collective then really runs (RCCL init, load order)
         dist.broadcast(t, src=0)
     return t
 
 
-def make_net(ctx: engine.Context, desc: NetDesc, blob: torch.Tensor, width: int = 512) -> engine.Net:
-    """Adopt a broadcast blob: device tensors are handed over by pointer, CPU tensors (gloo tests) as arrays."""
+def make_net(ctx: engine.Context, desc: NetDesc, blob, width: int = 512) -> engine.Net:
+    """Adopt a broadcast blob: device tensors are handed over by pointer, CPU tensors (gloo tests) as arrays, (ptr, n) as is."""
+    if isinstance(blob, tuple):
+        return engine.Net(ctx, desc, blob, width=width)
     if blob.is_cuda:
+        import torch
         torch.cuda.synchronize(blob.device)
         return engine.Net(ctx, desc, (blob.data_ptr(), blob.numel()), width=width)
     return engine.Net(ctx, desc, blob.numpy(), width=width)
 
 
+class TorchComm(object):
+    """The pieces bench.py needs from a process group, over torch.distributed."""
+
+    def __init__(self, backend: str, rank_: int, world_: int, device=None):
+        import torch
+        dist = _dist()
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29577')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        kw = {}
+        if backend == 'nccl' and device is not None:
+            kw['device_id'] = device
+        dist.init_process_group(backend, rank=rank_, world_size=world_, **kw)
+        self.device = device if device is not None else torch.device('cpu')
+        self.rank, self.world, self.kind = rank_, world_, 'torch.distributed/' + backend
+
+    def broadcast_net(self, ctx, desc, params, width=512):
+        return make_net(ctx, desc, broadcast_blob(desc, params, self.device), width=width)
+
+    def barrier(self):
+        _dist().barrier()
+
+    def max(self, v: float) -> float:
+        import torch
+        dist = _dist()
+        t = torch.tensor([v], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        dist = _dist()
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ RCCL through the C ABI
+def _rendezvous_path() -> str:
+    p = os.environ.get('RY_COMM_RENDEZVOUS')
+    if p:
+        return p
+    # every worker of one `torch.distributed.run` launch has the same parent (the elastic agent): the name is unique per launch
+    return '/tmp/ry355_comm_%d_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'))
+
+
+class NativeComm(object):
+    def __init__(self, ctx: engine.Context, rank_: int, world_: int, timeout: float = 120.0):
+        import ctypes
+        self.ctx, self.rank, self.world, self.kind = ctx, int(rank_), int(world_), 'rccl (C ABI, dlopen)'
+        lib = ctx.lib
+        idb = ctypes.create_string_buffer(128)
+        path = _rendezvous_path()
+        if self.rank == 0:
+            lib.check(lib.dll.ry_comm_unique_id(idb))
+            if self.world > 1:
+                with open(path + '.tmp', 'wb') as f:
+                    f.write(idb.raw)
+                os.replace(path + '.tmp', path)
+        else:
+            t0 = time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > timeout:
+                    raise _lib.Ry355Error('rank %d: no RCCL id at %s after %.0f s' % (self.rank, path, timeout))
+                time.sleep(0.01)
+            with open(path, 'rb') as f:
+                idb.raw = f.read(128)
+        h = ctypes.c_void_p()
+        lib.check(lib.dll.ry_comm_init(ctx.handle, idb, self.rank, self.world, ctypes.byref(h)))
+        self.handle = h
+        self.barrier()
+        if self.rank == 0 and self.world > 1:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+    def broadcast_net(self, ctx, desc, params, width=512):
+        n = param_count(desc)
+        ptr = ctx.dev_alloc(n)
+        if self.rank == 0:
+            if params is None:
+                raise ValueError('rank 0 must provide the weights')
+            ctx.dev_upload(ptr, flatten_params(desc, params))
+        ctx.lib.check(ctx.lib.dll.ry_comm_bcast_weights(self.handle, _lib._fptr(ptr), n, 0))
+        net = engine.Net(ctx, desc, (ptr, n), width=width)
+        ctx.dev_free(ptr)                                      # ry_net_create re-laid the filters out into its own buffers
+        return net
+
+    def barrier(self):
+        self.ctx.lib.check(self.ctx.lib.dll.ry_comm_barrier(self.handle))
+
+    def max(self, v: float) -> float:
+        import ctypes
+        x = ctypes.c_double(float(v))
+        self.ctx.lib.check(self.ctx.lib.dll.ry_comm_allreduce_max(self.handle, ctypes.byref(x)))
+        return float(x.value)
+
+    def close(self):
+        if self.handle is not None:
+            self.barrier()
+            self.ctx.lib.dll.ry_comm_destroy(self.handle)
+        self.handle = None
+
+
+# ------------------------------------------------------------------------------------------------ sharding helpers
 def shard(n_windows: int, r: Optional[int] = None, w: Optional[int] = None) -> List[int]:
     """Indices of the windows this rank converts (round robin, like a dispatcher handing out Item.index)."""
     r = rank() if r is None else r
@@ -69,6 +191,7 @@ def gather_in_order(local: List[numpy.ndarray], n_windows: int, dst: int = 0) ->
     """Results of all ranks re-assembled in window order on `dst` (None elsewhere)."""
     if world() == 1:
         return list(local)
+    dist = _dist()
     bucket = [None] * world() if rank() == dst else None
     dist.gather_object(local, bucket, dst=dst)
     if rank() != dst:

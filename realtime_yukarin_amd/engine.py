@@ -49,6 +49,23 @@ class Context(object):
             self.lib.dll.ry_shutdown(self.handle)
         self.handle = None
 
+    def dev_alloc(self, n_floats: int) -> int:
+        p = ctypes.POINTER(ctypes.c_float)()
+        self.lib.check(self.lib.dll.ry_dev_alloc(self.handle, int(n_floats), ctypes.byref(p)))
+        return ctypes.cast(p, ctypes.c_void_p).value
+
+    def dev_free(self, ptr: int):
+        self.lib.check(self.lib.dll.ry_dev_free(self.handle, _lib._fptr(int(ptr))))
+
+    def dev_upload(self, ptr: int, a: numpy.ndarray):
+        a = numpy.ascontiguousarray(a)
+        assert a.dtype.itemsize == 4, 'four-byte elements (float32 / int32)'
+        self.lib.check(self.lib.dll.ry_dev_upload(self.handle, _lib._fptr(int(ptr)), ctypes.cast(a.ctypes.data, ctypes.POINTER(ctypes.c_float)), a.size))
+
+    def dev_download(self, ptr: int, a: numpy.ndarray):
+        assert a.flags['C_CONTIGUOUS'] and a.dtype.itemsize == 4
+        self.lib.check(self.lib.dll.ry_dev_download(self.handle, ctypes.cast(a.ctypes.data, ctypes.POINTER(ctypes.c_float)), _lib._fptr(int(ptr)), a.size))
+
     def mc2sp(self, mc, mtx, floor: float = 0.0):
         """`decode_spectrogram` on the device: exp(mc (N, M) @ mtx (M, F)) + floor."""
         mc = numpy.ascontiguousarray(mc, dtype=numpy.float32)
@@ -106,21 +123,80 @@ class VcCore(object):
         h = ctypes.c_void_p()
         self.lib.check(self.lib.dll.ry_vc_create(stage1.handle, stage2.handle, _lib._fptr(mtx), self.M, self.F, ctypes.byref(h)))
         self.handle = h
+        self._pending = {}
 
-    def convert(self, x_eff: numpy.ndarray, effective: numpy.ndarray, sp_floor: float = 1e-16):
-        """x_eff (n_eff, in_ch) = features of the effective frames, effective (n_frames,) bool -> (mc (n_frames, M), sp (n_frames, F))."""
+    @staticmethod
+    def _rows(effective):
         effective = numpy.asarray(effective, dtype=bool)
-        n = int(effective.size)
-        rows = numpy.ascontiguousarray(numpy.nonzero(effective)[0], dtype=numpy.int32)
+        return int(effective.size), numpy.ascontiguousarray(numpy.nonzero(effective)[0], dtype=numpy.int32)
+
+    def submit(self, x_eff: numpy.ndarray, effective: numpy.ndarray, sp_floor: float = 1e-16) -> int:
+        """Queue one window (pinned ring slot -> H2D -> stage-1 -> ... -> D2H) and return its ticket without waiting; up to three
+        windows may be in flight (`ry_vc_submit`)."""
+        n, rows = self._rows(effective)
         x_eff = numpy.ascontiguousarray(x_eff, dtype=numpy.float32)
         if len(rows):
             x_eff = x_eff.reshape(len(rows), -1)
+        t = ctypes.c_int(-1)
+        self.lib.check(self.lib.dll.ry_vc_submit(self.handle, _lib._fptr(x_eff) if len(rows) else _lib._fptr(None),
+                                                 rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), len(rows), n, float(sp_floor), ctypes.byref(t)))
+        self._pending[t.value] = n
+        return int(t.value)
+
+    def wait(self, ticket: int):
+        """(mc (n_frames, M), sp (n_frames, F)) of a submitted window (`ry_vc_wait`)."""
+        n = self._pending.pop(ticket)
         mc = numpy.empty((n, self.M), dtype=numpy.float32)
         sp = numpy.empty((n, self.F), dtype=numpy.float32)
-        self.lib.check(self.lib.dll.ry_vc_convert(self.handle, _lib._fptr(x_eff) if len(rows) else _lib._fptr(None),
-                                                  rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), len(rows), n, float(sp_floor),
-                                                  _lib._fptr(mc), _lib._fptr(sp)))
+        self.lib.check(self.lib.dll.ry_vc_wait(self.handle, int(ticket), _lib._fptr(mc), _lib._fptr(sp)))
         return mc, sp
+
+    def convert(self, x_eff: numpy.ndarray, effective: numpy.ndarray, sp_floor: float = 1e-16):
+        """x_eff (n_eff, in_ch) = features of the effective frames, effective (n_frames,) bool -> (mc (n_frames, M), sp (n_frames, F))."""
+        return self.wait(self.submit(x_eff, effective, sp_floor))
+
+    def convert_stream(self, windows, sp_floor: float = 1e-16, depth: int = 2):
+        """Generator over (x_eff, effective) pairs -> (mc, sp) in order, keeping `depth` windows in flight: the copies of one window
+        run under the kernels of another."""
+        if not 1 <= depth <= 3:
+            raise ValueError('depth must be 1..3 (the ring has three slots)')
+        tickets = []
+        for x_eff, effective in windows:
+            tickets.append(self.submit(x_eff, effective, sp_floor))
+            if len(tickets) >= depth:
+                yield self.wait(tickets.pop(0))
+        while tickets:
+            yield self.wait(tickets.pop(0))
+
+    def enqueue_device(self, x_ptr: int, rows_ptr: int, n_eff: int, n_frames: int, mc_ptr: int, sp_ptr: int, sp_floor: float = 1e-16):
+        """Device pointers in and out, nothing waited for (`ry_vc_enqueue_device`)."""
+        self.lib.check(self.lib.dll.ry_vc_enqueue_device(
+            self.handle, _lib._fptr(int(x_ptr)), ctypes.cast(ctypes.c_void_p(int(rows_ptr)), ctypes.POINTER(ctypes.c_int)),
+            int(n_eff), int(n_frames), float(sp_floor), _lib._fptr(int(mc_ptr)), _lib._fptr(int(sp_ptr))))
+
+    # ---- the chain cut where the reference's own VoiceChanger cuts it (voice_changer.py:33-41)
+    def convert_stage1(self, x_eff: numpy.ndarray) -> numpy.ndarray:
+        """`AcousticConverter.convert` array part; the converted rows also stay on the device for `stage2_from_mc`."""
+        x_eff = numpy.ascontiguousarray(x_eff, dtype=numpy.float32)
+        y = numpy.empty((x_eff.shape[0], self.M), dtype=numpy.float32)
+        self.lib.check(self.lib.dll.ry_vc_stage1(self.handle, _lib._fptr(x_eff), x_eff.shape[0], _lib._fptr(y)))
+        return y
+
+    def stage2_from_mc(self, effective: numpy.ndarray, sp_floor: float) -> numpy.ndarray:
+        """combine_silent + decode_spectrogram + floor + SuperResolution.convert from the rows `convert_stage1` left on the device."""
+        n, rows = self._rows(effective)
+        sp = numpy.empty((n, self.F), dtype=numpy.float32)
+        self.lib.check(self.lib.dll.ry_vc_stage2_from_mc(self.handle, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), len(rows), n,
+                                                         float(sp_floor), _lib._fptr(sp)))
+        return sp
+
+    def mid_sp(self, effective: numpy.ndarray, sp_floor: float) -> numpy.ndarray:
+        """The intermediate spectrogram exp(mc @ M) + floor of the rows `convert_stage1` left on the device."""
+        n, rows = self._rows(effective)
+        sp = numpy.empty((n, self.F), dtype=numpy.float32)
+        self.lib.check(self.lib.dll.ry_vc_mid_sp(self.handle, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), len(rows), n,
+                                                 float(sp_floor), _lib._fptr(sp)))
+        return sp
 
     def close(self):
         if self.handle is not None and self.stage1.ctx.handle is not None and self.stage1.ctx.pid == os.getpid():

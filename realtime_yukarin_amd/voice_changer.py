@@ -43,6 +43,13 @@ class VoiceChanger(object):
             self._core_pid = key
         return self._core
 
+    def close(self) -> None:
+        """Free the device-resident core (ring buffers, pinned staging) in the process that built it; the converters stay usable."""
+        import os
+        if getattr(self, '_core_pid', None) == os.getpid() and getattr(self, '_core', None) is not None:
+            self._core.close()
+        self._core, self._core_pid = None, None
+
     def convert_from_acoustic_feature(self, f_in):
         core = self._fused_core()
         if core is None:                       # generic path: the reference's step order, one call per step

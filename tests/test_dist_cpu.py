@@ -74,3 +74,32 @@ def test_shard_is_a_partition():
     for w in (1, 2, 4, 8):
         seen = sorted(i for r in range(w) for i in rdist.shard(11, r, w))
         assert seen == list(range(11))
+
+
+def _bench_worker(rank, world, port, out_dir):
+    """One rank of `bench.py --gpus 2 --emulator`: bench.py's OWN main(), launched as torch.distributed.run launches it (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment)."""
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import bench
+    out = bench.main(['--gpus', str(world), '--emulator', '--frames', '40', '--steps', '2', '--warmup', '1'])
+    import json
+    with open(os.path.join(out_dir, 'bench_rank%d.json' % rank), 'w') as f:
+        json.dump(out, f)
+
+
+def test_bench_main_runs_its_distributed_branches_with_two_gloo_ranks(tmp_path):
+    """The N > 1 branches of bench.py (process group, one broadcast per predictor, barrier + fence, max over the ranks of the elapsed
+    time, weak-scaling aggregate) executed for real: two gloo ranks on the emulator build.  The numbers mean nothing; the plumbing is
+    the thing under test, so that a blind multi-GPU run cannot fail on it."""
+    import json
+    from realtime_yukarin_amd import build
+    build.build_emu()
+    port = _free_port()
+    mp.spawn(_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (json.load(open(tmp_path / ('bench_rank%d.json' % r))) for r in (0, 1))
+    assert r0['n_gpus'] == 2 and r0['scaling'] == 'weak' and r0['comm'] == 'torch.distributed/gloo'
+    assert r0['value'] > 0 and r0['steps'] == 2 and r0['warmup'] == 1 and 'EMULATOR' in r0['data']
+    assert r0['ms_per_step'] == r1['ms_per_step']                       # the maximum over the ranks, seen by both
+    assert abs(r0['value'] - 2 * 1 * 40 * 2 / (r0['ms_per_step'] * 2e-3)) / r0["value"] < 5e-3   # (value is rounded to 0.1) whole-job frames / max-over-ranks time
+    assert r0['config']['parallelism'].startswith('chunk-dp2')

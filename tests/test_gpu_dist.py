@@ -1,0 +1,66 @@
+"""The N > 1 path on the ONE GPU a test box has: a one-rank process group over RCCL ("nccl" backend of torch.distributed, and the
+C-ABI transport ry_comm_*), the weight broadcast, the adoption of the broadcast buffer by ry_net_create, barrier and max -- i.e. real
+RCCL initialisation and the real library load order next to libry355.so; then bench.py's own --force-dist mode through both
+transports.  (Multi-rank RCCL needs one GPU per rank and cannot run here; the multi-rank logic is covered with gloo on the CPU,
+tests/test_dist_cpu.py.)  Ordering contract of the reference: results are re-ordered by Item.index, /root/reference/run.py:171-183."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(code_or_args, env_extra=None, timeout=600):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable] + code_or_args, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + '\n' + r.stderr[-4000:]
+    return r.stdout
+
+
+ONE_RANK = r'''
+import sys, numpy
+sys.path.insert(0, %r)
+import torch
+from realtime_yukarin_amd import dist as rdist, engine, synth
+from realtime_yukarin_amd.weights import synthetic_params
+kind = sys.argv[1]
+torch.cuda.set_device(0)
+ctx = engine.get_context(0)
+comm = rdist.NativeComm(ctx, 0, 1) if kind == 'native' else rdist.TorchComm('nccl', 0, 1, torch.device('cuda', 0))
+d1, d2 = synth.model_descs('SYN-8')
+P1 = synthetic_params(d1, 31)
+net = comm.broadcast_net(ctx, d1, P1)
+comm.barrier()
+assert comm.max(2.5) == 2.5
+x = synth.stage1_input(100)[0]
+y = net.convert(x)
+from oracle import torch_ref
+r = torch_ref.stage1_convert_core(torch_ref.TorchUNet(P1), x)
+err = float(numpy.abs(y - r).max() / numpy.abs(r).max())
+print('RESULT', comm.kind, err)
+assert err < 1e-4
+net.close(); comm.close()
+''' % str(ROOT)
+
+
+@pytest.mark.parametrize('kind', ['torch', 'native'])
+def test_one_rank_rccl_broadcast_and_adoption(kind):
+    out = _run(['-c', ONE_RANK, kind], {'MASTER_PORT': '29611' if kind == 'torch' else '29612'})
+    assert 'RESULT' in out
+
+
+@pytest.mark.parametrize('comm', ['torch', 'native'])
+def test_bench_force_dist(comm):
+    """bench.py through its `comm is not None` branches on one GPU: same JSON contract, value close to the plain run's."""
+    out = _run(['bench.py', '--force-dist', '--comm', comm, '--steps', '10', '--warmup', '2', '--no-cpu-baseline', '--no-extras'],
+               {'MASTER_PORT': '29613' if comm == 'torch' else '29614', 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1'})
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['comm'] is not None and d['value'] > 50000 and d['dtype'] == 'f32'
+    assert d['roofline']['frac'] > 0.5 and d['config']['frames'] == 300

@@ -209,6 +209,65 @@ def test_reference_voice_changer_and_convert_stream_run_unchanged_on_the_shims(m
 
 
 @pytest.mark.skipif(not REF.exists(), reason='/root/reference is not mounted here')
+def test_unchanged_reference_class_keeps_the_data_on_the_device_between_the_cnns(models, on_emulator, monkeypatch):
+    """The reference's OWN VoiceChanger, not edited, calling the shims step by step (voice_changer.py:33-41): `convert` leaves its
+    rows on the device, `decode_spectrogram` hands back a lazy spectrogram, `+= 1e-16` / `astype` are remembered and
+    `SuperResolution.convert` continues on the device -- one small H2D, no second upload, no host mc2sp -- with the same
+    outputs as the plain step-by-step path (RY_FUSE_STEPS=0)."""
+    from realtime_yukarin_amd import fusion
+    for p in (str(ROOT / 'tests' / 'stubs'), str(REF)):
+        monkeypatch.syspath_prepend(p)
+    vc_mod = importlib.import_module('realtime_voice_conversion.yukarin_wrapper.voice_changer')
+    ac, sr = build_converters(models)
+    wave, feat = make_input(numpy.random.default_rng(21))
+    calls = {'stage1': 0, 'stage2_from_mc': 0, 'mid_sp': 0, 'net_convert': 0, 'host_mc2sp': 0}
+    for name, key in (('convert_stage1', 'stage1'), ('stage2_from_mc', 'stage2_from_mc'), ('mid_sp', 'mid_sp')):
+        real = getattr(engine.VcCore, name)
+        monkeypatch.setattr(engine.VcCore, name, (lambda real, key: lambda self, *a, **k: calls.__setitem__(key, calls[key] + 1) or real(self, *a, **k))(real, key))
+    real_nc = engine.Net.convert
+    monkeypatch.setattr(engine.Net, 'convert', lambda self, x: calls.__setitem__('net_convert', calls['net_convert'] + 1) or real_nc(self, x))
+    real_fast = sptk.mc2sp_fast
+    monkeypatch.setattr(sptk, 'mc2sp_fast', lambda *a, **k: calls.__setitem__('host_mc2sp', calls['host_mc2sp'] + 1) or real_fast(*a, **k))
+
+    def run():
+        f_in = vc_mod.AcousticFeatureWrapper(wave=wave, **{k: v.copy() for k, v in feat.items()})
+        return vc_mod.VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60).convert_from_acoustic_feature(f_in)
+    out = run()
+    assert calls == {'stage1': 1, 'stage2_from_mc': 1, 'mid_sp': 0, 'net_convert': 0, 'host_mc2sp': 0}, calls
+    check(out, expected(models, ac, wave, feat), feat)
+    assert isinstance(out.sp, numpy.ndarray) and out.sp.dtype == numpy.float32
+    monkeypatch.setenv('RY_FUSE_STEPS', '0')
+    plain = run()
+    assert calls['net_convert'] == 2 and calls['host_mc2sp'] == 1                      # the literal path: two uploads, host mc2sp
+    assert float(numpy.abs(out.sp / plain.sp - 1).max()) < 2e-5 and numpy.array_equal(out.mc, plain.mc)
+    assert numpy.array_equal(out.f0, plain.f0) and numpy.array_equal(out.ap, plain.ap)
+    monkeypatch.delenv('RY_FUSE_STEPS')
+    # the lazy spectrogram is indistinguishable from the array for anybody else
+    f_eff, eff = ac.separate_effective(wave=wave, feature=vc_mod.AcousticFeatureWrapper(wave=wave, **feat), threshold=60)
+    f = ac.decode_spectrogram(ac.combine_silent(effective=eff, feature=ac.convert(f_eff)))
+    assert isinstance(f.sp, fusion.LazySpectrogram) and f.sp.shape == (N, 513) and len(f.sp) == N and f.sp.dtype == numpy.float64
+    host = real_fast(f.mc, sptk.mcepalpha(FS), 1024)
+    f.sp += 1e-16
+    lazy32 = f.sp.astype(numpy.float32)
+    assert isinstance(lazy32, fusion.LazySpectrogram) and lazy32.dtype == numpy.float32
+    arr = numpy.asarray(lazy32)                                                        # a numpy function materialises it (ry_vc_mid_sp)
+    assert arr.dtype == numpy.float32 and float(numpy.abs(arr / (host + 1e-16) - 1).max()) < 2e-5 and calls['mid_sp'] == 1
+    assert float(numpy.abs(f.sp[3:5] / (host[3:5] + 1e-16) - 1).max()) < 2e-5         # indexing too
+    # a second SuperResolution shim is not the one the object was built for: it gets the array (and the right answer)
+    _, sr2 = build_converters(models)
+    n_before = calls['stage2_from_mc']
+    y2 = sr2.convert(f.sp.astype(numpy.float32))
+    assert calls['stage2_from_mc'] == n_before and float(numpy.abs(y2 / plain.sp - 1).max()) < 2e-5
+    # after another convert() the device rows are gone: the stale object falls back to the host formula
+    g = ac.decode_spectrogram(ac.combine_silent(effective=eff, feature=ac.convert(f_eff)))
+    ac.convert(f_eff)
+    stale = numpy.asarray(g.sp)
+    assert float(numpy.abs(stale / host - 1).max()) < 1e-12 and stale.dtype == numpy.float64
+    for m in [k for k in sys.modules if k.startswith('realtime_voice_conversion')]:
+        sys.modules.pop(m)
+
+
+@pytest.mark.skipif(not REF.exists(), reason='/root/reference is not mounted here')
 def test_convert_worker_mirror_matches_the_reference_loop_and_stays_bounded(models, on_emulator, monkeypatch):
     """`realtime_yukarin_amd.worker.convert_worker` over FeatureQueues against the reference's loop body
     (convert_worker.py:33-57) run inline: same windows out, while the mirror's stream no longer grows."""
