@@ -281,7 +281,18 @@ def main(argv=None):
             for _ in core.convert_stream([(xh, eff)] * 60, depth=3):
                 pass
             stream_ms = (time.perf_counter() - th) / 60 * 1e3
+            # the same call with the silence gate on the device (raw wave + all frames up; ry_vc_submit_wave)
+            from realtime_yukarin_amd import gate
+            wv32 = (0.1 * numpy.random.default_rng(1).normal(size=N * 80)).astype(numpy.float32)
+            p_eff, p_all = gate.thresholds(60)
+            for _ in range(3):
+                core.wait_wave(core.submit_wave(wv32, 80, 1024, p_eff, p_all, xh))
+            th = time.perf_counter()
+            for _ in range(20):
+                core.wait_wave(core.submit_wave(wv32, 80, 1024, p_eff, p_all, xh))
+            gated_ms = (time.perf_counter() - th) / 20 * 1e3
             out['host_path'] = {'call_ms_per_window': round(host_ms, 4), 'stream_ms_per_window': round(stream_ms, 4),
+                                'call_with_device_gate_ms_per_window': round(gated_ms, 4),
                                 'stream_frames_per_s': round(N / (stream_ms * 1e-3), 1),
                                 'note': 'host arrays in, host arrays out through the pinned ring of ry_vc_submit / ry_vc_wait (PCIe inclusive): one window '
                                         'at a time, and a stream with three windows in flight'}

@@ -134,6 +134,19 @@ int ry_vc_stage1(ry_vc* vc, const float* x_eff, int n_eff, float* y1_out);
 int ry_vc_stage2_from_mc(ry_vc* vc, const int* row_of, int n_eff, int n_frames, float sp_floor, float* sp_out);
 int ry_vc_mid_sp(ry_vc* vc, const int* row_of, int n_eff, int n_frames, float sp_floor, float* sp_mid_out);
 int ry_vc_reserve_frames(ry_vc* vc, int n_frames);   /* optional: size the ring ahead of the first window */
+/* ry_vc_submit with `separate_effective` (voice_changer.py:27-31) ON THE DEVICE: the raw wave (float32) and the feature block of ALL
+ * frames go up; frame powers (librosa.feature.rms(center=True, pad 'reflect') ** 2 in float32, numpy's summation order), the gate, the
+ * ordered compaction of the effective rows and the scatter back happen there.  The gate is evaluated in the power domain: effective =
+ * mse >= p_effective, or every frame when max(mse) >= p_all (power_to_db's top_db clamp); both thresholds come from the host's own
+ * float32 log10 by bisection (realtime_yukarin_amd/gate.py), so the mask equals the host formula's bit for bit.  fft_length: a power
+ * of two in 128 .. 1024.  ry_vc_wait_wave also returns the mask (n_frames bytes) and the count. */
+int ry_vc_submit_wave(ry_vc* vc, const float* wave, int n_samples, int hop, int fft_length, float p_effective, float p_all,
+                      const float* feat, int n_frames, float sp_floor, int* ticket);
+int ry_vc_wait_wave(ry_vc* vc, int ticket, float* mc_out, float* sp_out, unsigned char* effective_out, int* n_eff_out);
+/* The gate alone (`separate_effective`): mask [n_frames], count, and optionally the gathered rows x_eff [n_eff][in_ch] and their
+ * frame indices row_of [n_eff] (null to skip). */
+int ry_vc_gate(ry_vc* vc, const float* wave, int n_samples, int hop, int fft_length, float p_effective, float p_all,
+               const float* feat, int n_frames, unsigned char* effective_out, int* n_eff_out, float* x_eff_out, int* row_of_out);
 /* `AcousticConverter.decode_spectrogram` alone (host pointers): sp [n][bins] = exp(mc [n][m] @ mtx [m][bins]) + floor. */
 int ry_mc2sp(ry_ctx* ctx, const float* mc, const float* mtx, int n, int m, int bins, float floor, float* sp);
 

@@ -57,6 +57,11 @@ RY_DEV void ry_wave_sync() {
 RY_DEV void ry_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 RY_DEV float ry_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 RY_DEV float ry_shfl(float v, int src) { return __shfl(v, src, 64); }
+// separately rounded float32 product / sum (never contracted into an fma) and the correctly rounded square root: the silence gate
+// has to reproduce numpy's float32 arithmetic bit for bit
+RY_DEV float ry_mul_rn(float a, float b) { return __fmul_rn(a, b); }
+RY_DEV float ry_add_rn(float a, float b) { return __fadd_rn(a, b); }
+RY_DEV float ry_sqrt_rn(float a) { return __fsqrt_rn(a); }
 RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }
 
 typedef hipStream_t ry_stream_t;

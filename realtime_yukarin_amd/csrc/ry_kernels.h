@@ -393,6 +393,9 @@ template <int V> struct RyConst { static constexpr int value = V; };
 #ifndef RY_BF16_ISSUE_STEPS
 #define RY_BF16_ISSUE_STEPS 1
 #endif
+#ifndef RY_F32_ISSUE_STEPS
+#define RY_F32_ISSUE_STEPS 4      // fp32: the DMA pieces of the next chunk are spread over this many of the 4 K steps of the current one
+#endif
 
 template <int BM, int BN, int WM, int WN, int KG, bool BF16, int PATCH>
 RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
@@ -635,9 +638,10 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
                 for (int i = 0; i < TM; ++i) af[i] = ry_ld4(Ab + i * 32 * BK + pos);
     #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(Bc + ((wn * TN + j) * 4 + s) * 256 + lane * 4);
-                if (more) {
+                constexpr int ISG = BF16 ? NS : RY_F32_ISSUE_STEPS;
+                if (more && s < ISG) {
     #pragma unroll
-                    for (int q = (s * NI) / NS; q < ((s + 1) * NI) / NS; ++q) dma_item(q, An, Bn);
+                    for (int q = (s * NI) / ISG; q < ((s + 1) * NI) / ISG; ++q) dma_item(q, An, Bn);
                 }
                 if (BF16) {                        // one v_mfma_f32_32x32x16_bf16 per fragment pair: the 16 bytes are 8 bf16 of k = 16 s + 8 (lane >> 5) + j
     #pragma unroll
@@ -731,7 +735,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
             // DMA pieces of the next iteration: fp32 spreads them over the NS K steps of this one (a burst in front of the MFMAs
             // costs 5 %); a bf16 iteration is 16 x shorter on the matrix pipe, the pieces have to land before its closing
             // barrier, so they all go out in its FIRST K step (measured, split-bf16 forward: 4 / 2 / 1 steps -> 0.824 / 0.787 / 0.776 ms)
-            constexpr int ISL = BF16 ? RY_BF16_ISSUE_STEPS : NS;
+            constexpr int ISL = BF16 ? RY_BF16_ISSUE_STEPS : RY_F32_ISSUE_STEPS;
             auto issue = [&](int s) {
                 if (more_b && s < ISL) {
 #pragma unroll
@@ -1068,6 +1072,7 @@ struct RySrLastParams {
     int out_cols;               // W, or W + 1 with the last bin repeated (pad mode 'edge')
     int do_exp;
     int x3;                     // sources are split-bf16 copies [pixel][hi | lo] (rolling form only)
+    int xcd_band;               // rolling form: 1 = each XCD takes a contiguous band of output rows (the grid is then padded to 8 x ceil(blocks / 8))
 };
 
 // Simple form: 32 lanes per output pixel, 9 taps gathered per pixel (any width).
@@ -1120,8 +1125,17 @@ RY_KERNEL(256, 2) void ry_sr_last(RySrLastParams p) {
     constexpr int SW = 16;
     const int l = (int)threadIdx.x & 31;
     const int strips = p.W / SW;
-    const long long sid = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
     const long long total = (long long)p.B * p.rows_valid * strips;
+    // Workgroup b runs on XCD b % 8 (one L2 each) and every input row is read by three output rows: give each XCD a contiguous
+    // band of output rows, so that the re-reads hit ITS L2 instead of going back to the fabric three times (measured FETCH_SIZE
+    // 109 MB raw per launch against 100 MB of input with raster-order blocks, i.e. ~2.2x in HBM bytes).
+    long long lb = (long long)blockIdx.x;
+    if (p.xcd_band) {
+        const long long nb = (total + 7) >> 3, per = (nb + 7) >> 3;
+        lb = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (lb >= nb) return;
+    }
+    const long long sid = lb * 8 + (threadIdx.x >> 5);
     const bool live = sid < total;
     const long long ss = live ? sid : 0;
     const int x0 = (int)(ss % strips) * SW;
@@ -1659,8 +1673,9 @@ struct RyPadRowsParams {
 
 // ry_pad_min_rows -- ry_colmin + ry_pad_rows in one launch (one graph node less on the convert path): a workgroup owns 16
 // columns (16 row groups x 16 columns), takes their minimum over the real rows, then writes the padded / logged block.
-RY_KERNEL(256) void ry_pad_min_rows(RyPadRowsParams p) {      // blockIdx.y = window of the batch
-    __shared__ float red[256];
+template <int G>                                              // G row groups x 16 columns = 16 G threads (G = 16 or 64)
+RY_KERNEL(16 * G) void ry_pad_min_rows(RyPadRowsParams p) {   // blockIdx.y = window of the batch
+    __shared__ float red[16 * G];
     const int tid = (int)threadIdx.x, cl = tid & 15, grp = tid >> 4;
     const int c = (int)blockIdx.x * 16 + cl;
     const float* in = p.in + (size_t)blockIdx.y * (size_t)p.in_bstride;
@@ -1668,14 +1683,15 @@ RY_KERNEL(256) void ry_pad_min_rows(RyPadRowsParams p) {      // blockIdx.y = wi
     const bool cin_ok = c < p.cols_in, cout_ok = c < p.cols_out;
     float m = INFINITY;
     const bool need_min = p.rows_out > p.rows_in;
-    // pass 1: rows grp, grp + 16, ...: copy (log) the real rows and track the column minimum; 8 loads in flight per lane
-    for (int r0 = grp; r0 < p.rows_in; r0 += 128) {
+    // pass 1: rows grp, grp + G, ...: copy (log) the real rows and track the column minimum; 8 loads in flight per lane (with
+    // G = 64 a 300-frame window is ONE batch of loads per lane: the kernel is a chain of memory latencies, not bandwidth)
+    for (int r0 = grp; r0 < p.rows_in; r0 += 8 * G) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int r = r0 + 16 * u; v[u] = (cin_ok && r < p.rows_in) ? in[(size_t)r * p.cols_in + c] : INFINITY; }
+        for (int u = 0; u < 8; ++u) { const int r = r0 + G * u; v[u] = (cin_ok && r < p.rows_in) ? in[(size_t)r * p.cols_in + c] : INFINITY; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int r = r0 + 16 * u;
+            const int r = r0 + G * u;
             m = fminf(m, v[u]);
             if (cout_ok && r < p.rows_in && r < p.rows_out) out[(size_t)r * p.cols_out + c] = p.take_log ? logf(v[u]) : v[u];
         }
@@ -1684,11 +1700,11 @@ RY_KERNEL(256) void ry_pad_min_rows(RyPadRowsParams p) {      // blockIdx.y = wi
     red[tid] = m;
     __syncthreads();
     float mm = red[cl];
-#pragma unroll
-    for (int g = 1; g < 16; ++g) mm = fminf(mm, red[g * 16 + cl]);
+#pragma unroll 8
+    for (int g = 1; g < G; ++g) mm = fminf(mm, red[g * 16 + cl]);
     if (!cout_ok) return;
     const float fill = p.take_log ? logf(mm) : mm;
-    for (int r = p.rows_in + grp; r < p.rows_out; r += 16) out[(size_t)r * p.cols_out + c] = fill;
+    for (int r = p.rows_in + grp; r < p.rows_out; r += G) out[(size_t)r * p.cols_out + c] = fill;
 }
 
 RY_KERNEL(256) void ry_pad_rows(RyPadRowsParams p) {  // blockIdx.y = window of the batch
@@ -1728,6 +1744,95 @@ RY_KERNEL(256) void ry_scatter_rows(RyScatterParams p) {       // dst[row_of[i]]
     if (idx >= (long long)p.n_src * p.cols) return;
     const int c = (int)(idx % p.cols), i = (int)(idx / p.cols);
     p.dst[(size_t)p.row_of[i] * p.cols + c] = p.src[idx];
+}
+
+// ---------------------------------------------------------------------------------------------
+// `AcousticConverter.separate_effective` on the device (voice_changer.py:27-31).
+// ry_frame_power: mse[t] = librosa.feature.rms(wave, frame_length, hop, center=True, pad_mode='reflect')[t] ** 2 in float32 with
+//   NUMPY'S summation order, so that the mask is the host formula's bit for bit: `mean(abs(x) ** 2, axis=0)` of librosa's frame view
+//   is numpy's pairwise sum -- leaves of 128 elements, each 8 interleaved accumulators r[j] += a[8 i + j] combined as
+//   ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), leaves combined in a binary tree.  One wave per frame: lane (leaf, j) walks its
+//   16 elements in order, then a butterfly over the lanes IS that tree (fp addition is commutative, the tree shape is what matters).
+//   fft_length = 128 .. 1024, a power of two.  Products and sums are rounded separately (no fma contraction), sqrt is correctly rounded.
+// ry_gate_compact: one workgroup: the gate in the POWER domain -- effective = mse >= p_eff, or every frame when max(mse) >= p_all
+//   (librosa.power_to_db's top_db clamp) -- with both thresholds derived on the host, once per threshold_db, by bisection over the
+//   float32 values through the host's own log10 (realtime_yukarin_amd/gate.py), then an ordered compaction: row_of, the feature rows
+//   of the effective frames, the mask and the count.
+// ---------------------------------------------------------------------------------------------
+struct RyFramePowerParams { const float* wave; int n, hop, fft, n_wave_frames; float* power; };
+
+RY_DEV int ry_reflect_index(int i, int n) {                     // numpy.pad(mode='reflect') source index
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    int j = i % period;
+    if (j < 0) j += period;
+    return j < n ? j : period - j;
+}
+
+RY_KERNEL(256) void ry_frame_power(RyFramePowerParams p) {
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int frame = (int)blockIdx.x * 4 + (tid >> 6);
+    if (frame >= p.n_wave_frames) return;                       // wave-uniform
+    const int L = p.fft >> 4;                                   // active lanes: 8 per 128-element leaf
+    float r = 0.f;
+    if (lane < L) {
+        const int base = frame * p.hop - (p.fft >> 1) + 128 * (lane >> 3) + (lane & 7);
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = p.wave[ry_reflect_index(base + 8 * i, p.n)];
+        r = ry_mul_rn(v[0], v[0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) r = ry_add_rn(r, ry_mul_rn(v[i], v[i]));
+    }
+    for (int mask = 1; mask < L; mask <<= 1) r = ry_add_rn(r, ry_shfl_xor(r, mask));
+    if (lane == 0) {
+        const float rms = ry_sqrt_rn(r / (float)p.fft);        // a power of two: the division is exact scaling, as numpy's
+        p.power[frame] = ry_mul_rn(rms, rms);
+    }
+}
+
+struct RyGateParams {
+    const float* power; int n_wave_frames, n_frames; float p_eff, p_all;
+    const float* feat; int cin;                                // [n_frames][cin]
+    float* x_eff; int* row_of; int* count; unsigned char* mask;
+};
+
+RY_KERNEL(1024) void ry_gate_compact(RyGateParams p) {
+    __shared__ float fmx[1024];
+    __shared__ int scan[1024];
+    __shared__ int s_base;
+    const int tid = (int)threadIdx.x;
+    float m = 0.f;
+    for (int t = tid; t < p.n_wave_frames; t += 1024) m = fmaxf(m, p.power[t]);
+    fmx[tid] = m;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (tid < s) fmx[tid] = fmaxf(fmx[tid], fmx[tid + s]); __syncthreads(); }
+    const bool all = fmx[0] >= p.p_all;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < p.n_frames; t0 += 1024) {
+        const int t = t0 + tid;
+        const bool eff = t < p.n_frames && t < p.n_wave_frames && (all || p.power[t] >= p.p_eff);
+        scan[tid] = eff ? 1 : 0;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {                    // inclusive Hillis-Steele scan
+            const int add = tid >= d ? scan[tid - d] : 0;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        const int base = s_base;
+        if (t < p.n_frames) p.mask[t] = eff ? 1 : 0;
+        if (eff) {
+            const int pos = base + scan[tid] - 1;
+            p.row_of[pos] = t;
+            for (int c = 0; c < p.cin; ++c) p.x_eff[(size_t)pos * p.cin + c] = p.feat[(size_t)t * p.cin + c];
+        }
+        __syncthreads();
+        if (tid == 1023) s_base = base + scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) *p.count = s_base;
 }
 
 struct RyMc2spParams { const float* mc; const float* mtx; float* sp; int n, m, f; float floor; };

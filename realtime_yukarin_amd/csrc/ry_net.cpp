@@ -519,6 +519,7 @@ static void tile_dims(int tile, int* bm, int* bn) {
 }
 
 
+static int g_last_band = 1;   // RY_LAST_BAND=0: raster-order workgroups in ry_sr_last (A/B of the per-XCD row bands)
 static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
 static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
@@ -824,7 +825,9 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         dim3 grid((unsigned)((total + 7) / 8));
         if (C1 + C2 == 128 && lp.Wi % 16 == 0) {
             const long long strips = (long long)B * p.rows_valid * (lp.Wi / 16);
-            dim3 sg((unsigned)((strips + 7) / 8));
+            p.xcd_band = g_last_band;
+            const long long nb = (strips + 7) / 8;
+            dim3 sg((unsigned)(g_last_band ? ((nb + 7) / 8) * 8 : nb));
             RY_TRY(Lc.begin(lp.last_x3 ? "ry_sr_last<true>" : "ry_sr_last<false>", l.name, lp.flops, lp.bytes, sg));
             p.x3 = lp.last_x3 ? 1 : 0;
             if (lp.last_x3) RY_LAUNCH(ry_sr_last<true>, sg, 256, Lc.stream, p);
@@ -1147,7 +1150,8 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
         q.in_bstride = (long long)P.n_frames * cols_in; q.out_bstride = (long long)P.T * cols_out; q.minv_bstride = cols_in;
         dim3 pg((unsigned)((cols_in + 15) / 16), (unsigned)B);
         RY_TRY(Lc.begin("ry_pad_min_rows", "pad", 0, 4.0 * B * (P.n_frames * cols_in + P.T * cols_out), pg));
-        RY_LAUNCH(ry_pad_min_rows, pg, 256, Lc.stream, q);
+        if (P.n_frames > 128) RY_LAUNCH(ry_pad_min_rows<64>, pg, 1024, Lc.stream, q);   // one batch of loads per lane up to 512 frames
+        else RY_LAUNCH(ry_pad_min_rows<16>, pg, 256, Lc.stream, q);
         RY_TRY(Lc.end());
     }
     for (int i = 0; i < 16; ++i) {
@@ -1413,6 +1417,7 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_PLAN_X3_PEAK")) g_x3_peak = atof(e) * 1e6;
     if (const char* e = getenv("RY_PLAN_X3_KG2")) g_x3_kg2 = atof(e);
     if (const char* e = getenv("RY_XCD_GROUPS")) g_xcd_groups = atoi(e);
+    if (const char* e = getenv("RY_LAST_BAND")) g_last_band = atoi(e);
     if (const char* e = getenv("RY_S1_OS")) g_s1_os = atoi(e);
     if (const char* e = getenv("RY_S1_UNITS")) g_s1_units = atoi(e) > 0 ? atoi(e) : 1;
     memset(g_s1_force, 0, sizeof(g_s1_force));
@@ -1712,6 +1717,12 @@ int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat*
 struct VcSlot {
     float *h_x = nullptr, *h_mc = nullptr, *h_sp = nullptr;   // pinned
     int* h_row = nullptr;                                       // pinned
+    // device-side silence gate (ry_vc_submit_wave): the raw wave and the full feature block go up, the mask and the count come back
+    float *h_wave = nullptr, *d_wave = nullptr, *h_feat = nullptr, *d_feat = nullptr, *d_pow = nullptr;
+    unsigned char *h_mask = nullptr, *d_mask = nullptr;
+    int *h_count = nullptr, *d_count = nullptr;
+    int cap_wave = 0;
+    bool gated = false;      // the window in the slot came through ry_vc_submit_wave
     float *d_x = nullptr, *d_y1 = nullptr, *d_mc = nullptr, *d_sp = nullptr, *d_out = nullptr;
     int* d_row = nullptr;
     rt::Event ev_mid;        // stage-1 stream: the spectrogram of this window is in d_sp (and mc in h_mc)
@@ -1769,6 +1780,16 @@ static int vc_reserve(ry_vc* vc, int n_eff, int n_frames) {
         RY_TRY(vc_halloc(vc, (void**)&sl.h_row, e1 * sizeof(int)));
         RY_TRY(vc_halloc(vc, (void**)&sl.h_mc, (size_t)cf * vc->M * sizeof(float)));
         RY_TRY(vc_halloc(vc, (void**)&sl.h_sp, (size_t)cf * vc->F * sizeof(float)));
+        // gate buffers: the feature block of ALL frames, one power per frame, the mask and the count (the wave buffer is sized on demand)
+        float* q = nullptr;
+        RY_TRY(vc->bufs.alloc(&sl.d_feat, (size_t)cf * cin));
+        RY_TRY(vc->bufs.alloc(&sl.d_pow, (size_t)cf + 8));
+        RY_TRY(vc->bufs.alloc(&q, (size_t)cf / 4 + 4)); sl.d_mask = (unsigned char*)q;
+        RY_TRY(vc->bufs.alloc(&q, 4)); sl.d_count = (int*)q;
+        RY_TRY(vc_halloc(vc, (void**)&sl.h_feat, (size_t)cf * cin * sizeof(float)));
+        RY_TRY(vc_halloc(vc, (void**)&sl.h_mask, (size_t)cf + 16));
+        RY_TRY(vc_halloc(vc, (void**)&sl.h_count, 16));
+        sl.h_wave = nullptr; sl.d_wave = nullptr; sl.cap_wave = 0;
         sl.used = false;
     }
     vc->cap_eff = ce; vc->cap_frames = cf;
@@ -1865,7 +1886,7 @@ int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, in
     RY_TRY(ry_sr_convert(s2, sl.d_sp, sl.d_out, 1, n_frames, 1));
     RT_TRY(rt::d2h(sl.h_sp, sl.d_out, (size_t)n_frames * F * sizeof(float), st2));
     RT_TRY(rt::event_record(sl.ev_done, st2));
-    sl.used = true; sl.ticket = t; sl.n_eff = n_eff; sl.n_frames = n_frames;
+    sl.used = true; sl.ticket = t; sl.n_eff = n_eff; sl.n_frames = n_frames; sl.gated = false;
     vc->split_eff = -1;
     vc->next_ticket = t + 1;
     *ticket = t;
@@ -1891,6 +1912,125 @@ int ry_vc_convert(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, i
     int t = -1;
     RY_TRY(ry_vc_submit(vc, x_eff, row_of, n_eff, n_frames, sp_floor, &t));
     return ry_vc_wait(vc, t, mc_out, sp_out);
+}
+
+
+// ---- the silence gate on the device: `separate_effective` + the gather of the effective rows, then the
+// chain of ry_vc_submit.  The number of effective frames fixes the padded length of stage 1 (128 - n % 128), so the count is read
+// back (4 bytes, pinned) before stage 1 is queued: one short wait per window in exchange for the host-side numpy gate.
+}  // extern "C"
+
+// wave + features up, frame powers, gate, compaction, count and mask back (waits for the count); leaves x_eff / row_of in the slot
+static int vc_gate_into_slot(ry_vc* vc, VcSlot& sl, const float* wave, int n_samples, int hop, int fft_length, float p_effective, float p_all,
+                             const float* feat, int n_frames, int* n_eff_out) {
+    ry_net* s1 = vc->s1;
+    const int cin = s1->desc.in_ch;
+    ry_stream_t st1 = s1->stream;
+    if (sl.used) RT_TRY(rt::stream_wait_event(st1, sl.ev_done));
+    if (n_samples > sl.cap_wave) {                              // wave staging of this slot, grown on demand (owned by the ring's arenas)
+        RT_TRY(rt::stream_sync(st1));
+        const int cap = n_samples + n_samples / 4 + 1024;
+        RY_TRY(vc->bufs.alloc(&sl.d_wave, (size_t)cap));
+        RY_TRY(vc_halloc(vc, (void**)&sl.h_wave, (size_t)cap * sizeof(float)));
+        sl.cap_wave = cap;
+    }
+    memcpy(sl.h_wave, wave, (size_t)n_samples * sizeof(float));
+    memcpy(sl.h_feat, feat, (size_t)n_frames * cin * sizeof(float));
+    RT_TRY(rt::h2d(sl.d_wave, sl.h_wave, (size_t)n_samples * sizeof(float), st1));
+    RT_TRY(rt::h2d(sl.d_feat, sl.h_feat, (size_t)n_frames * cin * sizeof(float), st1));
+    Launcher Lc{s1, s1->ctx, st1, nullptr, nullptr};
+    int n_wave_frames = n_samples / hop + 1;                    // librosa: 1 + (len + 2 * (fft / 2) - fft) / hop
+    if (n_wave_frames > n_frames) n_wave_frames = n_frames;     // frames past the feature block are never looked at
+    RyFramePowerParams fp;
+    fp.wave = sl.d_wave; fp.n = n_samples; fp.hop = hop; fp.fft = fft_length; fp.n_wave_frames = n_wave_frames; fp.power = sl.d_pow;
+    dim3 fg((unsigned)((n_wave_frames + 3) / 4));
+    RY_TRY(Lc.begin("ry_frame_power", "separate_effective", 0, 0, fg));
+    RY_LAUNCH(ry_frame_power, fg, 256, st1, fp);
+    RY_TRY(Lc.end());
+    RyGateParams gp;
+    gp.power = sl.d_pow; gp.n_wave_frames = n_wave_frames; gp.n_frames = n_frames; gp.p_eff = p_effective; gp.p_all = p_all;
+    gp.feat = sl.d_feat; gp.cin = cin; gp.x_eff = sl.d_x; gp.row_of = sl.d_row; gp.count = sl.d_count; gp.mask = sl.d_mask;
+    RY_TRY(Lc.begin("ry_gate_compact", "separate_effective", 0, 0, dim3(1)));
+    RY_LAUNCH(ry_gate_compact, dim3(1), 1024, st1, gp);
+    RY_TRY(Lc.end());
+    RT_TRY(rt::d2h(sl.h_count, sl.d_count, sizeof(int), st1));
+    RT_TRY(rt::d2h(sl.h_mask, sl.d_mask, (size_t)n_frames, st1));
+    RT_TRY(rt::stream_sync(st1));                               // the count picks the stage-1 plan
+    const int n_eff = sl.h_count[0];
+    if (n_eff < 0 || n_eff > n_frames) return fail(RY_EHIP, "the gate returned %d effective frames of %d", n_eff, n_frames);
+    *n_eff_out = n_eff;
+    return RY_OK;
+}
+
+static int vc_gate_args(const ry_vc* vc, const float* wave, int n_samples, int hop, int fft_length, const float* feat, int n_frames) {
+    if (!vc || !wave || !feat) return fail(RY_EINVAL, "null argument");
+    if (n_samples < 1 || n_frames < 1 || hop < 1) return fail(RY_EINVAL, "bad sizes (%d samples, %d frames, hop %d)", n_samples, n_frames, hop);
+    if (fft_length < 128 || fft_length > 1024 || (fft_length & (fft_length - 1)))
+        return fail(RY_EINVAL, "the device gate takes fft_length 128 .. 1024, a power of two (got %d): use the host gate", fft_length);
+    return RY_OK;
+}
+
+extern "C" {
+
+// `AcousticConverter.separate_effective` alone: the mask, the count and (optionally) the gathered rows and their frame indices
+int ry_vc_gate(ry_vc* vc, const float* wave, int n_samples, int hop, int fft_length, float p_effective, float p_all,
+               const float* feat, int n_frames, unsigned char* effective_out, int* n_eff_out, float* x_eff_out, int* row_of_out) {
+    RY_TRY(vc_gate_args(vc, wave, n_samples, hop, fft_length, feat, n_frames));
+    if (!effective_out || !n_eff_out) return fail(RY_EINVAL, "null argument");
+    RT_TRY(rt::set_device(vc->s1->ctx->device));
+    RY_TRY(vc_reserve(vc, n_frames, n_frames));
+    VcSlot& sl = vc->slot[0];
+    if (sl.ticket >= 0) return fail(RY_ESTATE, "ring slot 0 is held by ticket %d: ry_vc_wait it first", sl.ticket);
+    int n_eff = 0;
+    RY_TRY(vc_gate_into_slot(vc, sl, wave, n_samples, hop, fft_length, p_effective, p_all, feat, n_frames, &n_eff));
+    memcpy(effective_out, sl.h_mask, (size_t)n_frames);
+    *n_eff_out = n_eff;
+    const int cin = vc->s1->desc.in_ch;
+    if (n_eff > 0 && x_eff_out) RT_TRY(rt::d2h(x_eff_out, sl.d_x, (size_t)n_eff * cin * sizeof(float), vc->s1->stream));
+    if (n_eff > 0 && row_of_out) RT_TRY(rt::d2h(row_of_out, sl.d_row, (size_t)n_eff * sizeof(int), vc->s1->stream));
+    RT_TRY(rt::stream_sync(vc->s1->stream));
+    vc->split_eff = -1;
+    return RY_OK;
+}
+
+int ry_vc_submit_wave(ry_vc* vc, const float* wave, int n_samples, int hop, int fft_length, float p_effective, float p_all,
+                      const float* feat, int n_frames, float sp_floor, int* ticket) {
+    RY_TRY(vc_gate_args(vc, wave, n_samples, hop, fft_length, feat, n_frames));
+    if (!ticket) return fail(RY_EINVAL, "null argument");
+    ry_net *s1 = vc->s1, *s2 = vc->s2;
+    RT_TRY(rt::set_device(s1->ctx->device));
+    RY_TRY(vc_reserve(vc, n_frames, n_frames));
+    const int t = vc->next_ticket;
+    VcSlot& sl = vc->slot[t % ry_vc::RING];
+    if (sl.ticket >= 0) return fail(RY_ESTATE, "all %d ring slots are in flight: ry_vc_wait ticket %d first", ry_vc::RING, sl.ticket);
+    const int M = vc->M, F = vc->F;
+    ry_stream_t st1 = s1->stream, st2 = s2->stream;
+    int n_eff = 0;
+    RY_TRY(vc_gate_into_slot(vc, sl, wave, n_samples, hop, fft_length, p_effective, p_all, feat, n_frames, &n_eff));
+    if (n_eff > 0) RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1));
+    RY_TRY(vc_enqueue_mid(vc, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp));
+    RT_TRY(rt::d2h(sl.h_mc, sl.d_mc, (size_t)n_frames * M * sizeof(float), st1));
+    RT_TRY(rt::event_record(sl.ev_mid, st1));
+    RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));
+    RY_TRY(ry_sr_convert(s2, sl.d_sp, sl.d_out, 1, n_frames, 1));
+    RT_TRY(rt::d2h(sl.h_sp, sl.d_out, (size_t)n_frames * F * sizeof(float), st2));
+    RT_TRY(rt::event_record(sl.ev_done, st2));
+    sl.used = true; sl.ticket = t; sl.n_eff = n_eff; sl.n_frames = n_frames; sl.gated = true;
+    vc->split_eff = -1;
+    vc->next_ticket = t + 1;
+    *ticket = t;
+    return RY_OK;
+}
+
+int ry_vc_wait_wave(ry_vc* vc, int ticket, float* mc_out, float* sp_out, unsigned char* effective_out, int* n_eff_out) {
+    if (!vc || !effective_out) return fail(RY_EINVAL, "null argument");
+    if (ticket < 0) return fail(RY_EINVAL, "bad ticket %d", ticket);
+    VcSlot& sl = vc->slot[ticket % ry_vc::RING];
+    if (sl.ticket != ticket || !sl.gated) return fail(RY_ESTATE, "ticket %d is not a window submitted with ry_vc_submit_wave", ticket);
+    memcpy(effective_out, sl.h_mask, (size_t)sl.n_frames);      // (already on the host: the submit waited for the count)
+    if (n_eff_out) *n_eff_out = sl.n_eff;
+    sl.gated = false;
+    return ry_vc_wait(vc, ticket, mc_out, sp_out);
 }
 
 // Everything on the device, nothing waited for: consecutive calls pipeline by themselves (stage-1 of window i + 1 runs on

@@ -155,6 +155,43 @@ class VcCore(object):
         """x_eff (n_eff, in_ch) = features of the effective frames, effective (n_frames,) bool -> (mc (n_frames, M), sp (n_frames, F))."""
         return self.wait(self.submit(x_eff, effective, sp_floor))
 
+    def submit_wave(self, wave: numpy.ndarray, hop: int, fft_length: int, p_effective: float, p_all: float, feat: numpy.ndarray,
+                    sp_floor: float = 1e-16) -> int:
+        """`ry_vc_submit_wave`: the silence gate on the device.  wave float32 (n_samples,), feat (n_frames, in_ch) = the features of ALL
+        frames; the thresholds come from `gate.thresholds(threshold_db)`."""
+        wave = numpy.ascontiguousarray(wave, dtype=numpy.float32)
+        feat = numpy.ascontiguousarray(feat, dtype=numpy.float32)
+        t = ctypes.c_int(-1)
+        self.lib.check(self.lib.dll.ry_vc_submit_wave(self.handle, _lib._fptr(wave), wave.size, int(hop), int(fft_length), float(p_effective),
+                                                      float(p_all), _lib._fptr(feat), feat.shape[0], float(sp_floor), ctypes.byref(t)))
+        self._pending[t.value] = feat.shape[0]
+        return int(t.value)
+
+    def gate(self, wave: numpy.ndarray, hop: int, fft_length: int, p_effective: float, p_all: float, feat: numpy.ndarray):
+        """`ry_vc_gate`: `separate_effective` alone on the device -> (effective (n,) bool, x_eff (n_eff, in_ch), row_of (n_eff,))."""
+        wave = numpy.ascontiguousarray(wave, dtype=numpy.float32)
+        feat = numpy.ascontiguousarray(feat, dtype=numpy.float32)
+        n = feat.shape[0]
+        mask = numpy.empty(n, dtype=numpy.uint8)
+        x = numpy.empty((n, feat.shape[1]), dtype=numpy.float32)
+        rows = numpy.empty(n, dtype=numpy.int32)
+        n_eff = ctypes.c_int(0)
+        self.lib.check(self.lib.dll.ry_vc_gate(self.handle, _lib._fptr(wave), wave.size, int(hop), int(fft_length), float(p_effective), float(p_all),
+                                               _lib._fptr(feat), n, mask.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), ctypes.byref(n_eff),
+                                               _lib._fptr(x), rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return mask.astype(bool), x[:n_eff.value], rows[:n_eff.value]
+
+    def wait_wave(self, ticket: int):
+        """(mc, sp, effective (n_frames,) bool) of a window submitted with `submit_wave`."""
+        n = self._pending.pop(ticket)
+        mc = numpy.empty((n, self.M), dtype=numpy.float32)
+        sp = numpy.empty((n, self.F), dtype=numpy.float32)
+        mask = numpy.empty(n, dtype=numpy.uint8)
+        n_eff = ctypes.c_int(0)
+        self.lib.check(self.lib.dll.ry_vc_wait_wave(self.handle, int(ticket), _lib._fptr(mc), _lib._fptr(sp),
+                                                    mask.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), ctypes.byref(n_eff)))
+        return mc, sp, mask.astype(bool)
+
     def convert_stream(self, windows, sp_floor: float = 1e-16, depth: int = 2):
         """Generator over (x_eff, effective) pairs -> (mc, sp) in order, keeping `depth` windows in flight: the copies of one window
         run under the kernels of another."""

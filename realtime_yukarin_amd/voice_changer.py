@@ -5,6 +5,7 @@ ConvertStream at realtime_voice_conversion/stream/convert_stream.py:15-27), same
 `sp += 1e-16` / float32 cast, so that the reference's own class and this one are interchangeable.  Added on top:
 `convert_windows`, which runs the two CNNs for several independent windows in one GPU batch (chunk parallelism
 inside a GPU)."""
+import os
 from typing import List, Optional
 
 import numpy
@@ -34,7 +35,6 @@ class VoiceChanger(object):
         ac, sr = self.acoustic_converter, self.super_resolution
         if not (hasattr(ac, 'fusable') and hasattr(sr, '_get_net') and ac.fusable()):
             return None
-        import os
         from . import engine
         key = os.getpid()
         if getattr(self, '_core_pid', None) != key:
@@ -45,7 +45,6 @@ class VoiceChanger(object):
 
     def close(self) -> None:
         """Free the device-resident core (ring buffers, pinned staging) in the process that built it; the converters stay usable."""
-        import os
         if getattr(self, '_core_pid', None) == os.getpid() and getattr(self, '_core', None) is not None:
             self._core.close()
         self._core, self._core_pid = None, None
@@ -56,10 +55,25 @@ class VoiceChanger(object):
             f_out = self._stage1(f_in)
             f_out.sp = self.super_resolution.convert(f_out.sp.astype(numpy.float32))
             return f_out
-        # device-resident path: silence mask on the host (it reads the raw wave), everything else in one ry_vc_convert
+        # device-resident path: everything in one window call.  The silence gate runs on the device too (ry_vc_submit_wave) when it
+        # can restate the host arithmetic bit for bit (float32 wave, absolute reference, power-of-two frame length); otherwise the
+        # mask is taken on the host (it reads the raw wave) and only the effective rows go up (ry_vc_convert).
         ac = self.acoustic_converter
-        f_eff, effective = ac.separate_effective(wave=f_in.wave, feature=f_in, threshold=self.threshold)
-        mc, sp = core.convert(numpy.asarray(f_eff.mc, dtype=numpy.float32), effective, SP_FLOOR)
+        from . import gate
+        from yukarin.wave import default_effective_ref
+        param = ac.config.dataset.acoustic_param
+        wave = f_in.wave
+        thr = self.threshold if self.threshold is not None else param.threshold_db
+        n = len(f_in.f0)
+        w = numpy.asarray(wave.wave)
+        if os.environ.get('RY_DEVICE_GATE', '1') != '0' and gate.device_gate_usable(w, param.fft_length, thr, default_effective_ref()):
+            hop, _ = wave.get_hop_and_length(param.frame_period)
+            p_eff, p_all = gate.thresholds(thr)
+            mc, sp, effective = core.wait_wave(core.submit_wave(w, hop, param.fft_length, p_eff, p_all, numpy.asarray(f_in.mc, dtype=numpy.float32), SP_FLOOR))
+            f_eff = f_in.indexing(effective)
+        else:
+            f_eff, effective = ac.separate_effective(wave=wave, feature=f_in, threshold=self.threshold)
+            mc, sp = core.convert(numpy.asarray(f_eff.mc, dtype=numpy.float32), effective, SP_FLOOR)
         f_out = ac.combine_silent(effective=effective, feature=self._passthrough(f_eff))
         f_out.mc = mc
         f_out.sp = sp

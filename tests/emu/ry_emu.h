@@ -58,6 +58,9 @@ RY_DEV void ry_glds16_off(const float* base_uniform, unsigned byte_off_lane, flo
 RY_DEV int ry_uniform(int v) { return v; }
 RY_DEV void ry_wave_sync() { ry_emu::wave_sync(); }
 RY_DEV void ry_sched_fence() {}
+RY_DEV float ry_mul_rn(float a, float b) { volatile float r = a * b; return r; }     // volatile: no contraction with a following add
+RY_DEV float ry_add_rn(float a, float b) { volatile float r = a + b; return r; }
+RY_DEV float ry_sqrt_rn(float a) { return sqrtf(a); }
 RY_DEV float ry_shfl_xor(float v, int mask) { return ry_emu::shfl_xor(v, mask); }
 RY_DEV float ry_shfl(float v, int src) { return ry_emu::shfl(v, src); }
 RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }

@@ -1,0 +1,115 @@
+"""SURVEY.md 8(f) row 2 -- `separate_effective` on the device (`ry_vc_submit_wave`): frame powers, gate, ordered compaction, against
+the independent loop-per-frame oracle (oracle/effective_frame.py).  Index / boolean work: the masks must be EQUAL bit for bit, and the
+spectrogram must be the one the host-gated path returns for the same mask.  Emulator here, the real GPU under -m gpu."""
+import numpy
+import pytest
+
+from oracle import effective_frame as oef
+from realtime_yukarin_amd import compat, engine, gate, sptk, synth
+from realtime_yukarin_amd.weights import flatten_params
+
+compat.install()
+FS, FP, HOP = 16000, 5, 80
+
+
+def waves():
+    rng = numpy.random.default_rng(77)
+    w = (0.1 * rng.normal(size=300 * HOP)).astype(numpy.float32)
+    w[40 * HOP:140 * HOP] *= 1e-4
+    w[200 * HOP:230 * HOP] = 0.0
+    ramp = (numpy.geomspace(1e-6, 0.5, 120 * HOP) * rng.normal(size=120 * HOP)).astype(numpy.float32)
+    w60 = w[:60 * HOP].copy(); w60[10 * HOP:25 * HOP] *= 1e-4; w60[40 * HOP:50 * HOP] = 0.0
+    return {'speechlike': w, 'ramp': ramp, 'speech60': w60, 'ramp40': ramp[::3].copy(), 'short': w[:300].copy(), 'tiny': w[:37].copy(), 'one_hop': w[:55].copy(),
+            'ragged': w[:1234].copy(), 'all_silent': numpy.zeros(50 * HOP, numpy.float32),
+            'all_loud': (0.5 * numpy.sign(rng.normal(size=50 * HOP))).astype(numpy.float32),
+            'loud_clamp': (30.0 * rng.normal(size=40 * HOP)).astype(numpy.float32)}          # max power > 20 dB: top_db clamp territory
+
+
+def make_core(ctx, name, sp_fftlen=256):
+    """A small spectrogram (sp_fftlen / 2 + 1 bins) keeps the chain behind the gate cheap: the gate is the thing under test."""
+    (d1, P1), (d2, P2) = synth.model_params(name)
+    n1 = engine.Net(ctx, d1, flatten_params(d1, P1))
+    n2 = engine.Net(ctx, d2, flatten_params(d2, P2), width=sp_fftlen // 2)
+    return engine.VcCore(n1, n2, sptk.mc2sp_matrix(8, sptk.mcepalpha(FS), sp_fftlen)), n1, n2
+
+
+def run_all(ctx, name, fft_lengths=(1024, 256), thrs=(60, 80, 100, 20), deltas=(0, 1, -1), only=None, chain=True):
+    core, n1, n2 = make_core(ctx, name)
+    rng = numpy.random.default_rng(5)
+    checked = 0
+    for wname, w in waves().items():
+        if only is not None and wname not in only:
+            continue
+        for fft in fft_lengths:
+            for thr in thrs:
+                for delta in deltas:
+                    n = len(w) // HOP + 1 + delta
+                    if n < 1:
+                        continue
+                    feat = (rng.normal(size=(n, 9)) * synth.MC_SCALE).astype(numpy.float32)
+                    want = oef.separate_effective_mask(w, FS, n, thr, fft, FP, 'abs')
+                    p_eff, p_all = gate.thresholds(thr)
+                    eff, x_eff, rows = core.gate(w, HOP, fft, p_eff, p_all, feat)            # the gate alone: mask, gathered rows, their indices
+                    assert numpy.array_equal(eff, want), (wname, fft, thr, delta, numpy.nonzero(eff != want)[0][:8])
+                    assert numpy.array_equal(rows, numpy.nonzero(want)[0]) and numpy.array_equal(x_eff, feat[want])
+                    if chain and fft == 1024 and thr in (60, 100) and delta == 0:     # the whole window: same as the host-gated call
+                        mc, sp, eff2 = core.wait_wave(core.submit_wave(w, HOP, fft, p_eff, p_all, feat))
+                        mc2, sp2 = core.convert(feat[want], want)
+                        assert numpy.array_equal(eff2, want) and numpy.array_equal(mc, mc2) and numpy.array_equal(sp, sp2)
+                        assert not mc[~want].any()
+                    checked += 1
+    core.close(); n1.close(); n2.close()
+    return checked
+
+
+def test_thresholds_reproduce_the_host_gate_at_the_boundary():
+    """The two float32 thresholds ARE the host predicate: one ulp below p_effective the shim's expression says 'not effective'."""
+    from yukarin.wave import AMIN
+    for thr in (20, 60, 80, 100):
+        p_eff, p_all = gate.thresholds(thr)
+        for p, want in ((numpy.float32(p_eff), True), (numpy.nextafter(numpy.float32(p_eff), numpy.float32(0)), False)):
+            db = 10.0 * numpy.log10(numpy.maximum(AMIN, numpy.full(7, p, numpy.float32)))
+            assert bool((db > -thr).all()) == want
+        assert p_all > p_eff
+
+
+def test_device_gate_masks_are_bit_equal_emu(emu_ctx):
+    # (the emulator runs a 1024-fiber workgroup per window: a subset here, the full cross product on the GPU)
+    assert run_all(emu_ctx, 'SYN-8', only=('speech60', 'ramp40', 'short', 'tiny', 'one_hop', 'ragged', 'all_silent', 'all_loud', 'loud_clamp'),
+                   chain=False) >= 200
+    assert run_all(emu_ctx, 'SYN-8', fft_lengths=(1024,), thrs=(60,), deltas=(0,), only=('speech60', 'tiny', 'all_silent')) == 3
+
+
+def test_mirror_voice_changer_takes_the_device_gate(emu_ctx, monkeypatch, tmp_path):
+    """The mirror VoiceChanger uses `submit_wave` for a float32 wave and falls back to the host gate otherwise; same outputs."""
+    import test_shims_e2e as e2e
+    monkeypatch.setattr(engine, 'get_context', lambda device=0, lib=None: emu_ctx)
+    from realtime_yukarin_amd.voice_changer import VoiceChanger
+    from yukarin import AcousticFeature, Wave
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    wave, feat = e2e.make_window(60, 21)
+    calls = []
+    real = engine.VcCore.submit_wave
+    monkeypatch.setattr(engine.VcCore, 'submit_wave', lambda self, *a, **k: calls.append(1) or real(self, *a, **k))
+
+    def run(w):
+        class Wrapped(AcousticFeature):
+            pass
+        f = Wrapped(**{k: v.copy() for k, v in feat.items()}); f.wave = Wave(wave=w, sampling_rate=FS)
+        return VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60).convert_from_acoustic_feature(f)
+    dev = run(wave)
+    assert calls == [1]
+    host = run(wave.astype(numpy.float64).astype(numpy.float32).astype(numpy.float64))     # a float64 wave: host gate (different arithmetic)
+    assert calls == [1]
+    monkeypatch.setenv('RY_DEVICE_GATE', '0')
+    host32 = run(wave)
+    assert calls == [1]
+    for o in (host32,):
+        assert numpy.array_equal(dev.sp, o.sp) and numpy.array_equal(dev.mc, o.mc) and numpy.array_equal(dev.f0, o.f0) and numpy.array_equal(dev.ap, o.ap)
+    assert float(numpy.abs(dev.sp / host.sp - 1).max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_device_gate_masks_are_bit_equal_gpu(gpu_ctx):
+    assert run_all(gpu_ctx, 'SYN-8') > 160
