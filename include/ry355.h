@@ -101,6 +101,9 @@ int ry_conv1d(ry_ctx* ctx, const float* x, int B, int L, int Cin, const float* W
  * 6 implicit-GEMM in split-bf16 form (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate; the input is split on the host here); tile: 0 auto, 1 = 128x128, 2 = 256x64, 3 = 64x128, 4 = 32x128, 5 = 128x64, 6 = 96x128, 7 = 256x128. */
 int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int W, int Cin, const float* Wt, const float* bias, const float* bn,
               int Cout, int k, int stride, int pad, int transposed, int act, int path, int tile, int splits, float* y);
+/* the same with a dilation (plain convolution on the implicit-GEMM or the direct path): out = (H + 2 pad - dilate (k - 1) - 1) / stride + 1 */
+int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int W, int Cin, const float* Wt, const float* bias, const float* bn,
+                      int Cout, int k, int stride, int pad, int dilate, int transposed, int act, int path, int tile, int splits, float* y);
 
 /* ---- the whole device-resident convert: stage-1 -> combine_silent -> mc2sp -> +floor -> stage-2 (voice_changer.py:27-41) ----
  * mc2sp(mc) = exp(mc @ mtx) with mtx [(order+1)][bins] precomputed on the host (every step of pysptk.mc2sp before the exp is

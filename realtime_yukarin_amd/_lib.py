@@ -26,7 +26,7 @@ TILES.update({k + 'k1': v + 32 for k, v in list(TILES.items()) if isinstance(k, 
 ABI_SYMBOLS = (
     'ry_init', 'ry_shutdown', 'ry_sync', 'ry_stream', 'ry_device_count', 'ry_last_error',
     'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_set_dtype', 'ry_net_forward',
-    'ry_ac_convert', 'ry_sr_convert', 'ry_conv1d', 'ry_conv2d',
+    'ry_ac_convert', 'ry_sr_convert', 'ry_conv1d', 'ry_conv2d', 'ry_conv2d_dilated',
     'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_debug_igemm_phases', 'ry_debug_plan_igemm', 'ry_debug_plan_igemm_bf16',
     'ry_vc_create', 'ry_vc_destroy', 'ry_vc_convert', 'ry_mc2sp',
     'ry_vc_submit', 'ry_vc_wait', 'ry_vc_enqueue_device', 'ry_vc_stage1', 'ry_vc_stage2_from_mc', 'ry_vc_mid_sp', 'ry_vc_reserve_frames',
@@ -95,6 +95,7 @@ class Ry355Lib(object):
         d.ry_sr_convert.argtypes = [_VP, _FP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         d.ry_conv1d.argtypes = [_VP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP] + [ctypes.c_int] * 8 + [_FP]
         d.ry_conv2d.argtypes = [_VP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP] + [ctypes.c_int] * 9 + [_FP]
+        d.ry_conv2d_dilated.argtypes = [_VP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP] + [ctypes.c_int] * 10 + [_FP]
         d.ry_vc_create.argtypes = [_VP, _VP, _FP, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_VP)]
         d.ry_vc_destroy.argtypes = [_VP]
         d.ry_vc_destroy.restype = None

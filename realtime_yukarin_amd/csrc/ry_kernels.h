@@ -84,6 +84,7 @@ struct RyConvGeom {
     int stride, pad, ostride;
     int nphases, ntaps;
     int kw;                     // taps per kernel row (conv: k, sub-pixel deconv: 2); taps are row-major
+    int dil;                    // dilation of a convolution (tap (ky, kx) reads input offset (ky, kx) * dil); 1 for the sub-pixel deconvolution
     int N;                      // output channels
     unsigned zoff1, zoff2;      // LDS-DMA kernel: byte offset of >= 16 zero bytes behind each source (the buffers carry a zeroed tail): padded
                                 // rows are fetched from there, so every lane of a piece shares ONE scalar base (scalar-base addressing mode)
@@ -249,7 +250,7 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
         src = first ? g.src1 : g.src2;
         const int Cs = first ? g.C1 : g.C2;
         const int cil = first ? ci0 : ci0 - g.C1;
-        dy = subpix ? pdy - ky : ky; dx = subpix ? pdx - kx : kx;
+        dy = subpix ? pdy - ky : ky * g.dil; dx = subpix ? pdx - kx : kx * g.dil;
         delta = (dy * g.Wi + dx) * Cs + cil;                    // workgroup-uniform (scalar unit)
         bdelta = (unsigned)((tap * cpt + cib) * 2048);
         amask[set] = 0;
@@ -585,7 +586,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
             const int Cs = c_first ? g.S1 : g.S2;
             int cil = c_first ? ci0 : ci0 - g.C1;
             if (cil >= Cs) cil -= Cs;                  // split-bf16 sources: the third K segment reads the hi half again
-            c_dy = subpix ? pdy - ky : ky; c_dx = subpix ? pdx - kx : kx;
+            c_dy = subpix ? pdy - ky : ky * g.dil; c_dx = subpix ? pdx - kx : kx * g.dil;
             c_delta = (c_dy * g.Wi + c_dx) * Cs + cil;
             c_bdelta = (unsigned)((tap * c32 + cib) * 2048);
             if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
@@ -1501,6 +1502,7 @@ struct RyC1dOsParams {
     float slope;
     int tiles;                  // position tiles per window (one tile = PG x TP rows)
     int kt_waves;
+    int n_real;                 // PADMIN instantiations: real rows per window in `sa`; rows n_real .. Lin - 1 are the per-channel minimum
 };
 
 // Keeps two values in separate registers: without it the compiler rewrites `c ? v[a] : v[b]` on a register array into a
@@ -1538,13 +1540,14 @@ struct RyReduceScatter64<1> {
     }
 };
 
-template <int MODE, int CB, int TP>
+template <int MODE, int CB, int TP, bool PADMIN>
 RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
     constexpr int TPO = MODE == RY_C1D_DECONV ? 2 * TP : TP;                       // outputs per position group
     constexpr int NP = MODE == RY_C1D_S2 ? 2 * TP + 2 : MODE == RY_C1D_DECONV ? TP + 2 : TP + 3;
     constexpr int A = CB * TPO;
     constexpr int LOG2A = A == 32 ? 5 : A == 16 ? 4 : A == 8 ? 3 : A == 4 ? 2 : A == 2 ? 1 : 0;
     static_assert(A <= 32 && (A & (A - 1)) == 0, "at most 32 sums per thread, a power of two");
+    static_assert(!PADMIN || MODE == RY_C1D_S1, "the fused pad is a first-layer (stride-1) feature");
     __shared__ float red[4 * 32];
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = ry_uniform(tid >> 6);
@@ -1555,38 +1558,56 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
     const int b = (int)blockIdx.y / p.tiles, tile = (int)blockIdx.y - b * p.tiles;
     const int r0 = (tile * PG + pg) * TP;                                            // first row of this position group
     const int pos0 = MODE == RY_C1D_S2 ? 2 * r0 - 1 : MODE == RY_C1D_DECONV ? r0 - 1 : r0 - p.pad;
+    // PADMIN (first layer of the convert wrapper): the source holds n_real rows per window and rows n_real .. Lin - 1 are
+    // numpy.pad(mode='minimum'): the per-channel minimum over the real rows, taken here by the workgroups that reach that far
+    const int src_rows = PADMIN ? p.n_real : p.Lin;
+    const bool need_min = PADMIN && pos0 + NP > p.n_real;                            // wave-uniform
 
     float acc[A];
 #pragma unroll
     for (int i = 0; i < A; ++i) acc[i] = 0.f;
-    // one input channel of this lane: its NP input rows and the taps of the CB output channels
-    auto load = [&](int c0, float (&x)[NP], f32x4 (&w)[CB]) {
+    // one input channel of this lane: its NP input rows and the taps of the CB output channels (32-bit offsets: the executor
+    // bounds every activation below 2^31 elements)
+    auto load = [&](int c0, float (&x)[NP], f32x4 (&w)[CB], float& cmin) {
         const bool cok = c0 < Ctot;
         const int ci = cok ? c0 : Ctot - 1;
         const bool fa = ci < p.Ca;
         const float* src = fa ? p.sa : p.sb;
         const int Cs = fa ? p.Ca : p.Cb, cl = fa ? ci : ci - p.Ca;
-        const float* col = src + (size_t)b * (size_t)p.Lin * (size_t)Cs + cl;
+        const float* col = src + (size_t)b * (size_t)src_rows * (size_t)Cs + cl;
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
             const int co = co0 + u < p.N ? co0 + u : p.N - 1;
-            w[u] = ry_ld4(p.w + ((size_t)co * (size_t)Ctot + ci) * 4);
+            w[u] = ry_ld4(p.w + (unsigned)((co * Ctot + ci) * 4));
         }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {                                               // out-of-range rows read row 0; `zero_pad` clears them
+        for (int j = 0; j < NP; ++j) {                                               // out-of-range rows read row 0; `fix` replaces them
             const int pos = pos0 + j;
-            const bool ok = pos >= 0 && pos < p.Lin;
-            x[j] = col[(size_t)(ok ? pos : 0) * (size_t)Cs];
+            const bool ok = pos >= 0 && pos < src_rows;
+            x[j] = col[(unsigned)((ok ? pos : 0) * Cs)];
+        }
+        if (PADMIN) {
+            cmin = INFINITY;
+            if (need_min) {
+                for (int r = 0; r < p.n_real; r += 8) {                              // eight independent loads in flight per round
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = col[(unsigned)((r + u < p.n_real ? r + u : 0) * Cs)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cmin = fminf(cmin, v[u]);
+                }
+            }
         }
     };
     // applied after the scheduling fence, so that no select sits between the loads (the scheduler otherwise waits for the first
     // eight loads before it issues the rest)
-    auto zero_pad = [&](int c0, float (&x)[NP]) {
+    auto fix = [&](int c0, float (&x)[NP], float cmin) {
         const bool cok = c0 < Ctot;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int pos = pos0 + j;
-            x[j] = (cok && pos >= 0 && pos < p.Lin) ? x[j] : 0.f;
+            const bool in = cok && pos >= 0 && pos < p.Lin;
+            x[j] = in ? ((PADMIN && pos >= p.n_real) ? cmin : x[j]) : 0.f;
         }
     };
     auto fma_all = [&](const float (&x)[NP], const f32x4 (&w)[CB]) {
@@ -1605,25 +1626,39 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
             }
         }
     };
-    // the channels of a lane are walked two at a time: both sets of loads are in flight before the first FMA (layers with more
-    // than 256 input channels would otherwise pay one memory round trip per 256 channels)
+    // The channels of a lane are walked up to four at a time: all their loads are in flight before the first FMA, so a layer with
+    // 1024 input channels pays ONE memory round trip, not one per 256 channels.
     const int cstep = ktw * 64;
-    for (int cb0 = kw * 64; cb0 < Ctot; cb0 += 2 * cstep) {                          // wave-uniform
-        float xa[NP], xb[NP];
-        f32x4 wa[CB], wb[CB];
-        if (cb0 + cstep < Ctot) {
-            load(cb0 + lane, xa, wa);
-            load(cb0 + cstep + lane, xb, wb);
+    int cb0 = kw * 64;                                                               // wave-uniform
+    constexpr bool QUAD = (NP + 4 * CB) * 4 + A <= 200;                              // register budget of four sets in flight
+    if (QUAD) {
+        for (; cb0 + 3 * cstep < Ctot; cb0 += 4 * cstep) {
+            float x0[NP], x1[NP], x2[NP], x3[NP], m0, m1, m2, m3;
+            f32x4 w0[CB], w1[CB], w2[CB], w3[CB];
+            load(cb0 + lane, x0, w0, m0); load(cb0 + cstep + lane, x1, w1, m1);
+            load(cb0 + 2 * cstep + lane, x2, w2, m2); load(cb0 + 3 * cstep + lane, x3, w3, m3);
             ry_sched_fence();                                                        // every load is issued before the first FMA
-            zero_pad(cb0 + lane, xa); zero_pad(cb0 + cstep + lane, xb);
-            fma_all(xa, wa);
-            fma_all(xb, wb);
-        } else {
-            load(cb0 + lane, xa, wa);
-            ry_sched_fence();
-            zero_pad(cb0 + lane, xa);
-            fma_all(xa, wa);
+            fix(cb0 + lane, x0, m0); fix(cb0 + cstep + lane, x1, m1); fix(cb0 + 2 * cstep + lane, x2, m2); fix(cb0 + 3 * cstep + lane, x3, m3);
+            fma_all(x0, w0); fma_all(x1, w1); fma_all(x2, w2); fma_all(x3, w3);
         }
+    }
+    for (; cb0 + cstep < Ctot; cb0 += 2 * cstep) {
+        float xa[NP], xb[NP], ma, mb;
+        f32x4 wa[CB], wb[CB];
+        load(cb0 + lane, xa, wa, ma);
+        load(cb0 + cstep + lane, xb, wb, mb);
+        ry_sched_fence();
+        fix(cb0 + lane, xa, ma); fix(cb0 + cstep + lane, xb, mb);
+        fma_all(xa, wa);
+        fma_all(xb, wb);
+    }
+    if (cb0 < Ctot) {
+        float xa[NP], ma;
+        f32x4 wa[CB];
+        load(cb0 + lane, xa, wa, ma);
+        ry_sched_fence();
+        fix(cb0 + lane, xa, ma);
+        fma_all(xa, wa);
     }
     const float tot = RyReduceScatter64<A>::run(acc, lane, 32);
     if ((lane & ((64 >> LOG2A) - 1)) == 0) red[wave * 32 + (lane >> (6 - LOG2A))] = tot;

@@ -287,7 +287,7 @@ static TapTable make_taps(const Layer& l) {
         for (int ky = 0; ky < l.k; ++ky)
             for (int kx = 0; kx < l.k; ++kx) {
                 const int tt = ky * l.k + kx;
-                t.dy[0][tt] = ky; t.dx[0][tt] = kx; t.ky[0][tt] = ky; t.kx[0][tt] = kx;
+                t.dy[0][tt] = ky * l.dil; t.dx[0][tt] = kx * l.dil; t.ky[0][tt] = ky; t.kx[0][tt] = kx;
             }
     }
     return t;
@@ -385,6 +385,7 @@ struct Plan {
     float* x_in = nullptr;                    // padded predictor input
     size_t user_in_floats = 0, user_out_floats = 0;
     bool s1_os = false;                       // stage-1 plan runs the output-stationary kernels (dense activated buffers in lp.out, no slabs)
+    bool s1_padfuse = false;                  // ... and its first layer takes the caller's block and pads it itself (no ry_pad_min_rows node)
     const float* cur_in = nullptr;            // where the forward reads the caller's block (staging, or the caller's device buffer)
     float* cur_out = nullptr;                 // where it writes the result
 #ifndef RY_HOST_EMU
@@ -497,7 +498,7 @@ static void fill_geom(RyConvGeom& g, const Layer& l, const LayerPlan& lp, int B,
     g.B = B; g.Hi = lp.Hi; g.Wi = lp.Wi; g.Ho = lp.Ho; g.Wo = lp.Wo;
     if (l.deconv) { g.Mh = lp.Hi; g.Mw = lp.Wi; g.stride = 1; g.pad = 0; g.ostride = 2; }
     else { g.Mh = lp.Ho; g.Mw = lp.Wo; g.stride = l.stride; g.pad = l.pad; g.ostride = 1; }
-    g.nphases = t.nphases; g.ntaps = t.ntaps; g.N = l.cout; g.kw = l.deconv ? 2 : l.k;
+    g.nphases = t.nphases; g.ntaps = t.ntaps; g.N = l.cout; g.kw = l.deconv ? 2 : l.k; g.dil = l.deconv ? 1 : l.dil;
     const size_t esize = lp.path == PATH_IGEMM_BF16 ? 2 : 4;                  // implicit-GEMM sources end in a zeroed tail (ZTAIL floats)
     g.zoff1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * g.S1 * esize); g.zoff2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * g.S2 * esize);
     for (int ph = 0; ph < 4; ++ph) {
@@ -904,6 +905,7 @@ static int choose_splits_1d(const Layer& l, int B, int rows, int mode) {
 
 
 // ---- stage-1, output-stationary form (ry_c1d_os) ----
+static int g_s1_padfuse = 1;       // RY_S1_PADFUSE=0: separate ry_pad_min_rows node in front of stage 1 (A/B)
 static int g_s1_os = 1;            // RY_S1_OS=0: the round-1 weight-streaming kernels with split-K slabs (A/B)
 static int g_s1_units = 256;       // RY_S1_UNITS: smallest workgroup count a layer should reach before it takes a larger slice per workgroup
 static int g_s1_force[16][2];      // RY_S1_CFG="layer:cb:tp,...": tuning aid, fixes the (output channels, rows) slice of single layers
@@ -934,12 +936,12 @@ static void choose_os(const Layer& l, int B, int rows, int* cb, int* tp) {
 }
 
 static int launch_c1d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int B, const float* sa, int Ca, const float* sb, int Cb,
-                         float* out, int keep, float slope) {
+                         float* out, int keep, float slope, int n_real = 0) {
     RyC1dOsParams p;
     memset(&p, 0, sizeof p);
     p.sa = sa; p.sb = sb; p.Ca = Ca; p.Cb = Cb; p.w = l.w1os; p.scale = l.scale; p.shift = l.shift; p.out = out;
     p.B = B; p.Lin = lp.Wi; p.Lout = lp.Wo; p.N = l.cout; p.keep = keep; p.pad = l.pad; p.act = l.act; p.slope = slope;
-    p.kt_waves = lp.os_kt;
+    p.kt_waves = lp.os_kt; p.n_real = n_real;
     const int mode = c1d_mode(l);
     const int rows = mode == RY_C1D_DECONV ? lp.Wi : lp.Wo;
     const int PG = 4 / lp.os_kt;
@@ -947,15 +949,18 @@ static int launch_c1d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     dim3 grid((unsigned)((l.cout + lp.os_cb - 1) / lp.os_cb), (unsigned)(B * p.tiles));
     if (grid.y > 65535u) return fail(RY_EINVAL, "%s: batch*tiles = %u exceeds the grid limit", l.name, grid.y);
     char nm[48];
-    snprintf(nm, sizeof nm, "ry_c1d_os<%d,%d,%d>", mode, lp.os_cb, lp.os_tp);        // as rocprofv3 prints it (MODE: 0 = k4 s2 conv, 1 = stride-1 conv, 2 = k4 s2 deconv)
+    snprintf(nm, sizeof nm, "ry_c1d_os<%d,%d,%d,%s>", mode, lp.os_cb, lp.os_tp, n_real > 0 ? "true" : "false");   // as rocprofv3 prints it (MODE: 0 = k4 s2 conv, 1 = stride-1 conv, 2 = k4 s2 deconv)
     RY_TRY(Lc.begin(nm, l.name, lp.flops, lp.bytes, grid));
-#define RY_OS_CASE(MODE_, CB_, TP_) if (lp.os_cb == CB_ && lp.os_tp == TP_) { RY_LAUNCH((ry_c1d_os<MODE_, CB_, TP_>), grid, 256, Lc.stream, p); } else
+#define RY_OS_CASE(MODE_, CB_, TP_) if (lp.os_cb == CB_ && lp.os_tp == TP_) { RY_LAUNCH((ry_c1d_os<MODE_, CB_, TP_, false>), grid, 256, Lc.stream, p); } else
+#define RY_OS_CASE_PM(CB_, TP_) if (n_real > 0 && lp.os_cb == CB_ && lp.os_tp == TP_) { RY_LAUNCH((ry_c1d_os<RY_C1D_S1, CB_, TP_, true>), grid, 256, Lc.stream, p); } else
     switch (mode) {
         case RY_C1D_S2:
             RY_OS_CASE(RY_C1D_S2, 4, 8) RY_OS_CASE(RY_C1D_S2, 4, 4) RY_OS_CASE(RY_C1D_S2, 2, 8) RY_OS_CASE(RY_C1D_S2, 2, 4)
             return fail(RY_EINVAL, "%s: no ry_c1d_os instantiation for slice %dx%d", l.name, lp.os_cb, lp.os_tp);
             break;
         case RY_C1D_S1:
+            if (n_real > 0 && mode != RY_C1D_S1) return fail(RY_EINVAL, "%s: the fused pad needs a stride-1 first layer", l.name);
+            RY_OS_CASE_PM(4, 8) RY_OS_CASE_PM(4, 4) RY_OS_CASE_PM(2, 8) RY_OS_CASE_PM(2, 4)
             RY_OS_CASE(RY_C1D_S1, 4, 8) RY_OS_CASE(RY_C1D_S1, 4, 4) RY_OS_CASE(RY_C1D_S1, 2, 8) RY_OS_CASE(RY_C1D_S1, 2, 4)
             return fail(RY_EINVAL, "%s: no ry_c1d_os instantiation for slice %dx%d", l.name, lp.os_cb, lp.os_tp);
             break;
@@ -965,6 +970,7 @@ static int launch_c1d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             break;
     }
 #undef RY_OS_CASE
+#undef RY_OS_CASE_PM
     return Lc.end();
 }
 
@@ -1006,6 +1012,8 @@ static int build_plan(ry_net* net, Plan& P) {
     if (nd == 1) {
         P.s1_os = g_s1_os != 0;
         for (int i = 0; i < 16; ++i) if (!c1d_os_capable(net->layers[i]) || !net->layers[i].w1os) P.s1_os = false;
+        // the pad of the convert wrapper inside the first layer: a stride-1 first layer whose input channels fit one lane set
+        P.s1_padfuse = P.s1_os && g_s1_padfuse && P.mode == 1 && c1d_mode(net->layers[0]) == RY_C1D_S1 && net->layers[0].cin() <= 64;
     }
     for (int i = 0; i < 16; ++i) {
         const Layer& l = net->layers[i];
@@ -1139,7 +1147,10 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
     const ry_net_desc& d = net->desc;
     const int nd = d.ndim, B = P.B;
     const float slope = d.lrelu_slope;
-    if (P.mode == 1) {
+    // the fused pad takes the column minimum inside the workgroups that reach the padding: one chain of n_frames / 8 load rounds, worth
+    // it while the window is short (measured: 300 frames -3 us, 1000 frames +14 us against the separate ry_pad_min_rows node)
+    const bool padfuse_now = nd == 1 && P.s1_padfuse && P.n_frames <= 512;
+    if (P.mode == 1 && !padfuse_now) {
         const int cols_in = nd == 1 ? d.in_ch : d.width + 1;
         const int cols_out = nd == 1 ? d.in_ch : d.width;
         // numpy.pad(mode='minimum') over time (+ log and the dropped last bin for stage 2): column minima and the padded
@@ -1158,10 +1169,11 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
         const Layer& l = net->layers[i];
         const LayerPlan& lp = P.lp[i];
         if (nd == 1 && P.s1_os) {
-            const float* sa = l.src_a < 0 ? (P.mode == 1 ? P.x_in : P.cur_in) : P.lp[l.src_a].out;
+            const bool fused_pad = l.src_a < 0 && padfuse_now;
+            const float* sa = l.src_a < 0 ? ((P.mode == 1 && !padfuse_now) ? P.x_in : P.cur_in) : P.lp[l.src_a].out;
             const float* sb = l.src_b < 0 ? nullptr : P.lp[l.src_b].out;
             const int keep = (i == 15 && P.mode == 1) ? P.n_frames : lp.Wo;      // the last layer crops to the real frames as it stores
-            RY_TRY(launch_c1d_os(Lc, l, lp, B, sa, l.cin_a, sb, l.cin_b, i == 15 ? P.cur_out : lp.out, keep, slope));
+            RY_TRY(launch_c1d_os(Lc, l, lp, B, sa, l.cin_a, sb, l.cin_b, i == 15 ? P.cur_out : lp.out, keep, slope, fused_pad ? P.n_frames : 0));
         } else if (nd == 1) {
             RY_TRY(launch_conv1d(Lc, l, lp, B, src1d_of(net, P, l.src_a), src1d_of(net, P, l.src_b), slope));
         } else {
@@ -1319,7 +1331,7 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
     Plan::GraphSlot* G = nullptr;
     for (Plan::GraphSlot& g : P.gslots) if (g.in == want_in && g.out == want_out) G = &g;
     if (!G) {
-        if (P.gslots.size() >= 8) {                       // bounded: evict the least recently used pair (its exec may be in flight: drain first)
+        if (P.gslots.size() >= 64) {                      // bounded: evict the least recently used pair (its exec may be in flight: drain first)
             size_t lru = 0;
             for (size_t i = 1; i < P.gslots.size(); ++i) if (P.gslots[i].used < P.gslots[lru].used) lru = i;
             RT_TRY(rt::stream_sync(net->stream));
@@ -1419,6 +1431,7 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_XCD_GROUPS")) g_xcd_groups = atoi(e);
     if (const char* e = getenv("RY_LAST_BAND")) g_last_band = atoi(e);
     if (const char* e = getenv("RY_S1_OS")) g_s1_os = atoi(e);
+    if (const char* e = getenv("RY_S1_PADFUSE")) g_s1_padfuse = atoi(e);
     if (const char* e = getenv("RY_S1_UNITS")) g_s1_units = atoi(e) > 0 ? atoi(e) : 1;
     memset(g_s1_force, 0, sizeof(g_s1_force));
     if (const char* e = getenv("RY_S1_CFG")) {
@@ -2427,24 +2440,31 @@ int ry_conv1d(ry_ctx* ctx, const float* x, int B, int L, int Cin, const float* W
 
 int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const float* Wt, const float* bias, const float* bn,
               int Cout, int k, int stride, int pad, int transposed, int act, int path, int tile, int splits, float* y) {
+    return ry_conv2d_dilated(ctx, x, B, H, Wd, Cin, Wt, bias, bn, Cout, k, stride, pad, 1, transposed, act, path, tile, splits, y);
+}
+
+int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin, const float* Wt, const float* bias, const float* bn,
+                      int Cout, int k, int stride, int pad, int dilate, int transposed, int act, int path, int tile, int splits, float* y) {
     if (!ctx || !x || !Wt || !y) return fail(RY_EINVAL, "null argument");
     if (B < 1 || H < 1 || Wd < 1 || Cin < 1 || Cout < 1 || k < 1 || k > 4 || stride < 1 || pad < 0) return fail(RY_EINVAL, "bad conv2d shape");
+    if (dilate < 1 || dilate * (k - 1) > 127) return fail(RY_EINVAL, "dilation %d is out of range", dilate);
+    if (dilate != 1 && (transposed || path == PATH_FIRST || path == PATH_LAST)) return fail(RY_EINVAL, "dilation applies to the plain convolution (implicit-GEMM or direct path)");
     if (transposed && !(k == 4 && stride == 2 && pad == 1)) return fail(RY_EINVAL, "transposed conv2d supports k4 s2 p1 only");
     if (act == RY_ACT_GLU) return fail(RY_EINVAL, "GLU is a stage-1 (1-D) epilogue");
     RT_TRY(rt::set_device(ctx->device));
     Layer l;
     snprintf(l.name, sizeof l.name, "conv2d");
-    l.deconv = transposed != 0; l.bn = bn != nullptr; l.k = k; l.stride = stride; l.pad = pad;
+    l.deconv = transposed != 0; l.bn = bn != nullptr; l.k = k; l.stride = stride; l.pad = pad; l.dil = dilate;
     l.cin_a = Cin; l.cout = Cout; l.act = act;
     Arena arena;
     RY_TRY(prepare_layer(ctx, arena, l, 2, 2e-5f, Wt, bias, bn));
     LayerPlan lp;
     lp.Hi = H; lp.Wi = Wd;
-    lp.Ho = transposed ? 2 * H : (H + 2 * pad - k) / stride + 1;
-    lp.Wo = transposed ? 2 * Wd : (Wd + 2 * pad - k) / stride + 1;
+    lp.Ho = transposed ? 2 * H : (H + 2 * pad - dilate * (k - 1) - 1) / stride + 1;
+    lp.Wo = transposed ? 2 * Wd : (Wd + 2 * pad - dilate * (k - 1) - 1) / stride + 1;
     if (lp.Ho < 1 || lp.Wo < 1) return fail(RY_EINVAL, "conv2d output would be empty");
     if (path == PATH_IGEMM && !l.wig) return fail(RY_EINVAL, "implicit-GEMM path needs Cin %% 32 == 0 and Cout %% 64 == 0");
-    const bool k3 = !transposed && k == 3 && stride == 1 && pad == 1;
+    const bool k3 = !transposed && k == 3 && stride == 1 && pad == 1 && dilate == 1;
     if (path == PATH_FIRST && !(k3 && Cin == 1 && Cout % 4 == 0)) return fail(RY_EINVAL, "'first' path is the 1 -> N (N %% 4 == 0) 3x3 layer");
     if (path == PATH_LAST && !(k3 && Cout == 1 && Cin % 128 == 0)) return fail(RY_EINVAL, "'last' path is the C -> 1 (C %% 128 == 0) 3x3 layer");
     if ((path == PATH_IGEMM_BF16 || path == PATH_IGEMM_X3) && !(l.wig && Cin % 64 == 0)) return fail(RY_EINVAL, "bf16 implicit-GEMM path needs Cin %% 64 == 0 and Cout %% 64 == 0");

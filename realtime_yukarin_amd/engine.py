@@ -92,22 +92,22 @@ class Context(object):
                                               Cout, k, stride, pad, dilate, int(bool(transposed)), a, int(splits), _lib._fptr(y)))
         return y
 
-    def conv2d(self, x, W, b=None, bn=None, stride=1, pad=0, transposed=False, act=None, path='auto', tile=None, splits=0):
+    def conv2d(self, x, W, b=None, bn=None, stride=1, pad=0, transposed=False, act=None, path='auto', tile=None, splits=0, dilate=1):
         """x (B, H, W, Cin) -> (B, Ho, Wo, Cout).  W (Cout,Cin,k,k) or transposed (Cin,Cout,k,k)."""
         x = numpy.ascontiguousarray(x, dtype=numpy.float32)
         W = numpy.ascontiguousarray(W, dtype=numpy.float32)
         B, H, Wd, Cin = x.shape
         Cout = W.shape[1] if transposed else W.shape[0]
         k = W.shape[2]
-        Ho = 2 * H if transposed else (H + 2 * pad - k) // stride + 1
-        Wo = 2 * Wd if transposed else (Wd + 2 * pad - k) // stride + 1
+        Ho = 2 * H if transposed else (H + 2 * pad - dilate * (k - 1) - 1) // stride + 1
+        Wo = 2 * Wd if transposed else (Wd + 2 * pad - dilate * (k - 1) - 1) // stride + 1
         y = numpy.empty((B, max(Ho, 0), max(Wo, 0), Cout), dtype=numpy.float32)
         bnv = None if bn is None else numpy.ascontiguousarray(numpy.concatenate([numpy.ravel(v) for v in bn]), dtype=numpy.float32)
         bv = None if b is None else numpy.ascontiguousarray(b, dtype=numpy.float32)
         pth = {'auto': 0, 'igemm': 1, 'direct': 2, 'first': 3, 'last': 4, 'igemm_bf16': 5, 'igemm_x3': 6}[path]
-        self.lib.check(self.lib.dll.ry_conv2d(self.handle, _lib._fptr(x), B, H, Wd, Cin, _lib._fptr(W), _lib._fptr(bv), _lib._fptr(bnv),
-                                              Cout, k, stride, pad, int(bool(transposed)), _lib.ACTS[act], pth, _lib.TILES[tile],
-                                              int(splits), _lib._fptr(y)))
+        self.lib.check(self.lib.dll.ry_conv2d_dilated(self.handle, _lib._fptr(x), B, H, Wd, Cin, _lib._fptr(W), _lib._fptr(bv), _lib._fptr(bnv),
+                                                      Cout, k, stride, pad, int(dilate), int(bool(transposed)), _lib.ACTS[act], pth, _lib.TILES[tile],
+                                                      int(splits), _lib._fptr(y)))
         return y
 
 

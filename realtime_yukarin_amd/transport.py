@@ -36,6 +36,24 @@ def _round_up(n: int) -> int:
     return (n + ALIGN - 1) // ALIGN * ALIGN
 
 
+def _attach(name: str) -> shared_memory.SharedMemory:
+    """Attach to the creator's block WITHOUT registering it with the resource tracker.  Before Python 3.13 an attach registers the
+    name as if this process had created it, so the tracker would unlink the block when the attaching process exits.  Unregistering
+    afterwards is no cure: fork / spawn children share the creator's tracker process, whose registry is a set, so the child's
+    unregister also drops the CREATOR's entry and the creator's own `unlink()` then trips a KeyError inside the tracker.  Only the
+    creating process owns the name; attaching leaves the registry alone."""
+    try:
+        return shared_memory.SharedMemory(name=name, track=False)            # Python >= 3.13
+    except TypeError:
+        pass
+    real = resource_tracker.register
+    resource_tracker.register = lambda *a, **k: None
+    try:
+        return shared_memory.SharedMemory(name=name)
+    finally:
+        resource_tracker.register = real
+
+
 class FeatureQueue(object):
     def __init__(self, slots: int = 8, slot_bytes: int = 16 << 20, ctx=None) -> None:
         if slots < 1 or slot_bytes < 4096:
@@ -62,10 +80,7 @@ class FeatureQueue(object):
         self.slots, self.slot_bytes, self._owner = s['slots'], s['slot_bytes'], s['owner']
         self._free, self._filled, self._put_lock, self._get_lock = s['free'], s['filled'], s['put_lock'], s['get_lock']
         self._head, self._tail = s['head'], s['tail']
-        self._shm = shared_memory.SharedMemory(name=s['name'])
-        # Python 3.10 registers attached blocks with the resource tracker too and would unlink the creator's block when
-        # this process exits; only the creating process owns the name.
-        resource_tracker.unregister(self._shm._name, 'shared_memory')
+        self._shm = _attach(s['name'])
 
     # ---- producer ---------------------------------------------------------------------------------------------------
     def put(self, obj, block: bool = True, timeout=None) -> None:

@@ -50,30 +50,47 @@ class VoiceChanger(object):
         self._core, self._core_pid = None, None
 
     def convert_from_acoustic_feature(self, f_in):
+        return self.finish(self.begin(f_in))
+
+    # ---- the same call in two halves: `begin` queues the window on the GPU and returns at once (up to three windows may be in flight,
+    # `ry_vc_submit` / `ry_vc_submit_wave`), `finish` waits for it and assembles the output feature.  `worker.convert_worker` uses the
+    # pair to keep a backlog of windows pipelined: H2D of window i + 1 and D2H of window i - 1 run under the kernels of window i.
+    def begin(self, f_in):
         core = self._fused_core()
-        if core is None:                       # generic path: the reference's step order, one call per step
+        if core is None:                       # generic path: the reference's step order, one call per step (nothing to overlap)
             f_out = self._stage1(f_in)
             f_out.sp = self.super_resolution.convert(f_out.sp.astype(numpy.float32))
-            return f_out
+            return ('done', f_out)
         # device-resident path: everything in one window call.  The silence gate runs on the device too (ry_vc_submit_wave) when it
         # can restate the host arithmetic bit for bit (float32 wave, absolute reference, power-of-two frame length); otherwise the
-        # mask is taken on the host (it reads the raw wave) and only the effective rows go up (ry_vc_convert).
+        # mask is taken on the host (it reads the raw wave) and only the effective rows go up (ry_vc_submit).
         ac = self.acoustic_converter
         from . import gate
         from yukarin.wave import default_effective_ref
         param = ac.config.dataset.acoustic_param
         wave = f_in.wave
         thr = self.threshold if self.threshold is not None else param.threshold_db
-        n = len(f_in.f0)
         w = numpy.asarray(wave.wave)
         if os.environ.get('RY_DEVICE_GATE', '1') != '0' and gate.device_gate_usable(w, param.fft_length, thr, default_effective_ref()):
             hop, _ = wave.get_hop_and_length(param.frame_period)
             p_eff, p_all = gate.thresholds(thr)
-            mc, sp, effective = core.wait_wave(core.submit_wave(w, hop, param.fft_length, p_eff, p_all, numpy.asarray(f_in.mc, dtype=numpy.float32), SP_FLOOR))
+            t = core.submit_wave(w, hop, param.fft_length, p_eff, p_all, numpy.asarray(f_in.mc, dtype=numpy.float32), SP_FLOOR)
+            return ('wave', core, t, f_in)
+        f_eff, effective = ac.separate_effective(wave=wave, feature=f_in, threshold=self.threshold)
+        t = core.submit(numpy.asarray(f_eff.mc, dtype=numpy.float32), effective, SP_FLOOR)
+        return ('host', core, t, f_eff, effective)
+
+    def finish(self, handle):
+        if handle[0] == 'done':
+            return handle[1]
+        ac = self.acoustic_converter
+        if handle[0] == 'wave':
+            _, core, t, f_in = handle
+            mc, sp, effective = core.wait_wave(t)
             f_eff = f_in.indexing(effective)
         else:
-            f_eff, effective = ac.separate_effective(wave=wave, feature=f_in, threshold=self.threshold)
-            mc, sp = core.convert(numpy.asarray(f_eff.mc, dtype=numpy.float32), effective, SP_FLOOR)
+            _, core, t, f_eff, effective = handle
+            mc, sp = core.wait(t)
         f_out = ac.combine_silent(effective=effective, feature=self._passthrough(f_eff))
         f_out.mc = mc
         f_out.sp = sp

@@ -72,6 +72,28 @@ CONV2D_CASES = [
 ]
 
 
+# 2-D dilated convolution (north_star operator coverage: "1-D/2-D dilated conv"): B, H, W, Cin, Cout, k, stride, pad, dilate, act, path, tile, splits
+CONV2D_DILATED_CASES = [
+    (1, 12, 16, 32, 128, 3, 1, 2, 2, 'lrelu', 'igemm', '32x128', 0),       # 'same' 3x3 with dilation 2 on the MFMA path
+    (2, 10, 14, 64, 128, 3, 1, 3, 3, 'relu', 'igemm', '64x128', 2),        # dilation 3, batch 2, split-K
+    (1, 16, 20, 32, 64, 4, 2, 3, 2, None, 'igemm', '128x64', 1),           # k4 s2 with dilation 2 (the gather variant: no input patches)
+    (1, 9, 11, 8, 12, 3, 1, 2, 2, 'lrelu', 'direct', None, 0),             # odd channel counts: the direct path
+    (1, 7, 9, 5, 6, 2, 1, 0, 4, None, 'direct', None, 0),                  # k2, dilation 4, no padding
+]
+
+
+def run_conv2d_dilated(ctx, rng, case, bn_params):
+    B, H, W_, Cin, Cout, k, s, p, d, act, path, tile, splits = case
+    x = rng.normal(size=(B, H, W_, Cin)).astype('f4')
+    Wt = rng.normal(0, 0.1, size=(Cout, Cin, k, k)).astype('f4')
+    b = rng.normal(0, 0.1, Cout).astype('f4')
+    bn = bn_params(rng, Cout)
+    y = ctx.conv2d(x, Wt, b, bn, stride=s, pad=p, dilate=d, act=act, path=path, tile=tile, splits=splits)
+    r = ops.conv_nd(x.transpose(0, 3, 1, 2), Wt, b, stride=s, pad=p, dilate=d)
+    r = ops.apply_act(ops.batch_norm_inference(r, *bn), act).transpose(0, 2, 3, 1)
+    return y, r
+
+
 def bf16_round(a):
     """float32 -> nearest-even bfloat16 -> float32 (what v_cvt_pk_bf16_f32 does to the operands of the bf16 kernel)."""
     u = numpy.ascontiguousarray(a, dtype=numpy.float32).view(numpy.uint32).astype(numpy.uint64)

@@ -30,6 +30,12 @@ def test_conv2d_gpu(gpu_ctx, case):
     assert rel_max(y, r) < cases.TOL
 
 
+@pytest.mark.parametrize('case', cases.CONV2D_DILATED_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_dilated_gpu(gpu_ctx, case):
+    y, r = cases.run_conv2d_dilated(gpu_ctx, numpy.random.default_rng(19), case, bn_params)
+    assert y.shape == r.shape and rel_max(y, r) < cases.TOL
+
+
 @pytest.mark.parametrize('case', cases.CONV2D_BF16_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
 def test_conv2d_bf16_gpu(gpu_ctx, case):
     """bf16-operand MFMA (BASELINE config #5): exact up to fp32 accumulation order against the oracle run on bf16-rounded

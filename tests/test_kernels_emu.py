@@ -26,6 +26,12 @@ def test_conv2d_emu(emu_ctx, case):
     assert rel_max(y, r) < cases.TOL
 
 
+@pytest.mark.parametrize('case', cases.CONV2D_DILATED_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_dilated_emu(emu_ctx, case):
+    y, r = cases.run_conv2d_dilated(emu_ctx, numpy.random.default_rng(19), case, bn_params)
+    assert y.shape == r.shape and rel_max(y, r) < cases.TOL
+
+
 @pytest.mark.parametrize('case', cases.CONV2D_BF16_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
 def test_conv2d_bf16_emu(emu_ctx, case):
     y, r16, r32 = cases.run_conv2d_bf16(emu_ctx, numpy.random.default_rng(16), case, bn_params)

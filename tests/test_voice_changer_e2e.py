@@ -320,5 +320,31 @@ def test_convert_worker_mirror_matches_the_reference_loop_and_stays_bounded(mode
     assert not t.is_alive() and not lock.locked()
     assert seen['segments'] <= 3                                              # bounded by the overlap, not by the run length
     q_in.close(); q_out.close()
+    # a backlog of items: the worker keeps two windows in flight (VoiceChanger.begin / finish) and still returns the same windows in order
+    from realtime_yukarin_amd.voice_changer import VoiceChanger as MirrorVC
+    flight = {'now': 0, 'max': 0}
+    real_begin, real_finish = MirrorVC.begin, MirrorVC.finish
+
+    def begin(self, f):
+        flight['now'] += 1; flight['max'] = max(flight['max'], flight['now'])
+        return real_begin(self, f)
+
+    def finish(self, h):
+        flight['now'] -= 1
+        return real_finish(self, h)
+    monkeypatch.setattr(MirrorVC, 'begin', begin); monkeypatch.setattr(MirrorVC, 'finish', finish)
+    q_in, q_out = FeatureQueue(slots=8, slot_bytes=4 << 20), FeatureQueue(slots=8, slot_bytes=4 << 20)
+    for i, f in enumerate(inputs):
+        q_in.put(util.Item(item=f, index=i))
+    q_in.put(None)
+    lock2 = threading.Lock(); lock2.acquire()
+    t2 = threading.Thread(target=worker.convert_worker, args=(ac, sr, time_length, extra_time, 60, q_in, q_out, lock2), daemon=True)
+    t2.start()
+    for i in range(n_items):
+        got = q_out.get(timeout=300)
+        assert got.index == i and float(numpy.abs(got.item.sp / want[i].sp - 1).max()) < 2e-5 and numpy.array_equal(got.item.f0, want[i].f0)
+    t2.join(timeout=30)
+    assert not t2.is_alive() and flight['max'] == 2 and flight['now'] == 0
+    q_in.close(); q_out.close()
     for m in [k for k in sys.modules if k.startswith('realtime_voice_conversion')]:
         sys.modules.pop(m)
