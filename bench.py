@@ -92,6 +92,8 @@ def pmc_table():
 
 def main(argv=None):
     args = parse(argv)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC for RCCL / device-buffer sharing: before the HIP runtime comes up
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

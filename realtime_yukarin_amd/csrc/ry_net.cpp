@@ -392,10 +392,10 @@ struct Plan {
     // one captured graph per (input, output) address pair the plan has been run with: host callers (plan staging), device callers
     // and the ring slots of ry_vc each keep their own, so switching between them neither re-captures nor destroys an exec that
     // may still be in flight
-    struct GraphSlot { const float* in; float* out; hipGraphExec_t gexec; bool tried; int graph_n, last_n; unsigned long long used; };
+    struct GraphSlot { const float* in; float* out; hipGraphExec_t gexec; hipGraphExec_t gexec2; bool tried; int graph_n, last_n; unsigned long long used; };
     std::vector<GraphSlot> gslots;
     unsigned long long gclock = 0;
-    ~Plan() { for (GraphSlot& g : gslots) if (g.gexec) hipGraphExecDestroy(g.gexec); }
+    ~Plan() { for (GraphSlot& g : gslots) { if (g.gexec) hipGraphExecDestroy(g.gexec); if (g.gexec2) hipGraphExecDestroy(g.gexec2); } }
 #endif
 };
 
@@ -412,6 +412,9 @@ struct ry_net {
     ry_stream_t stream = nullptr;            // each predictor enqueues on its own stream: stage-1 of one window overlaps stage-2 of another
     rt::Event done;                          // recorded after the last enqueue; ry_sync / ry_timer_stop wait on it
     bool has_done = false;
+    int split_at = 0;                        // > 0 (stage 2): the forward runs as two graphs, layers [0, split_at) and the rest, with `mid` recorded between them
+    rt::Event mid;                           // ... so that the NEXT window's stage 1 can be timed to run under the weight-streaming layers at the bottom of the U-Net
+    bool mid_recorded = false;
     ry_net_desc desc;
     std::vector<Layer> layers;
     Arena weights;
@@ -520,6 +523,7 @@ static void tile_dims(int tile, int* bm, int* bn) {
 }
 
 
+static int g_vc_stagger = 1;  // RY_VC_STAGGER=0: stage 1 of the next window starts at once instead of under the bottom layers of the previous window's stage 2
 static int g_last_band = 1;   // RY_LAST_BAND=0: raster-order workgroups in ry_sr_last (A/B of the per-XCD row bands)
 static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
@@ -1143,14 +1147,16 @@ static RySrc1d src1d_of(const ry_net* net, const Plan& P, int idx) {
 }
 
 // enqueue the whole forward of a plan (wrapper kernels included when mode == 1)
-static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
+// part 0: the whole forward; 1: the wrapper pad and layers [0, net->split_at); 2: layers [net->split_at, 16) and the tail wrappers
+static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
     const ry_net_desc& d = net->desc;
+    const int lo = part == 2 ? net->split_at : 0, hi = part == 1 ? net->split_at : 16;
     const int nd = d.ndim, B = P.B;
     const float slope = d.lrelu_slope;
     // the fused pad takes the column minimum inside the workgroups that reach the padding: one chain of n_frames / 8 load rounds, worth
     // it while the window is short (measured: 300 frames -3 us, 1000 frames +14 us against the separate ry_pad_min_rows node)
     const bool padfuse_now = nd == 1 && P.s1_padfuse && P.n_frames <= 512;
-    if (P.mode == 1 && !padfuse_now) {
+    if (P.mode == 1 && !padfuse_now && part != 2) {
         const int cols_in = nd == 1 ? d.in_ch : d.width + 1;
         const int cols_out = nd == 1 ? d.in_ch : d.width;
         // numpy.pad(mode='minimum') over time (+ log and the dropped last bin for stage 2): column minima and the padded
@@ -1165,7 +1171,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
         else RY_LAUNCH(ry_pad_min_rows<16>, pg, 256, Lc.stream, q);
         RY_TRY(Lc.end());
     }
-    for (int i = 0; i < 16; ++i) {
+    for (int i = lo; i < hi; ++i) {
         const Layer& l = net->layers[i];
         const LayerPlan& lp = P.lp[i];
         if (nd == 1 && P.s1_os) {
@@ -1187,6 +1193,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
             RY_TRY(launch_conv2d(Lc, l, lq, B, s1, l.cin_a, s2, l.cin_b, slope));
         }
     }
+    if (part == 1) return RY_OK;
     if (nd == 1 && P.s1_os) {
         // nothing left to do: decoder c7 wrote the cropped, dense result
     } else if (nd == 1) {
@@ -1336,9 +1343,10 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
             for (size_t i = 1; i < P.gslots.size(); ++i) if (P.gslots[i].used < P.gslots[lru].used) lru = i;
             RT_TRY(rt::stream_sync(net->stream));
             if (P.gslots[lru].gexec) hipGraphExecDestroy(P.gslots[lru].gexec);
+            if (P.gslots[lru].gexec2) hipGraphExecDestroy(P.gslots[lru].gexec2);
             P.gslots.erase(P.gslots.begin() + (long)lru);
         }
-        P.gslots.push_back(Plan::GraphSlot{want_in, want_out, nullptr, false, -1, -1, 0});
+        P.gslots.push_back(Plan::GraphSlot{want_in, want_out, nullptr, nullptr, false, -1, -1, 0});
         G = &P.gslots.back();
     }
     G->used = ++P.gclock;
@@ -1347,30 +1355,50 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
     if (G->gexec && G->graph_n != P.n_frames && G->last_n == P.n_frames) {
         RT_TRY(rt::stream_sync(net->stream));             // the exec being replaced may still be running
         hipGraphExecDestroy(G->gexec); G->gexec = nullptr; G->tried = false;
+        if (G->gexec2) { hipGraphExecDestroy(G->gexec2); G->gexec2 = nullptr; }
     }
     const bool capture_now = net->use_graph && !G->tried && (P.mode == 0 || G->last_n == P.n_frames || G->last_n < 0);
     G->last_n = P.n_frames;
-    if (capture_now) {
-        G->tried = true;
-        G->graph_n = P.n_frames;
+    const bool split = net->split_at > 0 && net->split_at < 16;
+    auto capture = [&](int part, hipGraphExec_t* ex) -> int {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(net->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            int r = enqueue_forward(net, P, Lc);
+            int r = enqueue_forward(net, P, Lc, part);
             hipError_t e = hipStreamEndCapture(net->stream, &graph);
             if (r == RY_OK && e == hipSuccess && graph) {
-                if (hipGraphInstantiate(&G->gexec, graph, nullptr, nullptr, 0) != hipSuccess) G->gexec = nullptr;
+                if (hipGraphInstantiate(ex, graph, nullptr, nullptr, 0) != hipSuccess) *ex = nullptr;
             }
             if (graph) hipGraphDestroy(graph);
             (void)hipGetLastError();
             if (r != RY_OK) return r;
         }
+        return RY_OK;
+    };
+    if (capture_now) {
+        G->tried = true;
+        G->graph_n = P.n_frames;
+        RY_TRY(capture(split ? 1 : 0, &G->gexec));
+        if (split && G->gexec) {
+            RY_TRY(capture(2, &G->gexec2));
+            if (!G->gexec2) { hipGraphExecDestroy(G->gexec); G->gexec = nullptr; }
+        }
     }
     if (G->gexec && G->graph_n == P.n_frames) {
         RT_TRY(hipGraphLaunch(G->gexec, net->stream));
+        if (split) {
+            RT_TRY(rt::event_record(net->mid, net->stream)); net->mid_recorded = true;
+            RT_TRY(hipGraphLaunch(G->gexec2, net->stream));
+        }
     } else
 #endif
     {
-        RY_TRY(enqueue_forward(net, P, Lc));
+        if (net->split_at > 0 && net->split_at < 16) {
+            RY_TRY(enqueue_forward(net, P, Lc, 1));
+            RT_TRY(rt::event_record(net->mid, net->stream)); net->mid_recorded = true;
+            RY_TRY(enqueue_forward(net, P, Lc, 2));
+        } else {
+            RY_TRY(enqueue_forward(net, P, Lc));
+        }
     }
     if (!on_device) {
         RT_TRY(rt::d2h(y, P.user_out, out_bytes, net->stream));
@@ -1430,6 +1458,7 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_PLAN_X3_KG2")) g_x3_kg2 = atof(e);
     if (const char* e = getenv("RY_XCD_GROUPS")) g_xcd_groups = atoi(e);
     if (const char* e = getenv("RY_LAST_BAND")) g_last_band = atoi(e);
+    if (const char* e = getenv("RY_VC_STAGGER")) g_vc_stagger = atoi(e);
     if (const char* e = getenv("RY_S1_OS")) g_s1_os = atoi(e);
     if (const char* e = getenv("RY_S1_PADFUSE")) g_s1_padfuse = atoi(e);
     if (const char* e = getenv("RY_S1_UNITS")) g_s1_units = atoi(e) > 0 ? atoi(e) : 1;
@@ -1542,7 +1571,13 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
     if (const char* e = getenv("RY_GRAPH")) net->use_graph = atoi(e) != 0;
     RT_TRY(rt::stream_create(&net->stream));
     RT_TRY(rt::event_create(&net->done));
+    RT_TRY(rt::event_create_fast(&net->mid));
     net->has_done = true;
+    // RY_S2_SPLIT=5 (off by default): stage 2 as two graphs cut after encoder c4 with an event between them, so that stage 1 of the next
+    // window can be held back (RY_VC_STAGGER) until the six weight-streaming layers at the bottom of the U-Net run.  Measured on one box,
+    // interleaved: 1.3477 ms per step with the cut and the stagger, 1.3477 without either, 1.3544 with the cut alone (the second graph
+    // launch costs ~5 us and the stagger only wins it back): the ~30 us a step takes beyond stage 2 alone is not stage-1 interference.
+    if (desc->ndim == 2) { net->split_at = 0; if (const char* e = getenv("RY_S2_SPLIT")) net->split_at = atoi(e); }
     size_t off = 0;
     for (Layer& l : net->layers) {
         const size_t nw = (size_t)l.cin() * l.cout * ipow((size_t)l.k, desc->ndim);
@@ -1566,7 +1601,7 @@ void ry_net_destroy(ry_net* net) {
     for (size_t i = 0; i < v.size(); ++i)
         if (v[i] == net) { v.erase(v.begin() + i); break; }
     net->plans.clear();
-    if (net->has_done) rt::event_destroy(net->done);
+    if (net->has_done) { rt::event_destroy(net->done); rt::event_destroy(net->mid); }
     rt::stream_destroy(net->stream);
     delete net;
 }
@@ -1834,6 +1869,14 @@ static int vc_enqueue_mid(ry_vc* vc, const float* y1, const int* row_of, int n_e
     return RY_OK;
 }
 
+// Stage 1 of a window is timed to start when the PREVIOUS window's stage 2 has finished its large encoder layers (ry_net::mid):
+// it then runs under the six weight-streaming layers at the bottom of the U-Net, which leave most of the chip idle, instead of
+// taking workgroup slots from the one-round grids of the MFMA-bound layers.
+static int vc_stagger(ry_vc* vc) {
+    if (g_vc_stagger && vc->s2->mid_recorded) RT_TRY(rt::stream_wait_event(vc->s1->stream, vc->s2->mid));
+    return RY_OK;
+}
+
 static int vc_check(const ry_vc* vc, const int* row_of, int n_eff, int n_frames, bool host_rows) {
     if (!vc) return fail(RY_EINVAL, "null argument");
     if (n_frames < 1 || n_eff < 0 || n_eff > n_frames) return fail(RY_EINVAL, "bad frame counts (%d effective of %d)", n_eff, n_frames);
@@ -1890,6 +1933,7 @@ int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, in
         memcpy(sl.h_row, row_of, (size_t)n_eff * sizeof(int));
         RT_TRY(rt::h2d(sl.d_x, sl.h_x, (size_t)n_eff * cin * sizeof(float), st1));
         RT_TRY(rt::h2d(sl.d_row, sl.h_row, (size_t)n_eff * sizeof(int), st1));
+        RY_TRY(vc_stagger(vc));
         RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1));                       // stage-1 CNN on the effective frames
     }
     RY_TRY(vc_enqueue_mid(vc, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp));
@@ -2020,7 +2064,7 @@ int ry_vc_submit_wave(ry_vc* vc, const float* wave, int n_samples, int hop, int 
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
     int n_eff = 0;
     RY_TRY(vc_gate_into_slot(vc, sl, wave, n_samples, hop, fft_length, p_effective, p_all, feat, n_frames, &n_eff));
-    if (n_eff > 0) RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1));
+    if (n_eff > 0) { RY_TRY(vc_stagger(vc)); RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1)); }
     RY_TRY(vc_enqueue_mid(vc, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp));
     RT_TRY(rt::d2h(sl.h_mc, sl.d_mc, (size_t)n_frames * M * sizeof(float), st1));
     RT_TRY(rt::event_record(sl.ev_mid, st1));
@@ -2060,7 +2104,7 @@ int ry_vc_enqueue_device(ry_vc* vc, const float* x_eff_dev, const int* row_of_de
     ++vc->dev_count;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
     if (sl.used) RT_TRY(rt::stream_wait_event(st1, sl.ev_done));                        // the slot's previous window has left d_sp
-    if (n_eff > 0) RY_TRY(ry_ac_convert(s1, x_eff_dev, sl.d_y1, 1, n_eff, 1));
+    if (n_eff > 0) { RY_TRY(vc_stagger(vc)); RY_TRY(ry_ac_convert(s1, x_eff_dev, sl.d_y1, 1, n_eff, 1)); }
     RY_TRY(vc_enqueue_mid(vc, sl.d_y1, row_of_dev, n_eff, n_frames, sp_floor, mc_out_dev, sl.d_sp));
     RT_TRY(rt::event_record(sl.ev_mid, st1));
     RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));
