@@ -423,12 +423,13 @@ def cpu_baseline(args, torch, d1, d2, x, mc_gpu, sp_gpu, N, gpu_value):
     torch.set_num_threads(mid)                                # oneDNN at batch 1 does not scale to every core of a large host: a middle setting beside 1 / all
     chain(x); t1 = time.perf_counter(); chain(x); chain(x); mid_s = (time.perf_counter() - t1) / 2
     torch.set_num_threads(nthr)
-    res = {'value': round(N / cpu_s, 1), 'unit': 'frames/s', 'cores': nthr, 'kind': 'port',
-           'sample': '%d x (stage-1 -> mc2sp -> stage-2 of one %d-frame window), CPU restatement (torch/oneDNN fp32), not Chainer; host has %d logical cpus'
-                     % (reps, N, os.cpu_count()),
-           'value_1_thread': round(N / one_s, 1), 'sample_1_thread': '1 x the same window with torch.set_num_threads(1)',
-           'value_%d_threads' % mid: round(N / mid_s, 1),
-           'gpu_over_cpu': round(gpu_value / (N / cpu_s), 1),
+    by_threads = {nthr: N / cpu_s, mid: N / mid_s, 1: N / one_s}
+    best = max(by_threads, key=lambda k: by_threads[k])     # oneDNN at batch 1 does not scale to every core of a large host: quote the best setting
+    res = {'value': round(by_threads[best], 1), 'unit': 'frames/s', 'cores': best, 'kind': 'port',
+           'sample': '%d x (stage-1 -> mc2sp -> stage-2 of one %d-frame window) with all %d threads, 2 x with %d, 1 x with one; `value` = the best of the three; '
+                     'CPU restatement (torch/oneDNN fp32), not Chainer; host has %d logical cpus' % (reps, N, nthr, mid, os.cpu_count()),
+           'frames_per_s_by_threads': {str(k): round(v, 1) for k, v in sorted(by_threads.items())},
+           'gpu_over_cpu': round(gpu_value / by_threads[best], 1),
            'gpu_result_vs_this_baseline': {'sp_max_rel': err_sp, 'mc_max_norm': err_mc, 'bar': 1e-4}}
     assert err_sp < 1e-4 and err_mc < 1e-4, 'GPU result of the timed region differs from the CPU restatement: %g %g' % (err_sp, err_mc)
     # BASELINE config #1, the plumbing baseline: check.py's schedule (/root/reference/check.py:96-125) = 5 windows of 1 s + 2 x 1 s
