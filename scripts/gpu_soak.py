@@ -30,8 +30,21 @@ t0 = time.time()
 frames_done = 0
 for it in range(iters):
     n = int(rng.integers(40, 700))
-    kind = it % 5
-    if kind < 3:                                        # one window through the fused core, data-dependent effective count
+    kind = it % 7
+    if kind == 5:                                       # the silence gate on the device: raw wave + all frames up, mask back (ry_vc_submit_wave)
+        from realtime_yukarin_amd import gate
+        w = (rng.choice([1e-5, 0.1]) * rng.normal(size=n * 80)).astype('f4'); w[(n // 3) * 80:(n // 2) * 80] = 0.0
+        feat = rng.normal(size=(n, d1.in_ch)).astype('f4')
+        mc, sp, eff = core.wait_wave(core.submit_wave(w, 80, 1024, *gate.thresholds(60), feat))
+        assert sp.shape == (n, synth.FFT_BINS) and numpy.isfinite(sp).all() and not mc[~eff].any() and not eff[n // 3 + 7:n // 2 - 7].any()
+    elif kind == 6:                                     # a short stream with three windows in flight through the pinned ring
+        wins = []
+        for _ in range(4):
+            m = int(rng.integers(40, 400)); e = rng.random(m) < 0.8
+            wins.append((rng.normal(size=(m, d1.in_ch)).astype('f4')[e], e))
+        for (xe, e), (mc, sp) in zip(wins, core.convert_stream(wins, depth=3)):
+            assert sp.shape == (len(e), synth.FFT_BINS) and numpy.isfinite(sp).all() and not mc[~e].any()
+    elif kind < 3:                                      # one window through the fused core, data-dependent effective count
         eff = rng.random(n) < rng.choice([0.0, 0.5, 0.9, 1.0], p=[0.05, 0.25, 0.4, 0.3])
         x = rng.normal(size=(n, d1.in_ch)).astype('f4')
         mc, sp = core.convert(x[eff], eff)
