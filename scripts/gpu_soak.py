@@ -54,7 +54,7 @@ for it in range(iters):
         sp = n2.convert(synth.stage2_input(min(n, 400), windows=b, seed=it))
         assert sp.shape == (b, min(n, 400), synth.FFT_BINS) and numpy.isfinite(sp).all()
     frames_done += n
-    if it % 250 == 249 or it == iters - 1:
+    if it % 100 == 99 or it == iters - 1:
         again = core.convert(probe_x[probe_eff], probe_eff)
         assert numpy.array_equal(again[0], probe[0]) and numpy.array_equal(again[1], probe[1]), 'probe window changed at %d' % it
         assert numpy.array_equal(n2.convert(probe_sp), probe_b), 'probe batch changed at %d' % it
@@ -63,8 +63,9 @@ for it in range(iters):
         samples.append(free)
         print('iter %5d  %.1f s  %.0f windows/s  free HBM %.2f GB (drift %+.1f MB)' % (
             it + 1, time.time() - t0, (it + 1) / (time.time() - t0), free / 1e9, (free - free0) / 1e6), flush=True)
-# the plan cache (<= 16 plans per predictor, cleared when full) makes the free memory saw-tooth; it must not trend down
-half = len(samples) // 2
-assert min(samples[half:]) >= min(samples[:half]) - 1e9, 'device memory keeps shrinking: %s' % samples
+# the plan cache (<= 16 plans per predictor of up to ~0.5 GB each, cleared when full) makes the free memory saw-tooth by several GB;
+# it must not TREND down: compare the low-water marks of the last and the first third of the run
+third = max(1, len(samples) // 3)
+assert min(samples[-third:]) >= min(samples[:third]) - 2e9, 'device memory keeps shrinking: %s' % [round(v / 1e9, 2) for v in samples]
 print('soak ok: %d windows, %d frames, probes bit-identical throughout' % (iters, frames_done))
 core.close(); n1.close(); n2.close()
