@@ -56,6 +56,20 @@ RY_DEV void ry_wave_sync() {
 // the instruction scheduler does not move anything across this point
 RY_DEV void ry_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 RY_DEV float ry_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+// lane ^ MASK exchange with a compile-time mask: DPP modifiers inside a row of 16 lanes (a VALU-latency move instead of a trip
+// through the LDS crossbar: ds_bpermute costs ~100 cycles of latency per dependent step), ds_bpermute across rows.
+template <int CTRL>
+RY_DEV float ry_dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int MASK>
+RY_DEV float ry_shfl_xor_c(float v) {
+    if constexpr (MASK == 1) return ry_dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) return ry_dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 4) return ry_dpp_mov<0x1B>(ry_dpp_mov<0x141>(v));   // row_half_mirror (i -> 7 - i), then quad_perm [3,2,1,0]: i -> i ^ 4
+    else if constexpr (MASK == 8) return ry_dpp_mov<0x128>(v);                 // row_ror:8
+    else return __shfl_xor(v, MASK, 64);
+}
 RY_DEV float ry_shfl(float v, int src) { return __shfl(v, src, 64); }
 // separately rounded float32 product / sum (never contracted into an fma) and the correctly rounded square root: the silence gate
 // has to reproduce numpy's float32 arithmetic bit for bit

@@ -1500,9 +1500,10 @@ struct RyC1dOsParams {
     int pad;                    // MODE S1 only
     int act;
     float slope;
-    int tiles;                  // position tiles per window (one tile = PG x TP rows)
-    int kt_waves;
+    int tiles;                  // position tiles per window (one tile = PG x TP rows) = gridDim.y; gridDim.z = windows
+    int kt_shift;               // log2 of the waves that share one position group (0 / 1 / 2 for <= 64 / <= 128 / more input channels)
     int n_real;                 // PADMIN instantiations: real rows per window in `sa`; rows n_real .. Lin - 1 are the per-channel minimum
+    unsigned long long* dbg;    // diagnostics (RY_S1_TIMING=1): per-workgroup s_memtime stamps at the phase boundaries, else null
 };
 
 // Keeps two values in separate registers: without it the compiler rewrites `c ? v[a] : v[b]` on a register array into a
@@ -1514,33 +1515,49 @@ RY_DEV void ry_keep2(float& a, float& b) {
 #endif
 }
 
-// Reduce-scatter over the 64 lanes of a wave: every lane brings N partial sums, lane L returns the 64-lane total of sum number
-// L >> (6 - log2 N) (lanes that share the upper bits hold the same total).  N - 1 + (6 - log2 N) shuffles, fixed order.
-template <int N>
+// Reduce-scatter over the 64 lanes of a wave: every lane brings N partial sums, the step with mask m halves them (lanes with bit m
+// set keep the upper half), masks 1, 2, 4, 8, 16, 32 in that order -- the steps that move the most values are the in-row DPP ones.
+// Lane L returns the 64-lane total of sum number bitrev_{log2 N}(L & (N - 1)) (all lanes that share those low bits hold the same
+// total).  N - 1 + (6 - log2 N) exchanges, fixed order.
+template <int N, int MASK>
 struct RyReduceScatter64 {
-    static RY_DEV float run(const float (&v)[N], int lane, int mask) {
+    static RY_DEV float run(const float (&v)[N], int lane) {
         float h[N / 2];
-        const bool up = (lane & mask) != 0;
+        const bool up = (lane & MASK) != 0;
 #pragma unroll
         for (int i = 0; i < N / 2; ++i) {
             float lo = v[i], hi = v[i + N / 2];
             ry_keep2(lo, hi);
-            const float recv = ry_shfl_xor(up ? lo : hi, mask);
+            const float recv = ry_shfl_xor_c<MASK>(up ? lo : hi);
             h[i] = (up ? hi : lo) + recv;
         }
-        return RyReduceScatter64<N / 2>::run(h, lane, mask >> 1);
+        return RyReduceScatter64<N / 2, MASK * 2>::run(h, lane);
     }
 };
-template <>
-struct RyReduceScatter64<1> {
-    static RY_DEV float run(const float (&v)[1], int, int mask) {
+template <int MASK>
+struct RyReduceScatter64<1, MASK> {
+    static RY_DEV float run(const float (&v)[1], int lane) {
         float r = v[0];
-        for (; mask >= 1; mask >>= 1) r += ry_shfl_xor(r, mask);
+        if constexpr (MASK <= 32) {
+            r += ry_shfl_xor_c<MASK>(r);
+            const float one[1] = {r};
+            return RyReduceScatter64<1, MASK * 2>::run(one, lane);
+        }
         return r;
     }
 };
+RY_DEV int ry_bitrev(int v, int bits) {            // reverse the low `bits` bits
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
 
-template <int MODE, int CB, int TP, bool PADMIN>
+// USRC: every wave reads ONE source (no second source, or the first one ends on a multiple of 64 channels -- the U-Net's case): the
+// source, its row pitch and the row offsets are then wave-uniform and live in SGPRs, and a load costs one VALU add instead of a
+// compare / select / 32-bit multiply / 64-bit add chain per lane.  (Measured with s_memtime stamps, RY_S1_STAMPS: the stretch from
+// kernel start to the last load issued was ~2000-2500 shader cycles per layer whether or not the instruction cache was warm, and
+// ~1000 more per extra channel set: three waves per SIMD x 40 loads x ~6 VALU instructions, a quarter-rate v_mul_lo_u32 among them.)
+template <int MODE, int CB, int TP, bool PADMIN, bool USRC>
 RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
     constexpr int TPO = MODE == RY_C1D_DECONV ? 2 * TP : TP;                       // outputs per position group
     constexpr int NP = MODE == RY_C1D_S2 ? 2 * TP + 2 : MODE == RY_C1D_DECONV ? TP + 2 : TP + 3;
@@ -1551,11 +1568,18 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
     __shared__ float red[4 * 32];
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = ry_uniform(tid >> 6);
-    const int ktw = p.kt_waves, PG = 4 / ktw;
-    const int pg = wave / ktw, kw = wave - pg * ktw;
+#if defined(RY_HOST_EMU) || !defined(RY_S1_STAMPS)
+#define RY_OS_STAMP(i)
+#else       // diagnostic build (-DRY_S1_STAMPS, RY_S1_TIMING=1): s_memtime at the phase boundaries, one record per workgroup
+    unsigned long long* const dbgp = p.dbg ? p.dbg + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 : nullptr;
+#define RY_OS_STAMP(i) if (dbgp && tid == 0) dbgp[i] = __builtin_amdgcn_s_memtime();
+#endif
+    RY_OS_STAMP(0)
+    const int ktw = 1 << p.kt_shift, PG = 4 >> p.kt_shift;                           // no integer division in the prologue
+    const int pg = wave >> p.kt_shift, kw = wave & (ktw - 1);
     const int Ctot = p.Ca + p.Cb;
     const int co0 = (int)blockIdx.x * CB;
-    const int b = (int)blockIdx.y / p.tiles, tile = (int)blockIdx.y - b * p.tiles;
+    const int b = (int)blockIdx.z, tile = (int)blockIdx.y;
     const int r0 = (tile * PG + pg) * TP;                                            // first row of this position group
     const int pos0 = MODE == RY_C1D_S2 ? 2 * r0 - 1 : MODE == RY_C1D_DECONV ? r0 - 1 : r0 - p.pad;
     // PADMIN (first layer of the convert wrapper): the source holds n_real rows per window and rows n_real .. Lin - 1 are
@@ -1563,28 +1587,44 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
     const int src_rows = PADMIN ? p.n_real : p.Lin;
     const bool need_min = PADMIN && pos0 + NP > p.n_real;                            // wave-uniform
 
+    // the epilogue's scale / shift of the output this thread will store: requested now, with the operand loads, instead of as one more
+    // dependent round trip behind the barrier
+    float ep_sc = 1.f, ep_sh = 0.f;
+    if (tid < PG * A) {
+        const int co_t = co0 + ((tid % A) / TPO);
+        ep_sc = p.scale[co_t < p.N ? co_t : p.N - 1]; ep_sh = p.shift[co_t < p.N ? co_t : p.N - 1];
+    }
     float acc[A];
 #pragma unroll
     for (int i = 0; i < A; ++i) acc[i] = 0.f;
     // one input channel of this lane: its NP input rows and the taps of the CB output channels (32-bit offsets: the executor
     // bounds every activation below 2^31 elements)
-    auto load = [&](int c0, float (&x)[NP], f32x4 (&w)[CB], float& cmin) {
+    auto load = [&](int cbase /* first channel of this wave's set: wave-uniform */, float (&x)[NP], f32x4 (&w)[CB], float& cmin) {
+        const int c0 = cbase + lane;
         const bool cok = c0 < Ctot;
         const int ci = cok ? c0 : Ctot - 1;
-        const bool fa = ci < p.Ca;
-        const float* src = fa ? p.sa : p.sb;
-        const int Cs = fa ? p.Ca : p.Cb, cl = fa ? ci : ci - p.Ca;
-        const float* col = src + (size_t)b * (size_t)src_rows * (size_t)Cs + cl;
+        const float* col;           // source column of this lane's channel (row 0 of window b), and the row pitch
+        int Cs;
+        if (USRC) {                 // the whole wave reads one source: everything but the lane's channel offset is scalar
+            const bool fa = cbase < p.Ca;
+            Cs = fa ? p.Ca : p.Cb;
+            col = (fa ? p.sa : p.sb) + (size_t)b * (size_t)src_rows * (size_t)Cs + (fa ? 0 : -p.Ca);
+        } else {
+            const bool fa = ci < p.Ca;
+            Cs = fa ? p.Ca : p.Cb;
+            col = (fa ? p.sa : p.sb) + (size_t)b * (size_t)src_rows * (size_t)Cs + (fa ? 0 : -p.Ca);
+        }
+        const unsigned wl = (unsigned)ci * 4u;
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
-            const int co = co0 + u < p.N ? co0 + u : p.N - 1;
-            w[u] = ry_ld4(p.w + (unsigned)((co * Ctot + ci) * 4));
+            const int co = co0 + u < p.N ? co0 + u : p.N - 1;                        // scalar
+            w[u] = ry_ld4(p.w + ((unsigned)(co * Ctot) * 4u + wl));
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {                                               // out-of-range rows read row 0; `fix` replaces them
             const int pos = pos0 + j;
-            const bool ok = pos >= 0 && pos < src_rows;
-            x[j] = col[(unsigned)((ok ? pos : 0) * Cs)];
+            const bool ok = pos >= 0 && pos < src_rows;                              // scalar
+            x[j] = col[(unsigned)((ok ? pos : 0) * Cs) + (unsigned)ci];
         }
         if (PADMIN) {
             cmin = INFINITY;
@@ -1592,7 +1632,7 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
                 for (int r = 0; r < p.n_real; r += 8) {                              // eight independent loads in flight per round
                     float v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = col[(unsigned)((r + u < p.n_real ? r + u : 0) * Cs)];
+                    for (int u = 0; u < 8; ++u) v[u] = col[(unsigned)((r + u < p.n_real ? r + u : 0) * Cs) + (unsigned)ci];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) cmin = fminf(cmin, v[u]);
                 }
@@ -1635,8 +1675,8 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
         for (; cb0 + 3 * cstep < Ctot; cb0 += 4 * cstep) {
             float x0[NP], x1[NP], x2[NP], x3[NP], m0, m1, m2, m3;
             f32x4 w0[CB], w1[CB], w2[CB], w3[CB];
-            load(cb0 + lane, x0, w0, m0); load(cb0 + cstep + lane, x1, w1, m1);
-            load(cb0 + 2 * cstep + lane, x2, w2, m2); load(cb0 + 3 * cstep + lane, x3, w3, m3);
+            load(cb0, x0, w0, m0); load(cb0 + cstep, x1, w1, m1);
+            load(cb0 + 2 * cstep, x2, w2, m2); load(cb0 + 3 * cstep, x3, w3, m3);
             ry_sched_fence();                                                        // every load is issued before the first FMA
             fix(cb0 + lane, x0, m0); fix(cb0 + cstep + lane, x1, m1); fix(cb0 + 2 * cstep + lane, x2, m2); fix(cb0 + 3 * cstep + lane, x3, m3);
             fma_all(x0, w0); fma_all(x1, w1); fma_all(x2, w2); fma_all(x3, w3);
@@ -1645,8 +1685,8 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
     for (; cb0 + cstep < Ctot; cb0 += 2 * cstep) {
         float xa[NP], xb[NP], ma, mb;
         f32x4 wa[CB], wb[CB];
-        load(cb0 + lane, xa, wa, ma);
-        load(cb0 + cstep + lane, xb, wb, mb);
+        load(cb0, xa, wa, ma);
+        load(cb0 + cstep, xb, wb, mb);
         ry_sched_fence();
         fix(cb0 + lane, xa, ma); fix(cb0 + cstep + lane, xb, mb);
         fma_all(xa, wa);
@@ -1655,14 +1695,18 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
     if (cb0 < Ctot) {
         float xa[NP], ma;
         f32x4 wa[CB];
-        load(cb0 + lane, xa, wa, ma);
+        load(cb0, xa, wa, ma);
         ry_sched_fence();
+        RY_OS_STAMP(1)
         fix(cb0 + lane, xa, ma);
         fma_all(xa, wa);
     }
-    const float tot = RyReduceScatter64<A>::run(acc, lane, 32);
-    if ((lane & ((64 >> LOG2A) - 1)) == 0) red[wave * 32 + (lane >> (6 - LOG2A))] = tot;
+    RY_OS_STAMP(2)
+    const float tot = RyReduceScatter64<A, 1>::run(acc, lane);
+    RY_OS_STAMP(3)
+    if (lane < A) red[wave * 32 + ry_bitrev(lane, LOG2A)] = tot;
     __syncthreads();
+    RY_OS_STAMP(4)
     if (tid < PG * A) {
         const int pq = tid / A, idx = tid - pq * A;
         float s = red[(pq * ktw) * 32 + idx];
@@ -1672,8 +1716,10 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
         const int rg = (tile * PG + pq) * TP;
         const int l = (MODE == RY_C1D_DECONV ? 2 * rg : rg) + j;
         if (co < p.N && l < p.Lout && l < p.keep)
-            p.out[((size_t)b * (size_t)p.keep + l) * (size_t)p.N + co] = ry_act(fmaf(s, p.scale[co], p.shift[co]), p.act, p.slope);
+            p.out[((size_t)b * (size_t)p.keep + l) * (size_t)p.N + co] = ry_act(fmaf(s, ep_sc, ep_sh), p.act, p.slope);
     }
+    RY_OS_STAMP(5)
+#undef RY_OS_STAMP
 }
 
 struct RyMaterializeParams {

@@ -909,6 +909,7 @@ static int choose_splits_1d(const Layer& l, int B, int rows, int mode) {
 
 
 // ---- stage-1, output-stationary form (ry_c1d_os) ----
+static int g_s1_timing = 0;        // RY_S1_TIMING=1 (diagnostics): every ry_c1d_os launch is followed by a sync and a print of its phase stamps
 static int g_s1_padfuse = 1;       // RY_S1_PADFUSE=0: separate ry_pad_min_rows node in front of stage 1 (A/B)
 static int g_s1_os = 1;            // RY_S1_OS=0: the round-1 weight-streaming kernels with split-K slabs (A/B)
 static int g_s1_units = 256;       // RY_S1_UNITS: smallest workgroup count a layer should reach before it takes a larger slice per workgroup
@@ -945,36 +946,71 @@ static int launch_c1d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     memset(&p, 0, sizeof p);
     p.sa = sa; p.sb = sb; p.Ca = Ca; p.Cb = Cb; p.w = l.w1os; p.scale = l.scale; p.shift = l.shift; p.out = out;
     p.B = B; p.Lin = lp.Wi; p.Lout = lp.Wo; p.N = l.cout; p.keep = keep; p.pad = l.pad; p.act = l.act; p.slope = slope;
-    p.kt_waves = lp.os_kt; p.n_real = n_real;
+    p.kt_shift = lp.os_kt == 4 ? 2 : lp.os_kt == 2 ? 1 : 0; p.n_real = n_real;
+    unsigned long long* dbg = nullptr;
+#ifndef RY_HOST_EMU
+    if (g_s1_timing) {
+        static unsigned long long* g_s1_dbg = nullptr;
+        if (!g_s1_dbg) RT_TRY(hipMalloc((void**)&g_s1_dbg, 65536 * 8 * sizeof(unsigned long long)));
+        RT_TRY(hipMemsetAsync(g_s1_dbg, 0, 65536 * 8 * sizeof(unsigned long long), Lc.stream));
+        dbg = g_s1_dbg;
+    }
+#endif
+    p.dbg = dbg;
     const int mode = c1d_mode(l);
     const int rows = mode == RY_C1D_DECONV ? lp.Wi : lp.Wo;
     const int PG = 4 / lp.os_kt;
     p.tiles = (rows + PG * lp.os_tp - 1) / (PG * lp.os_tp);
-    dim3 grid((unsigned)((l.cout + lp.os_cb - 1) / lp.os_cb), (unsigned)(B * p.tiles));
-    if (grid.y > 65535u) return fail(RY_EINVAL, "%s: batch*tiles = %u exceeds the grid limit", l.name, grid.y);
+    dim3 grid((unsigned)((l.cout + lp.os_cb - 1) / lp.os_cb), (unsigned)p.tiles, (unsigned)B);
+    if (grid.y > 65535u || grid.z > 65535u) return fail(RY_EINVAL, "%s: %u tiles x %u windows exceed the grid limit", l.name, grid.y, grid.z);
+    // every wave reads one source when there is no second one or the first ends on a wave boundary (the U-Net's case); else the per-lane form
+    const bool usrc = Cb == 0 || Ca % 64 == 0;
+    if (!usrc && !(lp.os_cb == 2 && lp.os_tp == 4)) return fail(RY_ESTATE, "%s: a layer whose sources split inside a wave runs the 2x4 slice", l.name);
     char nm[48];
-    snprintf(nm, sizeof nm, "ry_c1d_os<%d,%d,%d,%s>", mode, lp.os_cb, lp.os_tp, n_real > 0 ? "true" : "false");   // as rocprofv3 prints it (MODE: 0 = k4 s2 conv, 1 = stride-1 conv, 2 = k4 s2 deconv)
+    snprintf(nm, sizeof nm, "ry_c1d_os<%d,%d,%d,%s,%s>", mode, lp.os_cb, lp.os_tp, n_real > 0 ? "true" : "false", usrc ? "true" : "false");   // as rocprofv3 prints it (MODE: 0 = k4 s2 conv, 1 = stride-1 conv, 2 = k4 s2 deconv)
     RY_TRY(Lc.begin(nm, l.name, lp.flops, lp.bytes, grid));
-#define RY_OS_CASE(MODE_, CB_, TP_) if (lp.os_cb == CB_ && lp.os_tp == TP_) { RY_LAUNCH((ry_c1d_os<MODE_, CB_, TP_, false>), grid, 256, Lc.stream, p); } else
-#define RY_OS_CASE_PM(CB_, TP_) if (n_real > 0 && lp.os_cb == CB_ && lp.os_tp == TP_) { RY_LAUNCH((ry_c1d_os<RY_C1D_S1, CB_, TP_, true>), grid, 256, Lc.stream, p); } else
+#define RY_OS_CASE(MODE_, CB_, TP_) if (usrc && lp.os_cb == CB_ && lp.os_tp == TP_) { RY_LAUNCH((ry_c1d_os<MODE_, CB_, TP_, false, true>), grid, 256, Lc.stream, p); } else
+#define RY_OS_CASE_NU(MODE_) if (!usrc) { RY_LAUNCH((ry_c1d_os<MODE_, 2, 4, false, false>), grid, 256, Lc.stream, p); } else
+#define RY_OS_CASE_PM(CB_, TP_) if (n_real > 0 && lp.os_cb == CB_ && lp.os_tp == TP_) { RY_LAUNCH((ry_c1d_os<RY_C1D_S1, CB_, TP_, true, true>), grid, 256, Lc.stream, p); } else
     switch (mode) {
         case RY_C1D_S2:
-            RY_OS_CASE(RY_C1D_S2, 4, 8) RY_OS_CASE(RY_C1D_S2, 4, 4) RY_OS_CASE(RY_C1D_S2, 2, 8) RY_OS_CASE(RY_C1D_S2, 2, 4)
+            RY_OS_CASE_NU(RY_C1D_S2) RY_OS_CASE(RY_C1D_S2, 4, 8) RY_OS_CASE(RY_C1D_S2, 4, 4) RY_OS_CASE(RY_C1D_S2, 2, 8) RY_OS_CASE(RY_C1D_S2, 2, 4)
             return fail(RY_EINVAL, "%s: no ry_c1d_os instantiation for slice %dx%d", l.name, lp.os_cb, lp.os_tp);
             break;
         case RY_C1D_S1:
             if (n_real > 0 && mode != RY_C1D_S1) return fail(RY_EINVAL, "%s: the fused pad needs a stride-1 first layer", l.name);
             RY_OS_CASE_PM(4, 8) RY_OS_CASE_PM(4, 4) RY_OS_CASE_PM(2, 8) RY_OS_CASE_PM(2, 4)
-            RY_OS_CASE(RY_C1D_S1, 4, 8) RY_OS_CASE(RY_C1D_S1, 4, 4) RY_OS_CASE(RY_C1D_S1, 2, 8) RY_OS_CASE(RY_C1D_S1, 2, 4)
+            RY_OS_CASE_NU(RY_C1D_S1) RY_OS_CASE(RY_C1D_S1, 4, 8) RY_OS_CASE(RY_C1D_S1, 4, 4) RY_OS_CASE(RY_C1D_S1, 2, 8) RY_OS_CASE(RY_C1D_S1, 2, 4)
             return fail(RY_EINVAL, "%s: no ry_c1d_os instantiation for slice %dx%d", l.name, lp.os_cb, lp.os_tp);
             break;
         default:
-            RY_OS_CASE(RY_C1D_DECONV, 4, 4) RY_OS_CASE(RY_C1D_DECONV, 2, 8) RY_OS_CASE(RY_C1D_DECONV, 2, 4)
+            RY_OS_CASE_NU(RY_C1D_DECONV) RY_OS_CASE(RY_C1D_DECONV, 4, 4) RY_OS_CASE(RY_C1D_DECONV, 2, 8) RY_OS_CASE(RY_C1D_DECONV, 2, 4)
             return fail(RY_EINVAL, "%s: no ry_c1d_os instantiation for slice %dx%d", l.name, lp.os_cb, lp.os_tp);
             break;
     }
 #undef RY_OS_CASE
+#undef RY_OS_CASE_NU
 #undef RY_OS_CASE_PM
+#ifndef RY_HOST_EMU
+    if (dbg) {          // diagnostics: mean shader-clock deltas between the phase stamps over the workgroups, and the spread of start / end
+        RT_TRY(rt::stream_sync(Lc.stream));
+        const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+        std::vector<unsigned long long> h(nwg * 8);
+        RT_TRY(hipMemcpy(h.data(), dbg, nwg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double d[5] = {0, 0, 0, 0, 0};
+        unsigned long long t_first = ~0ull, t_last_start = 0, t_last_end = 0;
+        for (size_t w = 0; w < nwg; ++w) {
+            const unsigned long long* q = &h[w * 8];
+            const unsigned long long t1 = q[1] ? q[1] : q[0];
+            d[0] += (double)(t1 - q[0]); d[1] += (double)(q[2] - t1); d[2] += (double)(q[3] - q[2]); d[3] += (double)(q[4] - q[3]); d[4] += (double)(q[5] - q[4]);
+            if (q[0] < t_first) t_first = q[0];
+            if (q[0] > t_last_start) t_last_start = q[0];
+            if (q[5] > t_last_end) t_last_end = q[5];
+        }
+        fprintf(stderr, "S1TIMING %-12s %-24s wgs %5zu | issue %6.0f  loads+fma %6.0f  reduce %6.0f  lds+barrier %6.0f  store %6.0f | first start -> last start %6llu, -> last end %6llu cycles\n",
+                l.name, nm, nwg, d[0] / nwg, d[1] / nwg, d[2] / nwg, d[3] / nwg, d[4] / nwg, t_last_start - t_first, t_last_end - t_first);
+    }
+#endif
     return Lc.end();
 }
 
@@ -1028,6 +1064,7 @@ static int build_plan(ry_net* net, Plan& P) {
             lp.os_kt = c1d_os_ktw(l.cin());
             choose_os(l, B, mode == RY_C1D_DECONV ? lp.Wi : lp.Wo, &lp.os_cb, &lp.os_tp);
             if (g_s1_force[i][0] > 0) { lp.os_cb = g_s1_force[i][0]; lp.os_tp = g_s1_force[i][1]; }
+            if (l.cin_b > 0 && l.cin_a % 64 != 0) { lp.os_cb = 2; lp.os_tp = 4; }      // sources split inside a wave: the per-lane form exists for this slice only
             if (i < 15) RY_TRY(P.arena.alloc(&lp.out, out_elems));          // the last layer stores straight into the caller's block
         } else if (nd == 1) {
             const int mode = c1d_mode(l);
@@ -1461,6 +1498,7 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_VC_STAGGER")) g_vc_stagger = atoi(e);
     if (const char* e = getenv("RY_S1_OS")) g_s1_os = atoi(e);
     if (const char* e = getenv("RY_S1_PADFUSE")) g_s1_padfuse = atoi(e);
+    if (const char* e = getenv("RY_S1_TIMING")) g_s1_timing = atoi(e);
     if (const char* e = getenv("RY_S1_UNITS")) g_s1_units = atoi(e) > 0 ? atoi(e) : 1;
     memset(g_s1_force, 0, sizeof(g_s1_force));
     if (const char* e = getenv("RY_S1_CFG")) {

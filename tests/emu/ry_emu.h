@@ -62,6 +62,7 @@ RY_DEV float ry_mul_rn(float a, float b) { volatile float r = a * b; return r; }
 RY_DEV float ry_add_rn(float a, float b) { volatile float r = a + b; return r; }
 RY_DEV float ry_sqrt_rn(float a) { return sqrtf(a); }
 RY_DEV float ry_shfl_xor(float v, int mask) { return ry_emu::shfl_xor(v, mask); }
+template <int MASK> RY_DEV float ry_shfl_xor_c(float v) { return ry_emu::shfl_xor(v, MASK); }
 RY_DEV float ry_shfl(float v, int src) { return ry_emu::shfl(v, src); }
 RY_DEV int ry_lane() { return (int)(threadIdx.x & 63u); }
 
