@@ -889,6 +889,8 @@ RY_KERNEL(256) void ry_splitk_reduce(RyReduceParams p) {
     if (i4 >= p.total) return;
     // four independent partial sums (slabs k = 0,1,2,3 mod 4) keep >= 4 loads in flight; the order is fixed,
     // so the result is deterministic
+    const int n = (int)((unsigned)i4 % (unsigned)p.N);          // (the executor keeps every activation below 2^31 elements: 32-bit arithmetic)
+    const f32x4 sc = ry_ld4(p.scale + n), sh = ry_ld4(p.shift + n);       // requested with the slabs, not behind them
     f32x4 s0 = ry_ld4(p.slabs + i4), s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
     const size_t st = (size_t)p.slab_stride;
     int k = 1;
@@ -899,14 +901,12 @@ RY_KERNEL(256) void ry_splitk_reduce(RyReduceParams p) {
     }
     for (; k < p.splits; ++k) s1 += ry_ld4(p.slabs + (size_t)k * st + i4);
     const f32x4 s = (s0 + s1) + (s2 + s3);
-    const int n = (int)(i4 % p.N);
-    const f32x4 sc = ry_ld4(p.scale + n), sh = ry_ld4(p.shift + n);
     f32x4 o;
 #pragma unroll
     for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(s[u], sc[u], sh[u]), p.act, p.slope);
     if (p.out) ry_st4(p.out + i4, o);
     if (p.out16) {
-        if (p.x3) ry_st4_bf16_x3(p.out16, (size_t)(i4 / p.N), p.N, n, o);
+        if (p.x3) ry_st4_bf16_x3(p.out16, (size_t)((unsigned)i4 / (unsigned)p.N), p.N, n, o);
         else ry_st4_bf16(p.out16 + i4, o);
     }
 }
@@ -919,6 +919,9 @@ RY_KERNEL(256) void ry_splitk_reduce_wide(RyReduceParams p) {
     const long long i4 = ((long long)blockIdx.x * 64 + col) * 4;
     const bool live = i4 < p.total;
     const size_t st = (size_t)p.slab_stride;
+    const int n = (int)((unsigned)i4 % (unsigned)p.N);          // (the executor keeps every activation below 2^31 elements: 32-bit arithmetic)
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (grp == 0 && live) { sc = ry_ld4(p.scale + n); sh = ry_ld4(p.shift + n); }     // requested with the slabs, not behind the barrier
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f};
     if (live) {
         // group grp sums slabs grp, grp + 4, ... in that order; eight loads are in flight per round trip (the kernel is a
@@ -936,14 +939,12 @@ RY_KERNEL(256) void ry_splitk_reduce_wide(RyReduceParams p) {
     __syncthreads();
     if (grp == 0 && live) {
         const f32x4 s = (ry_ld4(&part[col * 4]) + ry_ld4(&part[(64 + col) * 4])) + (ry_ld4(&part[(128 + col) * 4]) + ry_ld4(&part[(192 + col) * 4]));
-        const int n = (int)(i4 % p.N);
-        const f32x4 sc = ry_ld4(p.scale + n), sh = ry_ld4(p.shift + n);
         f32x4 o;
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = ry_act(fmaf(s[u], sc[u], sh[u]), p.act, p.slope);
         if (p.out) ry_st4(p.out + i4, o);
         if (p.out16) {
-            if (p.x3) ry_st4_bf16_x3(p.out16, (size_t)(i4 / p.N), p.N, n, o);
+            if (p.x3) ry_st4_bf16_x3(p.out16, (size_t)((unsigned)i4 / (unsigned)p.N), p.N, n, o);
             else ry_st4_bf16(p.out16 + i4, o);
         }
     }
@@ -1009,20 +1010,20 @@ struct RySrFirstParams {
     int B, H, W, N;
     int act;
     float slope;
+    int qshift;                 // log2(N / 4) when that is a power of two, else -1
 };
 
 template <int PX>
-RY_KERNEL(256) void ry_sr_first(RySrFirstParams p) {
+RY_KERNEL(256) void ry_sr_first(RySrFirstParams p) {     // grid: (pixel groups x channel quads of one row / 256, rows, windows)
     const int quads = p.N >> 2;
     const int gpr = (p.W + PX - 1) / PX;                       // pixel groups per row
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)p.B * p.H * gpr * quads;
-    if (idx >= total) return;
-    const int cq = (int)(idx % quads);
-    long long pg = idx / quads;
-    const int gx = (int)(pg % gpr); pg /= gpr;
-    const int y = (int)(pg % p.H);
-    const int b = (int)(pg / p.H);
+    const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    // [r2] the row and the window come from the grid and the channel quad from a shift when N / 4 is a power of two: the kernel was
+    // VALU-bound on four emulated integer divisions per thread (16.4 us for a 50 MB write)
+    const int gx = p.qshift >= 0 ? idx >> p.qshift : idx / quads;
+    const int cq = idx - gx * quads;
+    if (gx >= gpr) return;
+    const int y = (int)blockIdx.y, b = (int)blockIdx.z;
     const int x0 = gx * PX;
     f32x4 wr[9];
 #pragma unroll

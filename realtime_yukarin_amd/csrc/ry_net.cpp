@@ -816,8 +816,12 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         p.out = (lp.w32 || !p.out16) ? lp.out : nullptr;          // split-bf16 mode: the fp32 copy only if a consumer reads it
         p.x3 = lp.o16x3 ? 1 : 0;
         p.B = B; p.H = lp.Hi; p.W = lp.Wi; p.N = l.cout; p.act = l.act; p.slope = slope;
-        const long long total = (long long)B * lp.Hi * ((lp.Wi + 3) / 4) * (l.cout / 4);
-        dim3 grid((unsigned)((total + 255) / 256));
+        const int quads = l.cout / 4;
+        p.qshift = -1;
+        for (int sh = 0; sh < 16; ++sh) if ((1 << sh) == quads) p.qshift = sh;
+        const long long per_row = (long long)((lp.Wi + 3) / 4) * quads;
+        dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)lp.Hi, (unsigned)B);
+        if (grid.y > 65535u || grid.z > 65535u) return fail(RY_EINVAL, "%s: %u rows x %u windows exceed the grid limit", l.name, grid.y, grid.z);
         RY_TRY(Lc.begin("ry_sr_first", l.name, lp.flops, lp.bytes, grid));
         RY_LAUNCH((ry_sr_first<4>), grid, 256, Lc.stream, p);
         RY_TRY(Lc.end());
