@@ -394,6 +394,9 @@ template <int V> struct RyConst { static constexpr int value = V; };
 #ifndef RY_BF16_ISSUE_STEPS
 #define RY_BF16_ISSUE_STEPS 1
 #endif
+#ifndef RY_F32_FRAG_PREFETCH
+#define RY_F32_FRAG_PREFETCH 0    // 1: experiment -- LDS fragments of K step s + 1 requested before the MFMAs of step s (fp32 patch loops)
+#endif
 #ifndef RY_F32_ISSUE_STEPS
 #define RY_F32_ISSUE_STEPS 4      // fp32: the DMA pieces of the next chunk are spread over this many of the 4 K steps of the current one
 #endif
@@ -747,9 +750,34 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
                     for (int q = (s * AI) / ISL; q < ((s + 1) * AI) / ISL; ++q) patch_item(q, An);
                 }
             };
+#if RY_F32_FRAG_PREFETCH
+            // experiment: the LDS fragments of K step s + 1 are requested before the MFMAs of step s (a second register set)
+            f32x4 afp[2][TM], bfp[2][TN];
+            auto ldfrag = [&](int s_, int set) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int pr = pbase[i] + TAPOFF;
+                    afp[set][i] = ry_ld4(Ac + pr * BK + (((2 * s_ + lh) ^ ((pr >> 1) & 7)) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfp[set][j] = ry_ld4(Bc + ((wn * TN + j) * 4 + s_) * 256 + lane * 4);
+            };
+            if (!BF16) ldfrag(0, 0);
+#endif
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 f32x4 af[TM], bf[TN];
+#if RY_F32_FRAG_PREFETCH
+                if (!BF16) {
+                    if (s + 1 < NS) ldfrag(s + 1, (s + 1) & 1);
+                    ry_sched_fence();
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = afp[s & 1][i];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[j] = bfp[s & 1][j];
+                } else
+#endif
+                {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int pr = pbase[i] + TAPOFF;
@@ -757,6 +785,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(Bc + ((wn * TN + j) * 4 + s) * 256 + lane * 4);
+                }
                 issue(s);
                 if (BF16) {
 #pragma unroll

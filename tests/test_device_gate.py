@@ -110,6 +110,36 @@ def test_mirror_voice_changer_takes_the_device_gate(emu_ctx, monkeypatch, tmp_pa
     assert float(numpy.abs(dev.sp / host.sp - 1).max()) < 1e-5
 
 
+def _fixtures_against(ctx):
+    import glob
+    from pathlib import Path
+    core, n1, n2 = make_core(ctx, 'SYN-8')
+    files = sorted(glob.glob(str(Path(__file__).resolve().parent / 'golden' / 'gate' / '*.npz')))
+    checked = 0
+    for f in files:
+        z = numpy.load(f)
+        n = int(z['n_frames'])
+        feat = numpy.zeros((n, 9), numpy.float32)
+        for key in z.files:
+            if not key.startswith('abs_'):
+                continue                                           # the device gate restates the absolute form
+            _, thr, fft = key.split('_')
+            eff, _, rows = core.gate(z['wave'], HOP, int(fft[3:]), *gate.thresholds(int(thr[3:])), feat)
+            assert numpy.array_equal(eff, z[key]) and numpy.array_equal(rows, numpy.nonzero(z[key])[0]), (f, key)
+            checked += 1
+    core.close(); n1.close(); n2.close()
+    return checked
+
+
+def test_device_gate_matches_the_committed_fixtures_emu(emu_ctx):
+    assert _fixtures_against(emu_ctx) == 40
+
+
+@pytest.mark.gpu
+def test_device_gate_matches_the_committed_fixtures_gpu(gpu_ctx):
+    assert _fixtures_against(gpu_ctx) == 40
+
+
 @pytest.mark.gpu
 def test_device_gate_masks_are_bit_equal_gpu(gpu_ctx):
     assert run_all(gpu_ctx, 'SYN-8') > 160

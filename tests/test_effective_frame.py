@@ -108,3 +108,24 @@ def test_bad_reference_name_is_refused(monkeypatch):
     monkeypatch.setenv('RY_EFFECTIVE_REF', 'peak')
     with pytest.raises(ValueError, match='RY_EFFECTIVE_REF'):
         shim_mask(numpy.ones(400, numpy.float32), 60, None)
+
+
+def test_shim_matches_the_committed_gate_fixtures():
+    """tests/golden/gate/*.npz (made by tests/golden/make_gate_golden.py from the oracle): a committed target independent of the oracle code."""
+    import glob
+    from pathlib import Path
+    files = sorted(glob.glob(str(Path(__file__).resolve().parent / 'golden' / 'gate' / '*.npz')))
+    assert len(files) == 5
+    for f in files:
+        z = numpy.load(f)
+        for key in z.files:
+            if key in ('wave', 'n_frames'):
+                continue
+            ref, thr, fft = key.split('_')
+            got = shim_mask_fft(z['wave'], int(thr[3:]), ref, int(fft[3:]))
+            assert numpy.array_equal(got[:int(z['n_frames'])], z[key]), (f, key)
+
+
+def shim_mask_fft(wave, thr, ref, fft):
+    from yukarin import Wave
+    return Wave(wave=wave, sampling_rate=FS).get_effective_frame(threshold_db=thr, fft_length=fft, frame_period=FP, ref=ref)
