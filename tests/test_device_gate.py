@@ -110,6 +110,31 @@ def test_mirror_voice_changer_takes_the_device_gate(emu_ctx, monkeypatch, tmp_pa
     assert float(numpy.abs(dev.sp / host.sp - 1).max()) < 1e-5
 
 
+def _long_window(ctx):
+    """More than 1024 frames: the compaction workgroup walks the window in chunks of 1024 and carries the running count."""
+    core, n1, n2 = make_core(ctx, 'SYN-8')
+    rng = numpy.random.default_rng(9)
+    n = 2500
+    w = (0.1 * rng.normal(size=n * HOP)).astype(numpy.float32)
+    for a, b in ((100, 400), (1000, 1100), (1500, 2300)):
+        w[a * HOP:b * HOP] *= 1e-5
+    feat = rng.normal(size=(n + 1, 9)).astype(numpy.float32)
+    want = oef.separate_effective_mask(w, FS, n + 1, 60, 1024, FP, 'abs')
+    eff, x_eff, rows = core.gate(w, HOP, 1024, *gate.thresholds(60), feat)
+    assert numpy.array_equal(eff, want) and numpy.array_equal(rows, numpy.nonzero(want)[0]) and numpy.array_equal(x_eff, feat[want])
+    assert 1000 < want.sum() < 2000
+    core.close(); n1.close(); n2.close()
+
+
+def test_device_gate_long_window_emu(emu_ctx):
+    _long_window(emu_ctx)
+
+
+@pytest.mark.gpu
+def test_device_gate_long_window_gpu(gpu_ctx):
+    _long_window(gpu_ctx)
+
+
 def _fixtures_against(ctx):
     import glob
     from pathlib import Path
