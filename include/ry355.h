@@ -188,6 +188,9 @@ typedef struct ry_kernel_stat {
 } ry_kernel_stat;
 /* Runs the forward `reps` times launch by launch, bracketing every kernel with HIP events. */
 int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats);
+/* The same for the convert wrapper on ONE window of n_frames (what ry_ac_convert / ry_sr_convert / the ry_vc_* window call run:
+ * pad kernel, layers, fused crop; stage 2 skips the decoder rows that only feed the padding the wrapper throws away). */
+int ry_net_profile_window(ry_net* net, int n_frames, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats);
 
 /* diagnostics (RY_TIMING=1 only): per-phase shader-clock totals of ry_igemm_f32, summed over waves; reads and resets */
 int ry_debug_igemm_phases(ry_ctx* ctx, unsigned long long* out8);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     'ry_init', 'ry_shutdown', 'ry_sync', 'ry_stream', 'ry_device_count', 'ry_last_error',
     'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_set_dtype', 'ry_net_forward',
     'ry_ac_convert', 'ry_sr_convert', 'ry_conv1d', 'ry_conv2d', 'ry_conv2d_dilated',
-    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_debug_igemm_phases', 'ry_debug_plan_igemm', 'ry_debug_plan_igemm_bf16',
+    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_net_profile_window', 'ry_debug_igemm_phases', 'ry_debug_plan_igemm', 'ry_debug_plan_igemm_bf16',
     'ry_vc_create', 'ry_vc_destroy', 'ry_vc_convert', 'ry_mc2sp',
     'ry_vc_submit', 'ry_vc_wait', 'ry_vc_enqueue_device', 'ry_vc_stage1', 'ry_vc_stage2_from_mc', 'ry_vc_mid_sp', 'ry_vc_reserve_frames',
     'ry_vc_submit_wave', 'ry_vc_wait_wave', 'ry_vc_gate',
@@ -129,6 +129,7 @@ class Ry355Lib(object):
         d.ry_timer_stop.argtypes = [_VP, ctypes.POINTER(ctypes.c_float)]
         d.ry_net_profile.argtypes = [_VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RyKernelStat),
                                      ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        d.ry_net_profile_window.argtypes = [_VP, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RyKernelStat), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
 
     def check(self, rc):
         if rc != 0:

@@ -369,6 +369,8 @@ struct LayerPlan {
     bool x3 = false;                          // PATH_IGEMM_BF16 in split-bf16 form: sources are [pixel][hi | lo], K = [hi | lo | hi] x filters [hi | hi | lo]
     bool o16x3 = false;                       // format of the out16 copy this layer writes: plain bf16 or split [hi | lo]
     float* slabs = nullptr;
+    int crop_hi = 0;                          // > 0 (set per enqueue, one window): the layer runs on the first crop_hi input rows only -- the rows behind them feed nothing but
+                                              // output rows the convert wrapper throws away (dead padding rows, see enqueue_forward)
     int last_rows = 0, last_cols = 0, last_exp = 0;   // PATH_LAST: fused exp / edge-pad / crop
     bool last_x3 = false;                     // PATH_LAST in split-bf16 mode: reads the producers' [hi | lo] copies instead of fp32 ones
     double flops = 0, bytes = 0;
@@ -499,8 +501,9 @@ static void fill_geom(RyConvGeom& g, const Layer& l, const LayerPlan& lp, int B,
     g.src1 = s1; g.src2 = s2; g.C1 = C1; g.C2 = C2; g.S1 = C1; g.S2 = C2;
     if (lp.path == PATH_IGEMM_BF16 && lp.x3) { g.C1 = 3 * C1; g.C2 = 3 * C2; g.S1 = 2 * C1; g.S2 = 2 * C2; }   // K = [hi | lo | hi(wrapped)] over [hi | lo] pixels
     g.B = B; g.Hi = lp.Hi; g.Wi = lp.Wi; g.Ho = lp.Ho; g.Wo = lp.Wo;
-    if (l.deconv) { g.Mh = lp.Hi; g.Mw = lp.Wi; g.stride = 1; g.pad = 0; g.ostride = 2; }
-    else { g.Mh = lp.Ho; g.Mw = lp.Wo; g.stride = l.stride; g.pad = l.pad; g.ostride = 1; }
+    if (lp.crop_hi > 0) { g.Hi = lp.crop_hi; g.Ho = l.deconv ? 2 * lp.crop_hi : lp.crop_hi; }   // B == 1: a row prefix of the same buffers; rows from crop_hi on read as padding
+    if (l.deconv) { g.Mh = g.Hi; g.Mw = lp.Wi; g.stride = 1; g.pad = 0; g.ostride = 2; }
+    else { g.Mh = g.Ho; g.Mw = lp.Wo; g.stride = l.stride; g.pad = l.pad; g.ostride = 1; }
     g.nphases = t.nphases; g.ntaps = t.ntaps; g.N = l.cout; g.kw = l.deconv ? 2 : l.k; g.dil = l.deconv ? 1 : l.dil;
     const size_t esize = lp.path == PATH_IGEMM_BF16 ? 2 : 4;                  // implicit-GEMM sources end in a zeroed tail (ZTAIL floats)
     g.zoff1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * g.S1 * esize); g.zoff2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * g.S2 * esize);
@@ -524,6 +527,7 @@ static void tile_dims(int tile, int* bm, int* bn) {
 
 
 static int g_vc_stagger = 1;  // RY_VC_STAGGER=0: stage 1 of the next window starts at once instead of under the bottom layers of the previous window's stage 2
+static int g_s2_crop = 1;     // RY_S2_CROP=0: every decoder layer of the convert wrapper computes all padded rows (A/B of the dead-row crop); 2: crop one-round grids too
 static int g_last_band = 1;   // RY_LAST_BAND=0: raster-order workgroups in ry_sr_last (A/B of the per-XCD row bands)
 static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
@@ -797,7 +801,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             r.slabs = lp.slabs; r.splits = lp.splits; r.slab_stride = p.slab_stride;
             r.scale = l.scale; r.shift = l.shift; r.out = lp.w32 ? lp.out : nullptr; r.out16 = lp.w16 ? lp.out16 : nullptr;
             r.x3 = lp.o16x3 ? 1 : 0;
-            r.total = p.slab_stride; r.N = l.cout;
+            r.total = (long long)B * g.Ho * lp.Wo * l.cout; r.N = l.cout;      // the rows this launch wrote (all of them unless cropped)
             r.act = l.act; r.slope = slope;
             if (lp.splits >= 16 && r.total <= (1 << 20)) {      // many slabs, few outputs
                 dim3 rg((unsigned)((r.total / 4 + 63) / 64));
@@ -1212,6 +1216,39 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
         else RY_LAUNCH(ry_pad_min_rows<16>, pg, 256, Lc.stream, q);
         RY_TRY(Lc.end());
     }
+    // Stage 2, convert wrapper, one window: the wrapper pads the window to T rows and keeps n_frames of the result
+    // (SuperResolution.convert crops), so the last layer reads rows [0, n_frames + 1) of decoder c6 and nothing ever reads the
+    // rows behind them.  Walking back through the decoder: R correct output rows of a k4 s2 p1 deconvolution need input rows
+    // [0, ceil((R + 1) / 2)) (output row 2m + 1 takes input row m + 1).  Rows are the outermost axis of the NHWC buffers, so a
+    // layer simply runs on a row prefix of the same buffers (LayerPlan::crop_hi; the first dropped row reads as zero padding, which
+    // only reaches rows that are not needed).  The encoder feeds the bottom of the U-Net and stays whole.
+    int crop[16];
+    for (int i = 0; i < 16; ++i) crop[i] = 0;
+    if (nd == 2 && B == 1 && P.mode == 1 && g_s2_crop && P.lp[15].path == PATH_LAST && net->layers[15].src_a == 14) {
+        int need = P.n_frames + 1;                                   // correct rows wanted from layer i's output
+        for (int i = 14; i >= 8; --i) {
+            const Layer& l = net->layers[i];
+            const LayerPlan& lp = P.lp[i];
+            if (need >= lp.Ho) break;
+            if (lp.path != PATH_IGEMM && lp.path != PATH_IGEMM_BF16) break;
+            if (l.src_a != i - 1) break;
+            int rows;
+            if (l.deconv) rows = (need + 2) / 2;                    // ceil((need + 1) / 2)
+            else if (l.k == 1 && l.stride == 1) rows = need;
+            else break;
+            int bm, bn; tile_dims(lp.tile, &bm, &bn);
+            const int Mw = l.deconv ? lp.Wi : lp.Wo, Mh = l.deconv ? lp.Hi : lp.Ho;
+            for (int tw = 16; tw >= 4; tw >>= 1)                      // keep the 2-D pixel tiles of launch_conv2d: whole tile rows
+                if (bm % tw == 0 && Mw % tw == 0 && Mh % (bm / tw) == 0) { const int th = bm / tw; rows = (rows + th - 1) / th * th; break; }
+            if (rows >= lp.Hi) break;
+            // measured at 300 frames (scripts/gpu_r2_ab3.sh): decoder c6 (1536 -> 1216 workgroups, six per CU -> five) 208 -> 177 us, decoder c5
+            // (512 -> 416, two per CU) 198 -> 193 us, decoder c4 (256 -> 224, one per CU) 196 -> 194 us: a grid of one workgroup per
+            // CU gains nothing and only leaves CUs idle, so it runs whole (RY_S2_CROP=2 crops it too)
+            const long wgs = (long)((Mh * Mw + bm - 1) / bm) * (l.cout / bn) * (l.deconv ? 4 : 1) * lp.splits;
+            if (g_s2_crop >= 2 || wgs > 256) { crop[i] = rows; need = rows; }
+            else need = lp.Hi;                                       // this layer runs whole: it reads every row of its producer
+        }
+    }
     for (int i = lo; i < hi; ++i) {
         const Layer& l = net->layers[i];
         const LayerPlan& lp = P.lp[i];
@@ -1231,6 +1268,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
             LayerPlan lq = lp;
             if (i == 15 && (P.mode == 0 || lp.path == PATH_LAST)) lq.out = P.cur_out;   // last layer writes the caller's block
             if (i == 15 && P.mode == 1 && lp.path == PATH_LAST) lq.last_rows = P.n_frames;
+            if (crop[i] > 0) { lq.crop_hi = crop[i]; lq.flops = lp.flops * crop[i] / lp.Hi; lq.bytes = lp.bytes * crop[i] / lp.Hi; }
             RY_TRY(launch_conv2d(Lc, l, lq, B, s1, l.cin_a, s2, l.cin_b, slope));
         }
     }
@@ -1499,6 +1537,7 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_PLAN_X3_KG2")) g_x3_kg2 = atof(e);
     if (const char* e = getenv("RY_XCD_GROUPS")) g_xcd_groups = atoi(e);
     if (const char* e = getenv("RY_LAST_BAND")) g_last_band = atoi(e);
+    if (const char* e = getenv("RY_S2_CROP")) g_s2_crop = atoi(e);
     if (const char* e = getenv("RY_VC_STAGGER")) g_vc_stagger = atoi(e);
     if (const char* e = getenv("RY_S1_OS")) g_s1_os = atoi(e);
     if (const char* e = getenv("RY_S1_PADFUSE")) g_s1_padfuse = atoi(e);
@@ -1758,13 +1797,26 @@ int ry_sr_convert(ry_net* net, const float* sp, float* out, int batch, int n_fra
     return convert_common(net, 2, sp, out, batch, n_frames, on_device);
 }
 
+static int profile_plan(ry_net* net, Plan* P, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats);
+
 int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats) {
     if (!net || !stats || !n_stats || reps < 1) return fail(RY_EINVAL, "bad argument");
     Plan* P = nullptr;
     RY_TRY(get_plan(net, batch, frames, 0, 0, &P));
+    return profile_plan(net, P, reps, stats, max_stats, n_stats);
+}
+
+int ry_net_profile_window(ry_net* net, int n_frames, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats) {
+    if (!net || !stats || !n_stats || reps < 1 || n_frames < 1) return fail(RY_EINVAL, "bad argument");
+    Plan* P = nullptr;
+    RY_TRY(get_plan(net, 1, n_frames + (128 - n_frames % 128), 1, n_frames, &P));
+    return profile_plan(net, P, reps, stats, max_stats, n_stats);
+}
+
+static int profile_plan(ry_net* net, Plan* P, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats) {
     ry_ctx* ctx = net->ctx;
     RT_TRY(rt::set_device(ctx->device));
-    if (!P->cur_in) { P->cur_in = P->user_in; P->cur_out = P->user_out; }
+    P->cur_in = P->user_in; P->cur_out = P->user_out;        // the plan's own staging: whatever the caller's last blocks were, they may be gone
     std::vector<KernelRec> rec;
     std::vector<double> total;
     for (int r = 0; r < reps; ++r) {

@@ -330,10 +330,15 @@ class Net(object):
         fn = self.ctx.lib.dll.ry_ac_convert if self.desc.ndim == 1 else self.ctx.lib.dll.ry_sr_convert
         self.ctx.lib.check(fn(self.handle, _lib._fptr(int(x_ptr)), _lib._fptr(int(y_ptr)), batch, n_frames, 1))
 
-    def profile(self, batch: int, frames: int, reps: int = 5) -> List[dict]:
+    def profile(self, batch: int, frames: int, reps: int = 5, window: bool = False) -> List[dict]:
+        """Per-launch timings of the raw forward at `frames` padded rows, or (window=True) of the convert wrapper on one window
+        of `frames` real frames -- what the window call runs."""
         stats = (_lib.RyKernelStat * 96)()
         n = ctypes.c_int()
-        self.ctx.lib.check(self.ctx.lib.dll.ry_net_profile(self.handle, batch, frames, reps, stats, 96, ctypes.byref(n)))
+        if window:
+            self.ctx.lib.check(self.ctx.lib.dll.ry_net_profile_window(self.handle, frames, reps, stats, 96, ctypes.byref(n)))
+        else:
+            self.ctx.lib.check(self.ctx.lib.dll.ry_net_profile(self.handle, batch, frames, reps, stats, 96, ctypes.byref(n)))
         return [dict(name=stats[i].name.decode(), layer=stats[i].layer.decode(), ms=float(stats[i].ms),
                      flops=float(stats[i].flops), bytes=float(stats[i].bytes), grid=tuple(stats[i].grid))
                 for i in range(n.value)]

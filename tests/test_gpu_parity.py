@@ -130,6 +130,29 @@ def test_stage2_syn64_convert(syn64, n_frames):
     assert numpy.array_equal(y[:, -1], y[:, -2]), "pad(mode='edge') repeats the last predicted bin"
 
 
+@pytest.mark.parametrize('n_frames', [300, 100, 257, 383, 600])
+def test_stage2_dead_row_crop_is_bit_identical(syn64, gpu_ctx, monkeypatch, n_frames):
+    """Decoder layers of a single padded window skip the rows that only feed the padding `SuperResolution.convert` crops away
+    (DESIGN.md 4.1b): every kept element must be bit-identical to the run that computes all padded rows, whichever layers are cropped
+    (1 = only the layers it speeds up, the default; 2 = every decoder layer the rule allows)."""
+    import ctypes
+    _, (n2, _) = syn64
+    sp = synth.stage2_input(n_frames)[0]
+    reread = lambda: gpu_ctx.lib.check(gpu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    try:
+        out = {}
+        for mode in ('0', '1', '2'):
+            monkeypatch.setenv('RY_S2_CROP', mode); reread()
+            n2.set_dtype('f32')                                         # drops the launch plans and the graphs captured under the previous setting
+            out[mode] = n2.convert(sp)                                  # launch by launch
+            out[mode + 'g'] = [n2.convert(sp) for _ in range(2)][-1]    # graph replay
+        for k in out:
+            assert numpy.array_equal(out[k], out['0']), (n_frames, k)
+    finally:
+        monkeypatch.delenv('RY_S2_CROP', raising=False)
+        reread(); n2.set_dtype('f32')
+
+
 def test_stage2_syn64_against_the_c_restatement(syn64):
     """Full-size stage 2 against the plain-C loop nests (oracle/ops_ref.c), float and double sums: the HIP path sits as close
     to the double-sum result as the fp32 CPU restatement does."""

@@ -187,6 +187,34 @@ def test_stage2_x3_pipeline_emu(emu_ctx, monkeypatch):
     net.close()
 
 
+def test_stage2_dead_row_crop_emu(emu_ctx, monkeypatch):
+    """The convert wrapper keeps n_frames rows of a window padded to a multiple of 128: decoder layers may skip the rows that only
+    feed the discarded padding (LayerPlan::crop_hi).  Same arithmetic on the rows that are kept: results are bit-identical to the
+    uncropped run, for every n_frames, and stay on the oracle."""
+    import ctypes
+    d = NetDesc(2, 1, 1, 64, 3)
+    P = synthetic_params(d, 433, bias_std=0.05)
+    net = engine.Net(emu_ctx, d, flatten_params(d, P), width=16)
+    reread = lambda: emu_ctx.lib.check(emu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    try:
+        for n in (11, 30, 127):
+            sp = numpy.exp(numpy.random.default_rng(40 + n).normal(-6.0, 1.5, (n, 17))).astype('f4')
+            monkeypatch.setenv('RY_S2_CROP', '0'); reread()
+            whole = net.convert(sp)
+            g_whole = {q['layer']: q['grid'] for q in net.profile(1, n, 1, window=True)}
+            monkeypatch.setenv('RY_S2_CROP', '2'); reread()
+            cropped = net.convert(sp)
+            g_crop = {q['layer']: q['grid'] for q in net.profile(1, n, 1, window=True)}
+            assert numpy.array_equal(whole, cropped), n
+            assert float(numpy.abs(cropped / unet.stage2_convert(sp, P, 3) - 1).max()) < cases.TOL
+            fewer = [k for k in g_whole if g_crop[k][0] < g_whole[k][0]]
+            assert ('decoder/c6' in fewer) == (n < 100) and all(k.startswith('decoder/') for k in fewer), (n, fewer)     # 127 frames: every row of decoder c6 is needed
+    finally:
+        monkeypatch.delenv('RY_S2_CROP', raising=False)
+        reread()
+    net.close()
+
+
 def test_autotuned_plans_stay_correct_emu(emu_ctx, monkeypatch):
     """RY_AUTOTUNE=1 (opt-in): candidate launch plans of every implicit-GEMM layer are run on the device when a plan is built and
     the fastest replaces the planner's pick.  The emulator has no clock, so RY_AUTOTUNE_PICK forces a non-default candidate per
