@@ -126,6 +126,12 @@ int ry_vc_wait(ry_vc* vc, int ticket, float* mc_out, float* sp_out);
  * window i + 1 runs on its stream under stage-2 of window i.  bench.py times this. */
 int ry_vc_enqueue_device(ry_vc* vc, const float* x_eff_dev, const int* row_of_dev, int n_eff, int n_frames, float sp_floor,
                          float* mc_out_dev, float* sp_out_dev);
+/* Several independent windows of n_frames each in one call (streams served side by side; the backlog of run.py's queue): x_eff_dev /
+ * row_of_dev hold the effective rows / row maps of the windows one after the other (sum of n_eff[] rows), n_eff is a HOST array of
+ * n_windows counts, mc_out_dev [n_windows][n_frames][order+1], sp_out_dev [n_windows][n_frames][bins].  Stage 2 runs as one batch.
+ * Window w of the result equals ry_vc_enqueue_device on that window up to summation order (the batch may run under another launch plan). */
+int ry_vc_enqueue_device_batch(ry_vc* vc, int n_windows, const float* x_eff_dev, const int* row_of_dev, const int* n_eff, int n_frames,
+                               float sp_floor, float* mc_out_dev, float* sp_out_dev);
 /* The chain cut where the reference's own class cuts it, so that its unchanged step-by-step calls (voice_changer.py:33-41) keep
  * the data on the device between the two CNNs:
  *   ry_vc_stage1         `acoustic_converter.convert(f_in_effective)`: x_eff [n_eff][in_ch] -> y1_out [n_eff][order+1]; the rows

@@ -80,6 +80,7 @@ struct RyConvGeom {
     int S1, S2;                 // LDS-DMA kernel: elements per pixel of each source (= C1 / C2, except in the split-bf16 mode where a pixel
                                 // keeps [hi | lo] = 2 C bf16 and the K axis runs over [hi | lo | hi] = 3 C: a channel offset past S wraps to 0)
     int B, Hi, Wi, Ho, Wo;
+    int Hs, Hos;                // rows per image IN MEMORY of the sources / the output (>= Hi / Ho: a launch may cover a row prefix of every image, see LayerPlan::crop_hi)
     int Mh, Mw;
     int stride, pad, ostride;
     int nphases, ntaps;
@@ -187,8 +188,8 @@ RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
         if (live) {
             yb = ry * g.stride - g.pad;
             xb = rx * g.stride - g.pad;
-            pb = b * g.Hi * g.Wi;
-            ob = (b * g.Ho + ry * g.ostride + pdy) * g.Wo + rx * g.ostride + pdx;
+            pb = b * g.Hs * g.Wi;
+            ob = (b * g.Hos + ry * g.ostride + pdy) * g.Wo + rx * g.ostride + pdx;
         }
         rY[r] = yb; rX[r] = xb; rP[r] = pb; rO[r] = ob;
     }
@@ -517,8 +518,8 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
         if (live) {
             yb = ry * g.stride - g.pad;
             xb = rx * g.stride - g.pad;
-            pb = b * g.Hi * g.Wi;
-            ob = (b * g.Ho + ry * g.ostride + pdy) * g.Wo + rx * g.ostride + pdx;
+            pb = b * g.Hs * g.Wi;
+            ob = (b * g.Hos + ry * g.ostride + pdy) * g.Wo + rx * g.ostride + pdx;
         }
         rY[r] = yb; rX[r] = xb; rP[r] = pb; rO[r] = ob;
     }
@@ -549,7 +550,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
             const int iy = oy0 + PS * py, ix = ox0 + PS * px;
             const bool ok = pr < PR && bimg < g.B;
             const int ce = (dpos ^ ((pr >> 1) & 7)) * ES;
-            const int pix = (bimg * g.Hi + iy) * g.Wi + ix;
+            const int pix = (bimg * g.Hs + iy) * g.Wi + ix;
             ayb[j] = ok ? iy : -(1 << 20); axb[j] = ix;
             aoff1[j] = ok ? pix * g.S1 + ce : 0;
             aoff2[j] = ok ? pix * g.S2 + ce : 0;
@@ -1009,7 +1010,7 @@ RY_KERNEL(256) void ry_conv_direct(RyDirectParams p) {
     for (int t = 0; t < g.ntaps; ++t) {
         const int iy = yb + g.tdy[phase][t], ix = xb + g.tdx[phase][t];
         if ((unsigned)iy >= (unsigned)g.Hi || (unsigned)ix >= (unsigned)g.Wi) continue;
-        const size_t pix = (size_t)(b * g.Hi + iy) * g.Wi + ix;
+        const size_t pix = (size_t)(b * g.Hs + iy) * g.Wi + ix;
         const float* w = p.wd + ((size_t)(phase * g.ntaps + t) * Ctot) * g.N + n;
         const float* s1 = g.src1 + pix * g.C1;
         for (int c = 0; c < g.C1; ++c) acc = fmaf(s1[c], w[(size_t)c * g.N], acc);
@@ -1019,7 +1020,7 @@ RY_KERNEL(256) void ry_conv_direct(RyDirectParams p) {
             for (int c = 0; c < g.C2; ++c) acc = fmaf(s2[c], w2[(size_t)c * g.N], acc);
         }
     }
-    const size_t ob = (size_t)(b * g.Ho + ry * g.ostride + g.pdy[phase]) * g.Wo + rx * g.ostride + g.pdx[phase];
+    const size_t ob = (size_t)(b * g.Hos + ry * g.ostride + g.pdy[phase]) * g.Wo + rx * g.ostride + g.pdx[phase];
     p.out[ob * g.N + n] = ry_act(fmaf(acc, p.scale[n], p.shift[n]), p.act, p.slope);
 }
 

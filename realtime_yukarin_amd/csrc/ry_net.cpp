@@ -501,7 +501,8 @@ static void fill_geom(RyConvGeom& g, const Layer& l, const LayerPlan& lp, int B,
     g.src1 = s1; g.src2 = s2; g.C1 = C1; g.C2 = C2; g.S1 = C1; g.S2 = C2;
     if (lp.path == PATH_IGEMM_BF16 && lp.x3) { g.C1 = 3 * C1; g.C2 = 3 * C2; g.S1 = 2 * C1; g.S2 = 2 * C2; }   // K = [hi | lo | hi(wrapped)] over [hi | lo] pixels
     g.B = B; g.Hi = lp.Hi; g.Wi = lp.Wi; g.Ho = lp.Ho; g.Wo = lp.Wo;
-    if (lp.crop_hi > 0) { g.Hi = lp.crop_hi; g.Ho = l.deconv ? 2 * lp.crop_hi : lp.crop_hi; }   // B == 1: a row prefix of the same buffers; rows from crop_hi on read as padding
+    g.Hs = lp.Hi; g.Hos = lp.Ho;
+    if (lp.crop_hi > 0) { g.Hi = lp.crop_hi; g.Ho = l.deconv ? 2 * lp.crop_hi : lp.crop_hi; }   // a row prefix of every image in the same buffers; rows from crop_hi on read as padding
     if (l.deconv) { g.Mh = g.Hi; g.Mw = lp.Wi; g.stride = 1; g.pad = 0; g.ostride = 2; }
     else { g.Mh = g.Ho; g.Mw = lp.Wo; g.stride = l.stride; g.pad = l.pad; g.ostride = 1; }
     g.nphases = t.nphases; g.ntaps = t.ntaps; g.N = l.cout; g.kw = l.deconv ? 2 : l.k; g.dil = l.deconv ? 1 : l.dil;
@@ -801,7 +802,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             r.slabs = lp.slabs; r.splits = lp.splits; r.slab_stride = p.slab_stride;
             r.scale = l.scale; r.shift = l.shift; r.out = lp.w32 ? lp.out : nullptr; r.out16 = lp.w16 ? lp.out16 : nullptr;
             r.x3 = lp.o16x3 ? 1 : 0;
-            r.total = (long long)B * g.Ho * lp.Wo * l.cout; r.N = l.cout;      // the rows this launch wrote (all of them unless cropped)
+            r.total = B == 1 ? (long long)g.Ho * lp.Wo * l.cout : p.slab_stride; r.N = l.cout;      // one window: only the rows this launch wrote (a prefix when cropped)
             r.act = l.act; r.slope = slope;
             if (lp.splits >= 16 && r.total <= (1 << 20)) {      // many slabs, few outputs
                 dim3 rg((unsigned)((r.total / 4 + 63) / 64));
@@ -1216,7 +1217,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
         else RY_LAUNCH(ry_pad_min_rows<16>, pg, 256, Lc.stream, q);
         RY_TRY(Lc.end());
     }
-    // Stage 2, convert wrapper, one window: the wrapper pads the window to T rows and keeps n_frames of the result
+    // Stage 2, convert wrapper: the wrapper pads every window to T rows and keeps n_frames of the result
     // (SuperResolution.convert crops), so the last layer reads rows [0, n_frames + 1) of decoder c6 and nothing ever reads the
     // rows behind them.  Walking back through the decoder: R correct output rows of a k4 s2 p1 deconvolution need input rows
     // [0, ceil((R + 1) / 2)) (output row 2m + 1 takes input row m + 1).  Rows are the outermost axis of the NHWC buffers, so a
@@ -1224,7 +1225,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
     // only reaches rows that are not needed).  The encoder feeds the bottom of the U-Net and stays whole.
     int crop[16];
     for (int i = 0; i < 16; ++i) crop[i] = 0;
-    if (nd == 2 && B == 1 && P.mode == 1 && g_s2_crop && P.lp[15].path == PATH_LAST && net->layers[15].src_a == 14) {
+    if (nd == 2 && P.mode == 1 && g_s2_crop && P.lp[15].path == PATH_LAST && net->layers[15].src_a == 14) {
         int need = P.n_frames + 1;                                   // correct rows wanted from layer i's output
         for (int i = 14; i >= 8; --i) {
             const Layer& l = net->layers[i];
@@ -1244,7 +1245,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
             // measured at 300 frames (scripts/gpu_r2_ab3.sh): decoder c6 (1536 -> 1216 workgroups, six per CU -> five) 208 -> 177 us, decoder c5
             // (512 -> 416, two per CU) 198 -> 193 us, decoder c4 (256 -> 224, one per CU) 196 -> 194 us: a grid of one workgroup per
             // CU gains nothing and only leaves CUs idle, so it runs whole (RY_S2_CROP=2 crops it too)
-            const long wgs = (long)((Mh * Mw + bm - 1) / bm) * (l.cout / bn) * (l.deconv ? 4 : 1) * lp.splits;
+            const long wgs = (long)(((long)B * Mh * Mw + bm - 1) / bm) * (l.cout / bn) * (l.deconv ? 4 : 1) * lp.splits;
             if (g_s2_crop >= 2 || wgs > 256) { crop[i] = rows; need = rows; }
             else need = lp.Hi;                                       // this layer runs whole: it reads every row of its producer
         }
@@ -1890,6 +1891,12 @@ struct ry_vc {
     int next_ticket = 0;
     int dev_count = 0;       // device-pointer calls (ry_vc_enqueue_device) take the slots round robin
     int split_eff = -1;      // ry_vc_stage1 left the converted rows of this many effective frames in slot 0's d_y1 (-1: nothing)
+    // several windows per call (ry_vc_enqueue_device_batch): their own intermediates, re-allocated when a larger batch arrives
+    Arena batch_bufs;
+    float *b_y1 = nullptr, *b_sp = nullptr;
+    size_t b_cap_y1 = 0, b_cap_sp = 0;
+    rt::Event b_mid, b_done;
+    bool b_ev = false, b_used = false;
     void free_pinned() { for (void* q : pinned) rt::hfree(q); pinned.clear(); }
 };
 
@@ -2005,6 +2012,7 @@ void ry_vc_destroy(ry_vc* vc) {
     rt::set_device(vc->s1->ctx->device);
     rt::stream_sync(vc->s1->stream); rt::stream_sync(vc->s2->stream);
     if (vc->has_ev) for (VcSlot& sl : vc->slot) { rt::event_destroy(sl.ev_mid); rt::event_destroy(sl.ev_done); }
+    if (vc->b_ev) { rt::event_destroy(vc->b_mid); rt::event_destroy(vc->b_done); }
     vc->free_pinned();
     delete vc;
 }
@@ -2205,6 +2213,82 @@ int ry_vc_enqueue_device(ry_vc* vc, const float* x_eff_dev, const int* row_of_de
     RY_TRY(ry_sr_convert(s2, sl.d_sp, sp_out_dev, 1, n_frames, 1));
     RT_TRY(rt::event_record(sl.ev_done, st2));
     sl.used = true;
+    vc->split_eff = -1;
+    return RY_OK;
+}
+
+// Several independent windows of the same length in one call (streams served side by side, or the backlog of run.py's queue): stage 1
+// runs as one batch when every window kept the same number of effective frames (else window by window), combine_silent per window,
+// decode_spectrogram over all rows at once, stage 2 as ONE batch -- its bottom layers stream their filters once for all windows and
+// every grid is many rounds of workgroups (measured at 300 frames: 1.28 ms for one window, 1.01 ms per window for eight).
+// x_eff_dev / row_of_dev: the effective rows / row maps of the windows one after the other (sum of n_eff rows); n_eff: host array.
+int ry_vc_enqueue_device_batch(ry_vc* vc, int n_windows, const float* x_eff_dev, const int* row_of_dev, const int* n_eff, int n_frames,
+                               float sp_floor, float* mc_out_dev, float* sp_out_dev) {
+    if (!vc || !n_eff || !mc_out_dev || !sp_out_dev) return fail(RY_EINVAL, "null argument");
+    if (n_windows < 1 || n_windows > 4096) return fail(RY_EINVAL, "n_windows must be in 1..4096 (got %d)", n_windows);
+    long long total_eff = 0;
+    bool same = true;
+    for (int w = 0; w < n_windows; ++w) {
+        RY_TRY(vc_check(vc, nullptr, n_eff[w], n_frames, false));
+        total_eff += n_eff[w];
+        if (n_eff[w] != n_eff[0]) same = false;
+    }
+    if (total_eff > 0 && (!x_eff_dev || !row_of_dev)) return fail(RY_EINVAL, "null argument");
+    ry_net *s1 = vc->s1, *s2 = vc->s2;
+    RT_TRY(rt::set_device(s1->ctx->device));
+    const int cin = s1->desc.in_ch, M = vc->M, F = vc->F;
+    ry_stream_t st1 = s1->stream, st2 = s2->stream;
+    if (!vc->b_ev) {
+        RT_TRY(rt::event_create_fast(&vc->b_mid)); RT_TRY(rt::event_create_fast(&vc->b_done));
+        vc->b_ev = true;
+    }
+    const size_t need_y1 = (size_t)(total_eff > 0 ? total_eff : 1) * M, need_sp = (size_t)n_windows * n_frames * F;
+    if (need_y1 > vc->b_cap_y1 || need_sp > vc->b_cap_sp) {
+        RT_TRY(rt::stream_sync(st1)); RT_TRY(rt::stream_sync(st2));       // queued work may still use the old buffers
+        vc->batch_bufs.release();
+        vc->b_cap_y1 = vc->b_cap_sp = 0;
+        RY_TRY(vc->batch_bufs.alloc(&vc->b_y1, need_y1));
+        RY_TRY(vc->batch_bufs.alloc(&vc->b_sp, need_sp));
+        vc->b_cap_y1 = need_y1; vc->b_cap_sp = need_sp;
+    }
+    if (vc->b_used) RT_TRY(rt::stream_wait_event(st1, vc->b_done));         // the previous batch has left b_sp
+    if (total_eff > 0) {
+        if (same) RY_TRY(ry_ac_convert(s1, x_eff_dev, vc->b_y1, n_windows, n_eff[0], 1));
+        else {
+            long long off = 0;
+            for (int w = 0; w < n_windows; ++w) {
+                if (n_eff[w] > 0) RY_TRY(ry_ac_convert(s1, x_eff_dev + off * cin, vc->b_y1 + off * M, 1, n_eff[w], 1));
+                off += n_eff[w];
+            }
+        }
+    }
+    {   // combine_silent per window (its own row map), then decode_spectrogram over the rows of all windows in one launch
+        Launcher Lc{s1, s1->ctx, st1, nullptr, nullptr};
+        RT_TRY(rt::dmemset(mc_out_dev, 0, (size_t)n_windows * n_frames * M * sizeof(float), st1));
+        long long off = 0;
+        for (int w = 0; w < n_windows; ++w) {
+            if (n_eff[w] > 0) {
+                RyScatterParams sc;
+                sc.src = vc->b_y1 + off * M; sc.row_of = row_of_dev + off; sc.dst = mc_out_dev + (size_t)w * n_frames * M; sc.n_src = n_eff[w]; sc.cols = M;
+                dim3 sg((unsigned)(((long long)n_eff[w] * M + 255) / 256));
+                RY_TRY(Lc.begin("ry_scatter_rows", "combine_silent", 0, 0, sg));
+                RY_LAUNCH(ry_scatter_rows, sg, 256, st1, sc);
+                RY_TRY(Lc.end());
+            }
+            off += n_eff[w];
+        }
+        RyMc2spParams mp;
+        mp.mc = mc_out_dev; mp.mtx = vc->d_mtx; mp.sp = vc->b_sp; mp.n = n_windows * n_frames; mp.m = M; mp.f = F; mp.floor = sp_floor;
+        dim3 mg((unsigned)(((long long)n_windows * n_frames * F + 255) / 256));
+        RY_TRY(Lc.begin("ry_mc2sp", "decode_spectrogram", 0, 0, mg));
+        RY_LAUNCH(ry_mc2sp, mg, 256, st1, mp);
+        RY_TRY(Lc.end());
+    }
+    RT_TRY(rt::event_record(vc->b_mid, st1));
+    RT_TRY(rt::stream_wait_event(st2, vc->b_mid));
+    RY_TRY(ry_sr_convert(s2, vc->b_sp, sp_out_dev, n_windows, n_frames, 1));
+    RT_TRY(rt::event_record(vc->b_done, st2));
+    vc->b_used = true;
     vc->split_eff = -1;
     return RY_OK;
 }

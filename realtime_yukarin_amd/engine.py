@@ -211,6 +211,42 @@ class VcCore(object):
             self.handle, _lib._fptr(int(x_ptr)), ctypes.cast(ctypes.c_void_p(int(rows_ptr)), ctypes.POINTER(ctypes.c_int)),
             int(n_eff), int(n_frames), float(sp_floor), _lib._fptr(int(mc_ptr)), _lib._fptr(int(sp_ptr))))
 
+    def enqueue_device_batch(self, x_ptr: int, rows_ptr: int, n_eff, n_frames: int, mc_ptr: int, sp_ptr: int, sp_floor: float = 1e-16):
+        """`ry_vc_enqueue_device_batch`: len(n_eff) windows of n_frames each, device pointers, nothing waited for."""
+        ne = numpy.ascontiguousarray(n_eff, dtype=numpy.int32)
+        self.lib.check(self.lib.dll.ry_vc_enqueue_device_batch(
+            self.handle, len(ne), _lib._fptr(int(x_ptr)), ctypes.cast(ctypes.c_void_p(int(rows_ptr)), ctypes.POINTER(ctypes.c_int)),
+            ne.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), int(n_frames), float(sp_floor), _lib._fptr(int(mc_ptr)), _lib._fptr(int(sp_ptr))))
+
+    def convert_batch(self, windows, sp_floor: float = 1e-16):
+        """Host arrays in and out for a list of (x_eff, effective) windows of ONE length: [(mc, sp), ...].  Plain (blocking) copies:
+        the call is for throughput on a backlog, not for latency."""
+        ctx = self.stage1.ctx
+        n, cin = len(windows[0][1]), self.stage1.desc.in_ch
+        xs, rows, ne = [], [], []
+        for x_eff, effective in windows:
+            nn, r = self._rows(effective)
+            if nn != n:
+                raise ValueError('convert_batch needs windows of one length (got %d and %d frames)' % (n, nn))
+            x_eff = numpy.ascontiguousarray(x_eff, dtype=numpy.float32)
+            if x_eff.shape[0] != len(r):
+                raise ValueError('%d effective rows for a mask with %d set frames' % (x_eff.shape[0], len(r)))
+            xs.append(x_eff.reshape(len(r), cin)); rows.append(r); ne.append(len(r))
+        W, tot = len(windows), int(sum(ne))
+        d_x = ctx.dev_alloc(max(tot, 1) * cin); d_r = ctx.dev_alloc(max(tot, 1)); d_mc = ctx.dev_alloc(W * n * self.M); d_sp = ctx.dev_alloc(W * n * self.F)
+        try:
+            if tot:
+                ctx.dev_upload(d_x, numpy.concatenate(xs))
+                ctx.dev_upload(d_r, numpy.concatenate(rows).astype(numpy.int32))
+            self.enqueue_device_batch(d_x, d_r, ne, n, d_mc, d_sp, sp_floor)
+            ctx.sync()
+            mc = numpy.empty((W, n, self.M), numpy.float32); sp = numpy.empty((W, n, self.F), numpy.float32)
+            ctx.dev_download(d_mc, mc); ctx.dev_download(d_sp, sp)
+        finally:
+            for q in (d_x, d_r, d_mc, d_sp):
+                ctx.dev_free(q)
+        return [(mc[w], sp[w]) for w in range(W)]
+
     # ---- the chain cut where the reference's own VoiceChanger cuts it (voice_changer.py:33-41)
     def convert_stage1(self, x_eff: numpy.ndarray) -> numpy.ndarray:
         """`AcousticConverter.convert` array part; the converted rows also stay on the device for `stage2_from_mc`."""

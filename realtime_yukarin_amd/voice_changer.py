@@ -108,7 +108,21 @@ class VoiceChanger(object):
 
     def convert_windows(self, f_ins: List) -> List:
         """Independent windows: stage-1 per window (its length is data dependent after the silence split),
-        stage-2 for all equal-length windows in one batched GPU call."""
+        stage-2 for all equal-length windows in one batched GPU call -- everything on the device when both converters are the MI355X shims."""
+        core = self._fused_core()
+        if core is not None and f_ins and len({len(f.mc) for f in f_ins}) == 1:
+            # device-resident: one call for all windows (`ry_vc_enqueue_device_batch`): stage 1 per window or as a batch, the hop between
+            # the CNNs on the device, stage 2 as one batch
+            ac = self.acoustic_converter
+            split = [ac.separate_effective(wave=f.wave, feature=f, threshold=self.threshold) for f in f_ins]
+            res = core.convert_batch([(numpy.asarray(f_eff.mc, dtype=numpy.float32), effective) for f_eff, effective in split], SP_FLOOR)
+            outs = []
+            for (f_eff, effective), (mc, sp) in zip(split, res):
+                f_out = ac.combine_silent(effective=effective, feature=self._passthrough(f_eff))
+                f_out.mc = mc
+                f_out.sp = sp
+                outs.append(f_out)
+            return outs
         outs = [self._stage1(f) for f in f_ins]
         lengths = {len(o.sp) for o in outs}
         sr = self.super_resolution

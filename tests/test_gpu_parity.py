@@ -140,14 +140,19 @@ def test_stage2_dead_row_crop_is_bit_identical(syn64, gpu_ctx, monkeypatch, n_fr
     sp = synth.stage2_input(n_frames)[0]
     reread = lambda: gpu_ctx.lib.check(gpu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
     try:
-        out = {}
+        out, out3 = {}, []
         for mode in ('0', '1', '2'):
             monkeypatch.setenv('RY_S2_CROP', mode); reread()
             n2.set_dtype('f32')                                         # drops the launch plans and the graphs captured under the previous setting
             out[mode] = n2.convert(sp)                                  # launch by launch
             out[mode + 'g'] = [n2.convert(sp) for _ in range(2)][-1]    # graph replay
+            if n_frames in (100, 300):                                  # three windows in one call: a row prefix of every image
+                out3.append(n2.convert(numpy.stack([sp, sp[::-1], sp])))
         for k in out:
             assert numpy.array_equal(out[k], out['0']), (n_frames, k)
+        for o in out3:
+            assert numpy.array_equal(o, out3[0]) and numpy.array_equal(o[2], o[0])
+            assert float(numpy.abs(o[0] / out['0'] - 1).max()) < 1e-5          # a batch may run under another plan: summation order only
     finally:
         monkeypatch.delenv('RY_S2_CROP', raising=False)
         reread(); n2.set_dtype('f32')

@@ -206,6 +206,13 @@ def test_stage2_dead_row_crop_emu(emu_ctx, monkeypatch):
             cropped = net.convert(sp)
             g_crop = {q['layer']: q['grid'] for q in net.profile(1, n, 1, window=True)}
             assert numpy.array_equal(whole, cropped), n
+            if n == 30:                                                 # two windows in one call: a row prefix of EVERY image
+                sp2 = numpy.stack([sp, sp[::-1]])
+                both = net.convert(sp2)
+                assert numpy.array_equal(both[0], cropped)
+                monkeypatch.setenv('RY_S2_CROP', '0'); reread()
+                assert numpy.array_equal(net.convert(sp2), both)
+                monkeypatch.setenv('RY_S2_CROP', '2'); reread()
             assert float(numpy.abs(cropped / unet.stage2_convert(sp, P, 3) - 1).max()) < cases.TOL
             fewer = [k for k in g_whole if g_crop[k][0] < g_whole[k][0]]
             assert ('decoder/c6' in fewer) == (n < 100) and all(k.startswith('decoder/') for k in fewer), (n, fewer)     # 127 frames: every row of decoder c6 is needed

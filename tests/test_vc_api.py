@@ -95,3 +95,30 @@ def test_stream_generator_depth(core):
         assert all(numpy.array_equal(g[1], r[1]) and numpy.array_equal(g[0], r[0]) for g, r in zip(got, ref))
     with pytest.raises(ValueError):
         list(core.convert_stream([], depth=4))
+
+
+def test_batch_call_equals_the_windows_one_by_one(core):
+    """`ry_vc_enqueue_device_batch` (several windows of one length per call: stage 2 as one batch): every window of the result is the
+    single-window call on that window -- ragged effective counts (stage 1 window by window), equal counts (stage 1 as one batch), an
+    all-silent window in the middle, and a bad argument is refused with a message."""
+    n = 20
+    ws = [window(n, 11), window(n, 12, keep=0.0), window(n, 13, keep=0.4)]
+    one = [core.convert(x[e], e) for x, e in ws]
+    got = core.convert_batch([(x[e], e) for x, e in ws])
+    for (mc, sp), (rmc, rsp) in zip(got, one):
+        assert numpy.array_equal(mc, rmc)
+        assert float(numpy.abs(sp / rsp - 1).max()) < 1e-5                   # the batch may run under another launch plan: summation order only
+    assert numpy.all(got[1][0] == 0)                                          # the all-silent window: zero mc rows (AcousticFeature.silent)
+    full = [(x, numpy.ones(n, bool)) for x, _ in ws[:2]]                      # equal effective counts: stage 1 runs as one batch
+    got = core.convert_batch(full)
+    for (mc, sp), (x, e) in zip(got, full):
+        rmc, rsp = core.convert(x, e)
+        assert float(numpy.abs(mc - rmc).max()) <= 1e-5 * float(numpy.abs(rmc).max())
+        assert float(numpy.abs(sp / rsp - 1).max()) < 1e-5
+    with pytest.raises(ValueError, match='one length'):
+        core.convert_batch([(ws[0][0][ws[0][1]], ws[0][1]), window(21, 5)])
+    ne = (ctypes.c_int * 2)(3, 99)
+    with pytest.raises(_lib.Ry355Error, match='bad frame counts'):
+        core.lib.check(core.lib.dll.ry_vc_enqueue_device_batch(core.handle, 2, None, None, ne, n, 1e-16, _lib._fptr(1 << 12), _lib._fptr(1 << 12)))
+    mc, sp = core.convert(ws[0][0][ws[0][1]], ws[0][1])                      # the handle is still usable
+    assert numpy.array_equal(mc, one[0][0]) and numpy.array_equal(sp, one[0][1])
