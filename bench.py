@@ -5,8 +5,9 @@ Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver 
 GPU, RCCL).  One "step" = one pass of the hot path over one window already resident in HBM, CHAINED as
 `VoiceChanger.convert_from_acoustic_feature` chains it (/root/reference/realtime_voice_conversion/yukarin_wrapper/voice_changer.py:
 33-41): effective frames -> stage-1 CNN -> combine_silent -> mc2sp (+1e-16) -> stage-2 CNN -> spectrogram in HBM
-(`ry_vc_enqueue_device`).  Consecutive steps pipeline two deep by themselves: stage-1 of window i + 1 runs on its stream under stage-2
-of window i, as it does for consecutive buffers of a live stream.  Default window: 300 frames = buffer_time 0.5 s + 2 x
+(`ry_vc_enqueue_device`).  Consecutive steps pipeline by themselves: the window call keeps up to six windows in flight over two
+pairs of predictor streams (`ry_vc_set_lanes`, `--lanes`, default 2; `--lanes 1` = one stage-2 forward after the other), as consecutive
+buffers of a live stream or the windows of run.py's queue would be.  Default window: 300 frames = buffer_time 0.5 s + 2 x
 convert_extra_time 0.5 s at 5 ms frames (/root/reference/config.yaml:14; BASELINE config #3).  Windows are independent, so N GPUs take
 N times the windows (weak scaling) with one RCCL broadcast of each weight blob at start-up and no collective in the timed region.
 Prints ONE JSON line on rank 0.
@@ -43,6 +44,7 @@ def parse(argv=None):
                     help='overlap frames on EACH side of the window that ConvertStream throws away (convert_stream.py:40-42); default 100 '
                          '(= convert_extra_time 0.5 s) for the 300-frame window, else 0')
     ap.add_argument('--windows', type=int, default=1, help='windows per GPU per step (converted one after the other)')
+    ap.add_argument('--lanes', type=int, default=None, help='windows that run side by side on their own predictor streams (ry_vc_set_lanes; default RY_VC_LANES or 2)')
     ap.add_argument('--model', default=None)
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'bf16x3'],
                     help="stage-2 MFMA operand type ('bf16' = BASELINE config #5; 'bf16x3' = split-bf16, DESIGN.md 4.7); the headline is f32")
@@ -93,6 +95,7 @@ def pmc_table():
 def main(argv=None):
     args = parse(argv)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC for RCCL / device-buffer sharing: before the HIP runtime comes up
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')             # one hardware queue per stream of the window lanes (realtime_yukarin_amd/_lib.py)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -145,7 +148,7 @@ def main(argv=None):
     if args.dtype != 'f32':
         net2.set_dtype(args.dtype)
     mtx = sptk.mc2sp_matrix(d1.out_ch - 1, sptk.mcepalpha(16000), 2 * (synth.FFT_BINS - 1))
-    core = engine.VcCore(net1, net2, mtx)
+    core = engine.VcCore(net1, net2, mtx, lanes=args.lanes)
 
     def sync_all():
         ctx.sync()
@@ -160,8 +163,11 @@ def main(argv=None):
         ctx.dev_upload(d_x[w], xs_host[w])
     d_rows = ctx.dev_alloc(N)
     ctx.dev_upload(d_rows, rows_host)
-    d_mc = [ctx.dev_alloc(N * d1.out_ch) for _ in range(Wn)]
-    d_sp = [ctx.dev_alloc(N * synth.FFT_BINS) for _ in range(Wn)]
+    # windows that are in flight together write their own result blocks (six ring slots)
+    NB = 6 * Wn
+    d_mc = [ctx.dev_alloc(N * d1.out_ch) for _ in range(NB)]
+    d_sp = [ctx.dev_alloc(N * synth.FFT_BINS) for _ in range(NB)]
+    turn = {'n': 0, 'w0': 0}
     sync_all()
 
     if args.profile_only:
@@ -185,7 +191,11 @@ def main(argv=None):
 
     def step():
         for w in range(Wn):
-            core.enqueue_device(d_x[w], d_rows, N, N, d_mc[w], d_sp[w], SP_FLOOR)
+            k = turn['n'] % NB
+            turn['n'] += 1
+            if w == 0:
+                turn['w0'] = k
+            core.enqueue_device(d_x[w], d_rows, N, N, d_mc[k], d_sp[k], SP_FLOOR)
 
     def fence():
         sync_all()
@@ -193,7 +203,14 @@ def main(argv=None):
             comm.barrier()
         sync_all()
 
+    primed = {'done': False}
+
     def timed():
+        # launch plans and captured graphs of every ring slot are built before the warm-up (one-off set-up, like loading the weights)
+        if not primed['done']:
+            for _ in range(2 * 6):
+                step()
+            primed['done'] = True
         # W untimed warm-up steps, then exactly K steps between barrier + synchronize fences; the maximum over the ranks
         for _ in range(args.warmup):
             step()
@@ -202,16 +219,18 @@ def main(argv=None):
         ctx.timer_start()
         for _ in range(args.steps):
             step()
-        dms = ctx.timer_stop()
         fence()
         el = time.perf_counter() - t0
+        # device-side stamp AFTER the fence: ry_timer_stop while the lanes still have work queued (an event record on every predictor
+        # stream plus cross-stream waits) was measured to cost the two lanes their overlap for the whole run (1.33 vs 1.16 ms per window)
+        dms = ctx.timer_stop()
         if comm is not None:
             el = comm.max(el)
         return el, dms
 
     elapsed, dev_ms = timed()
-    sp_gpu = numpy.empty((N, synth.FFT_BINS), numpy.float32); ctx.dev_download(d_sp[0], sp_gpu)
-    mc_gpu = numpy.empty((N, d1.out_ch), numpy.float32); ctx.dev_download(d_mc[0], mc_gpu)
+    sp_gpu = numpy.empty((N, synth.FFT_BINS), numpy.float32); ctx.dev_download(d_sp[turn['w0']], sp_gpu)      # window 0 of the last timed step
+    mc_gpu = numpy.empty((N, d1.out_ch), numpy.float32); ctx.dev_download(d_mc[turn['w0']], mc_gpu)
     assert numpy.isfinite(sp_gpu).all() and numpy.isfinite(mc_gpu).all() and (sp_gpu > 0).all()
 
     frames_total = world * Wn * N * args.steps
@@ -236,7 +255,8 @@ def main(argv=None):
                                '@16 kHz / 5 ms -> %d real frames (%d padded) per window, %d window(s) per GPU per step, %s random-init weights'
                                % (N, T, Wn, model),
                    'model': model, 'frames': N, 'padded_frames': T, 'windows_per_gpu': Wn,
-                   'parallelism': 'chunk-dp%d (independent windows, RCCL weight broadcast at init, no steady-state collective)' % world},
+                   'lanes_per_gpu': core.lanes,
+                   'parallelism': 'chunk-dp%d (independent windows, RCCL weight broadcast at init, no steady-state collective); %d window lane(s) per GPU' % (world, core.lanes)},
     }
 
     def time_only(fn, reps=20):
@@ -252,7 +272,7 @@ def main(argv=None):
         ctx.dev_upload(d_s2in, synth.stage2_input(N)[0])
         s1_ms = time_only(lambda: net1.convert_device(d_x[0], d_y1, 1, N))
         s2_ms = time_only(lambda: net2.convert_device(d_s2in, d_s2out, 1, N))
-        chain_ms = time_only(lambda: (core.enqueue_device(d_x[0], d_rows, N, N, d_mc[0], d_sp[0], SP_FLOOR), ctx.sync()))   # one window at a time: no overlap
+        chain_ms = time_only(lambda: (step(), ctx.sync())) / Wn   # one window at a time: no overlap
         out['graph_replay_ms'] = {'stage1_alone': round(s1_ms, 4), 'stage2_alone': round(s2_ms, 4), 'chain_one_window_synced': round(chain_ms, 4)}
         # live per-launch profile (HIP events around every launch of both predictors) for the roofline objects
         st2 = net2.profile(1, N, args.profile_reps, window=True)        # launch by launch, the convert wrapper on one window: what the step runs
@@ -271,23 +291,23 @@ def main(argv=None):
             del scratch
             # host windows (PCIe inclusive; never the headline): one at a time, and a stream with windows in flight through the pinned ring
             xh = xs_host[0]; eff = numpy.ones(N, bool)
-            for _ in range(3):
+            for _ in range(12):                                   # every ring slot has its launch plans and graphs
                 core.convert(xh, eff)
             th = time.perf_counter()
             for _ in range(20):
                 core.convert(xh, eff)
             host_ms = (time.perf_counter() - th) / 20 * 1e3
-            for _ in core.convert_stream([(xh, eff)] * 6, depth=3):
+            for _ in core.convert_stream([(xh, eff)] * 12, depth=6):
                 pass
             th = time.perf_counter()
-            for _ in core.convert_stream([(xh, eff)] * 60, depth=3):
+            for _ in core.convert_stream([(xh, eff)] * 60, depth=6):
                 pass
             stream_ms = (time.perf_counter() - th) / 60 * 1e3
             # the same call with the silence gate on the device (raw wave + all frames up; ry_vc_submit_wave)
             from realtime_yukarin_amd import gate
             wv32 = (0.1 * numpy.random.default_rng(1).normal(size=N * 80)).astype(numpy.float32)
             p_eff, p_all = gate.thresholds(60)
-            for _ in range(3):
+            for _ in range(12):
                 core.wait_wave(core.submit_wave(wv32, 80, 1024, p_eff, p_all, xh))
             th = time.perf_counter()
             for _ in range(20):
@@ -297,7 +317,7 @@ def main(argv=None):
                                 'call_with_device_gate_ms_per_window': round(gated_ms, 4),
                                 'stream_frames_per_s': round(N / (stream_ms * 1e-3), 1),
                                 'note': 'host arrays in, host arrays out through the pinned ring of ry_vc_submit / ry_vc_wait (PCIe inclusive): one window '
-                                        'at a time, and a stream with three windows in flight'}
+                                        'at a time, and a stream with six windows in flight'}
             # 8 windows per stage-1 call: the regime in which the filters are amortised (bytes per frame / 8)
             d_x8 = ctx.dev_alloc(8 * N * d1.in_ch); d_y8 = ctx.dev_alloc(8 * N * d1.out_ch)
             ctx.dev_upload(d_x8, synth.stage1_input(N, 8))
@@ -349,8 +369,9 @@ def main(argv=None):
         # the same K steps with stage-2 in split-bf16 mode -- reported BESIDE the exact-fp32 headline, never as `value` of an f32 run
         if args.dtype == 'f32' and not args.no_split_bf16 and not args.no_extras and world == 1:
             net2.set_dtype('bf16x3')
+            primed['done'] = False
             el3, _ = timed()
-            sp3 = numpy.empty_like(sp_gpu); ctx.dev_download(d_sp[0], sp3)
+            sp3 = numpy.empty_like(sp_gpu); ctx.dev_download(d_sp[turn['w0']], sp3)
             net2.set_dtype('f32')
             step(); sync_all()
             out['split_bf16'] = {'dtype': 'bf16x3', 'value': round(world * Wn * N * args.steps / el3, 1), 'unit': 'frames/s',

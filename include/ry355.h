@@ -69,6 +69,9 @@ size_t ry_net_param_count(const ry_net_desc* desc);
 int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, size_t n_floats,
                   int weights_on_device, ry_net** out);
 void ry_net_destroy(ry_net* net);
+/* A second handle on the same predictor: the filters are shared (freed with the last handle), the clone has its own stream, launch
+ * plans, activation buffers and captured graphs.  ry_net_set_dtype on one handle does not change the others. */
+int ry_net_clone(ry_net* net, ry_net** out);
 
 /* BASELINE config #5: dtype 1 runs the stage-2 implicit-GEMM layers with bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate,
  * bf16 activations between those layers; filters converted once).  dtype 2 ("split-bf16") runs them as three bf16 products per fp32
@@ -117,10 +120,15 @@ int ry_vc_convert(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, i
                   float* mc_out, float* sp_out);
 /* The same in two halves, for a convert loop that keeps several windows in flight (the live caller is the worker loop of
  * realtime_voice_conversion/worker/convert_worker.py:45-59: get -> convert -> put).  ry_vc_submit copies the window into a pinned
- * ring slot (three slots), queues H2D -> stage-1 -> combine_silent -> mc2sp -> stage-2 -> D2H on the two predictor streams and returns
+ * ring slot (six slots), queues H2D -> stage-1 -> combine_silent -> mc2sp -> stage-2 -> D2H on the two predictor streams and returns
  * a ticket WITHOUT waiting; ry_vc_wait blocks for that ticket and copies the results out.  H2D of window i + 1 and D2H of window i - 1
  * run under the kernels of window i.  ry_vc_convert == submit + wait.  RY_ESTATE when all slots are in flight. */
 int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, int n_frames, float sp_floor, int* ticket);
+/* Lanes: with `lanes` = 2 or 3 the ring slots run on their own predictor handles (ry_net_clone of the pair given to ry_vc_create: one
+ * copy of the filters, separate streams / launch plans / activations), so that the windows in flight execute side by side instead of
+ * one stage-2 forward after the other.  Same results.  Device-pointer callers (ry_vc_enqueue_device) must then give windows that are in
+ * flight together their own output blocks.  No ticket may be in flight when the lane count changes.  Default 1. */
+int ry_vc_set_lanes(ry_vc* vc, int lanes);
 int ry_vc_wait(ry_vc* vc, int ticket, float* mc_out, float* sp_out);
 /* All pointers on the device, nothing waited for (ry_sync / your own event): consecutive calls pipeline by themselves -- stage-1 of
  * window i + 1 runs on its stream under stage-2 of window i.  bench.py times this. */
@@ -197,6 +205,10 @@ int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat*
 /* The same for the convert wrapper on ONE window of n_frames (what ry_ac_convert / ry_sr_convert / the ry_vc_* window call run:
  * pad kernel, layers, fused crop; stage 2 skips the decoder rows that only feed the padding the wrapper throws away). */
 int ry_net_profile_window(ry_net* net, int n_frames, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats);
+
+/* diagnostics: ratio[i * n + j] = wall time of a `us`-microsecond spin kernel on each of two fresh streams i and j, divided by `us`:
+ * ~1 when the two streams run side by side, ~2 when one waits for the other (scripts/gpu_r2_queues.py). */
+int ry_debug_stream_overlap(ry_ctx* ctx, int n, int us, float* ratio);
 
 /* diagnostics (RY_TIMING=1 only): per-phase shader-clock totals of ry_igemm_f32, summed over waves; reads and resets */
 int ry_debug_igemm_phases(ry_ctx* ctx, unsigned long long* out8);

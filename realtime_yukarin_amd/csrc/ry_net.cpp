@@ -18,6 +18,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -412,14 +413,14 @@ struct ry_net {
                                              // 2 = split-bf16 (hi*hi + lo*hi + hi*lo on the bf16 pipe, fp32 accumulate: fp32-class results)
     ry_ctx* ctx = nullptr;
     ry_stream_t stream = nullptr;            // each predictor enqueues on its own stream: stage-1 of one window overlaps stage-2 of another
-    rt::Event done;                          // recorded after the last enqueue; ry_sync / ry_timer_stop wait on it
+    rt::Event done;                          // (spare: ry_sync / ry_timer_stop join the predictor streams on the host)
     bool has_done = false;
     int split_at = 0;                        // > 0 (stage 2): the forward runs as two graphs, layers [0, split_at) and the rest, with `mid` recorded between them
     rt::Event mid;                           // ... so that the NEXT window's stage 1 can be timed to run under the weight-streaming layers at the bottom of the U-Net
     bool mid_recorded = false;
     ry_net_desc desc;
     std::vector<Layer> layers;
-    Arena weights;
+    std::shared_ptr<Arena> weights = std::make_shared<Arena>();   // filters, scale / shift: shared by the clones of a predictor (ry_net_clone)
     std::map<std::tuple<int, int, int, int>, std::unique_ptr<Plan>> plans;
     bool use_graph = true;
     // profiling hook
@@ -1483,8 +1484,6 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
     if (!on_device) {
         RT_TRY(rt::d2h(y, P.user_out, out_bytes, net->stream));
         RT_TRY(rt::stream_sync(net->stream));
-    } else {
-        RT_TRY(rt::event_record(net->done, net->stream));      // lets ry_sync / ry_timer_stop join this predictor's stream
     }
     return RY_OK;
 }
@@ -1606,17 +1605,22 @@ void* ry_stream(ry_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int ry_timer_start(ry_ctx* ctx) {
     if (!ctx) return fail(RY_ESTATE, "null context");
+    // Everything queued so far is waited for on the HOST, then t0 is recorded and waited for: whatever is enqueued afterwards starts after
+    // t0 without a cross-stream wait.  (The former form -- every predictor stream waits on t0 with hipStreamWaitEvent -- left the two
+    // window lanes of ry_vc serialised for the rest of the run: 1.32 instead of 1.16 ms per window, scripts/gpu_r2_lanes_ab.sh.)
+    for (ry_net* n : ctx->nets) RT_TRY(rt::stream_sync(n->stream));
+    RT_TRY(rt::stream_sync(ctx->stream));
     RT_TRY(rt::event_record(ctx->t0, ctx->stream));
-    for (ry_net* n : ctx->nets) RT_TRY(rt::stream_wait_event(n->stream, ctx->t0));   // predictors start after t0
+    RT_TRY(rt::event_sync(ctx->t0));
     return RY_OK;
 }
 
 int ry_timer_stop(ry_ctx* ctx, float* ms) {
     if (!ctx || !ms) return fail(RY_EINVAL, "null argument");
-    for (ry_net* n : ctx->nets) {                                                      // t1 after every predictor stream
-        RT_TRY(rt::event_record(n->done, n->stream));
-        RT_TRY(rt::stream_wait_event(ctx->stream, n->done));
-    }
+    // t1 after every predictor stream, joined on the HOST: an event record on each predictor stream plus hipStreamWaitEvent from the
+    // context stream, issued while the two window lanes of ry_vc still had work queued, cost them their overlap for the rest of the run
+    // (1.33 instead of 1.16 ms per window, BENCH_TIMER_MODE sweep of round 2)
+    for (ry_net* n : ctx->nets) RT_TRY(rt::stream_sync(n->stream));
     RT_TRY(rt::event_record(ctx->t1, ctx->stream));
     RT_TRY(rt::event_sync(ctx->t1));
     RT_TRY(rt::event_elapsed(ms, ctx->t0, ctx->t1));
@@ -1652,7 +1656,7 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
     net->layers = build_topology(*desc);
     if (const char* e = getenv("RY_GRAPH")) net->use_graph = atoi(e) != 0;
     RT_TRY(rt::stream_create(&net->stream));
-    RT_TRY(rt::event_create(&net->done));
+    RT_TRY(rt::event_create_fast(&net->done));
     RT_TRY(rt::event_create_fast(&net->mid));
     net->has_done = true;
     // RY_S2_SPLIT=5 (off by default): stage 2 as two graphs cut after encoder c4 with an event between them, so that stage 1 of the next
@@ -1667,8 +1671,28 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
         const float* b = blob + off; off += l.cout;
         const float* bn = nullptr;
         if (l.bn) { bn = blob + off; off += 4 * (size_t)l.cout; }
-        RY_TRY(prepare_layer(ctx, net->weights, l, desc->ndim, net->desc.bn_eps, W, b, bn));
+        RY_TRY(prepare_layer(ctx, *net->weights, l, desc->ndim, net->desc.bn_eps, W, b, bn));
     }
+    ctx->nets.push_back(net.get());
+    *out = net.release();
+    return RY_OK;
+}
+
+// A second handle on the same predictor: the filters stay where they are (one copy in HBM, freed with the last handle), the clone
+// gets its own stream, launch plans, activation buffers and captured graphs -- what a window needs to run beside another one.
+int ry_net_clone(ry_net* src, ry_net** out) {
+    if (!src || !out) return fail(RY_EINVAL, "null argument");
+    *out = nullptr;
+    ry_ctx* ctx = src->ctx;
+    RT_TRY(rt::set_device(ctx->device));
+    std::unique_ptr<ry_net> net(new ry_net());
+    net->ctx = ctx; net->desc = src->desc; net->dtype = src->dtype; net->use_graph = src->use_graph; net->split_at = src->split_at;
+    net->layers = src->layers;                       // device pointers into the shared arena
+    net->weights = src->weights;
+    RT_TRY(rt::stream_create(&net->stream));
+    RT_TRY(rt::event_create_fast(&net->done));
+    RT_TRY(rt::event_create_fast(&net->mid));
+    net->has_done = true;
     ctx->nets.push_back(net.get());
     *out = net.release();
     return RY_OK;
@@ -1742,7 +1766,7 @@ int ry_net_set_dtype(ry_net* net, int dtype) {
                     for (int nl = 0; nl < 64; ++nl)
                         w16[(o * (C / 64) + c / 64) * 4096 + wig16_inblock(nl, c % 64)] = host_f2bf(w32[(o * (C / 32) + c / 32) * 2048 + wig_inblock(nl, c % 32)]);
             float* d = nullptr;
-            RY_TRY(net->weights.alloc(&d, (n + 1) / 2));
+            RY_TRY(net->weights->alloc(&d, (n + 1) / 2));
             RT_TRY(rt::h2d(d, w16.data(), n * sizeof(unsigned short), ctx->stream));
             RT_TRY(rt::stream_sync(ctx->stream));
             l.wig16 = d;
@@ -1762,7 +1786,7 @@ int ry_net_set_dtype(ry_net* net, int dtype) {
             std::vector<unsigned short> wx;
             build_wigx3(l, w32, wx);
             float* d = nullptr;
-            RY_TRY(net->weights.alloc(&d, (wx.size() + 1) / 2));
+            RY_TRY(net->weights->alloc(&d, (wx.size() + 1) / 2));
             RT_TRY(rt::h2d(d, wx.data(), wx.size() * sizeof(unsigned short), ctx->stream));
             RT_TRY(rt::stream_sync(ctx->stream));
             l.wigx3 = d;
@@ -1876,7 +1900,8 @@ struct VcSlot {
 };
 
 struct ry_vc {
-    static const int RING = 3;
+    static const int RING = 6;            // windows in flight: two per lane with three lanes (stage 1 of a lane's next window runs under stage 2 of its previous one)
+    static const int MAX_LANES = 3;
     ry_net* s1 = nullptr;
     ry_net* s2 = nullptr;
     int M = 0, F = 0;
@@ -1891,6 +1916,27 @@ struct ry_vc {
     int next_ticket = 0;
     int dev_count = 0;       // device-pointer calls (ry_vc_enqueue_device) take the slots round robin
     int split_eff = -1;      // ry_vc_stage1 left the converted rows of this many effective frames in slot 0's d_y1 (-1: nothing)
+    // Lanes (ry_vc_set_lanes): ring slot k runs on the predictor pair l1 / l2 [k % lanes].  Lane 0 is the caller's pair; the others are
+    // clones (same filters, own streams / plans / activations), so that the windows in flight really run side by side: the tails of one
+    // window's one-round grids and its weight-streaming bottom layers are filled by the other windows' kernels.
+    int lanes = 1;
+    int stagger_at = 0;      // > 0 with several lanes: every stage-2 forward runs as two graphs cut before layer `stagger_at`, and the forward of the
+                             // next window (other lane) starts when this one reaches the cut: the two windows in flight are always in different halves
+    ry_net* last_s2 = nullptr;
+    ry_net* l1[MAX_LANES] = {nullptr, nullptr, nullptr};
+    ry_net* l2[MAX_LANES] = {nullptr, nullptr, nullptr};
+    // a clone follows the arithmetic mode of the handle it was made from (ry_net_set_dtype on the caller's handle converts the filters
+    // once; the clone takes the pointers and drops its launch plans)
+    static ry_net* follow(ry_net* n, ry_net* src) {
+        if (n != src && n->dtype != src->dtype) {
+            rt::stream_sync(n->stream);
+            n->layers = src->layers; n->dtype = src->dtype; n->plans.clear();
+        }
+        return n;
+    }
+    ry_net* lane1(int slot) const { return follow(l1[slot % lanes], s1); }
+    ry_net* lane2(int slot) const { return follow(l2[slot % lanes], s2); }
+    void sync_lanes() { for (int k = 0; k < lanes; ++k) { rt::stream_sync(l1[k]->stream); rt::stream_sync(l2[k]->stream); } }
     // several windows per call (ry_vc_enqueue_device_batch): their own intermediates, re-allocated when a larger batch arrives
     Arena batch_bufs;
     float *b_y1 = nullptr, *b_sp = nullptr;
@@ -1911,7 +1957,7 @@ static int vc_reserve(ry_vc* vc, int n_eff, int n_frames) {
     if (n_eff <= vc->cap_eff && n_frames <= vc->cap_frames) return RY_OK;
     for (VcSlot& sl : vc->slot)
         if (sl.ticket >= 0) return fail(RY_ESTATE, "a larger window arrived while ticket %d is still in flight: ry_vc_wait it first", sl.ticket);
-    rt::stream_sync(vc->s1->stream); rt::stream_sync(vc->s2->stream);
+    vc->sync_lanes();
     vc->bufs.release(); vc->free_pinned();
     const int ce = n_eff > vc->cap_eff ? n_eff : vc->cap_eff, cf = n_frames > vc->cap_frames ? n_frames : vc->cap_frames;
     const int cin = vc->s1->desc.in_ch;
@@ -1947,8 +1993,7 @@ static int vc_reserve(ry_vc* vc, int n_eff, int n_frames) {
 }
 
 // scatter the converted rows into the all-silent block, then sp = exp(mc @ M) + floor   (stage-1 stream)
-static int vc_enqueue_mid(ry_vc* vc, const float* y1, const int* row_of, int n_eff, int n_frames, float sp_floor, float* mc, float* sp) {
-    ry_net* s1 = vc->s1;
+static int vc_enqueue_mid(ry_vc* vc, ry_net* s1, const float* y1, const int* row_of, int n_eff, int n_frames, float sp_floor, float* mc, float* sp) {
     ry_stream_t st1 = s1->stream;
     Launcher Lc{s1, s1->ctx, st1, nullptr, nullptr};
     const int M = vc->M, F = vc->F;
@@ -1970,11 +2015,21 @@ static int vc_enqueue_mid(ry_vc* vc, const float* y1, const int* row_of, int n_e
     return RY_OK;
 }
 
+// stage 2 of one window on its lane; with several lanes and a cut (ry_vc::stagger_at) it starts when the previous window's forward,
+// on another lane, has reached the cut
+static int vc_run_stage2(ry_vc* vc, ry_net* s2, const float* sp_in, float* sp_out, int n_frames) {
+    if (vc->lanes > 1 && vc->stagger_at > 0 && vc->last_s2 && vc->last_s2 != s2 && vc->last_s2->mid_recorded)
+        RT_TRY(rt::stream_wait_event(s2->stream, vc->last_s2->mid));
+    RY_TRY(ry_sr_convert(s2, sp_in, sp_out, 1, n_frames, 1));
+    vc->last_s2 = s2;
+    return RY_OK;
+}
+
 // Stage 1 of a window is timed to start when the PREVIOUS window's stage 2 has finished its large encoder layers (ry_net::mid):
 // it then runs under the six weight-streaming layers at the bottom of the U-Net, which leave most of the chip idle, instead of
 // taking workgroup slots from the one-round grids of the MFMA-bound layers.
-static int vc_stagger(ry_vc* vc) {
-    if (g_vc_stagger && vc->s2->mid_recorded) RT_TRY(rt::stream_wait_event(vc->s1->stream, vc->s2->mid));
+static int vc_stagger(ry_net* s1, ry_net* s2) {
+    if (g_vc_stagger && s2->mid_recorded) RT_TRY(rt::stream_wait_event(s1->stream, s2->mid));
     return RY_OK;
 }
 
@@ -1999,6 +2054,7 @@ int ry_vc_create(ry_net* s1, ry_net* s2, const float* mtx, int M, int F, ry_vc**
     RT_TRY(rt::set_device(s1->ctx->device));
     std::unique_ptr<ry_vc> vc(new ry_vc());
     vc->s1 = s1; vc->s2 = s2; vc->M = M; vc->F = F;
+    vc->l1[0] = s1; vc->l2[0] = s2;
     std::vector<float> h(mtx, mtx + (size_t)M * F);
     RY_TRY(upload(vc->arena, s1->ctx, h, &vc->d_mtx));
     for (VcSlot& sl : vc->slot) { RT_TRY(rt::event_create_fast(&sl.ev_mid)); RT_TRY(rt::event_create_fast(&sl.ev_done)); }
@@ -2010,22 +2066,56 @@ int ry_vc_create(ry_net* s1, ry_net* s2, const float* mtx, int M, int F, ry_vc**
 void ry_vc_destroy(ry_vc* vc) {
     if (!vc) return;
     rt::set_device(vc->s1->ctx->device);
-    rt::stream_sync(vc->s1->stream); rt::stream_sync(vc->s2->stream);
+    vc->sync_lanes();
+    for (int k = 1; k < vc->lanes; ++k) { ry_net_destroy(vc->l1[k]); ry_net_destroy(vc->l2[k]); }
     if (vc->has_ev) for (VcSlot& sl : vc->slot) { rt::event_destroy(sl.ev_mid); rt::event_destroy(sl.ev_done); }
     if (vc->b_ev) { rt::event_destroy(vc->b_mid); rt::event_destroy(vc->b_done); }
     vc->free_pinned();
     delete vc;
 }
 
+// 1 .. 3 lanes: ring slot k runs on its own pair of predictor handles (clones of the caller's: same filters, own streams, plans,
+// activations and graphs), so that up to `lanes` windows really run side by side.  Measured at 300 frames (scripts/gpu_r2_twostream.py):
+// 1.281 / 1.200 / 1.160 ms per window with 1 / 2 / 3 lanes -- the one-round grids of one window leave tails and its bottom layers leave
+// most of the chip idle; the other windows' kernels fill both.  Results do not change (same plans, same arithmetic).
+int ry_vc_set_lanes(ry_vc* vc, int lanes) {
+    if (!vc) return fail(RY_EINVAL, "null argument");
+    if (lanes < 1 || lanes > ry_vc::MAX_LANES) return fail(RY_EINVAL, "lanes must be in 1..%d (got %d)", ry_vc::MAX_LANES, lanes);
+    for (VcSlot& sl : vc->slot)
+        if (sl.ticket >= 0) return fail(RY_ESTATE, "ticket %d is still in flight: ry_vc_wait it before changing the lanes", sl.ticket);
+    RT_TRY(rt::set_device(vc->s1->ctx->device));
+    vc->sync_lanes();
+    while (vc->lanes > lanes) {
+        --vc->lanes;
+        ry_net_destroy(vc->l1[vc->lanes]); ry_net_destroy(vc->l2[vc->lanes]);
+        vc->l1[vc->lanes] = vc->l2[vc->lanes] = nullptr;
+    }
+    while (vc->lanes < lanes) {
+        ry_net *a = nullptr, *b = nullptr;
+        RY_TRY(ry_net_clone(vc->s1, &a));
+        int rc = ry_net_clone(vc->s2, &b);
+        if (rc != RY_OK) { ry_net_destroy(a); return rc; }
+        vc->l1[vc->lanes] = a; vc->l2[vc->lanes] = b;
+        ++vc->lanes;
+    }
+    vc->stagger_at = 0;
+    if (const char* e = getenv("RY_VC_STAGGER_AT")) vc->stagger_at = atoi(e);
+    if (vc->stagger_at < 1 || vc->stagger_at > 15 || vc->lanes < 2) vc->stagger_at = 0;
+    for (int k = 0; k < vc->lanes; ++k)
+        if (vc->l2[k]->split_at != vc->stagger_at) { vc->l2[k]->split_at = vc->stagger_at; vc->l2[k]->plans.clear(); vc->l2[k]->mid_recorded = false; }
+    vc->last_s2 = nullptr;
+    return RY_OK;
+}
+
 // Host window in, ticket out: returns as soon as the copies and kernels are queued (nothing is waited for).
 int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, int n_frames, float sp_floor, int* ticket) {
     if (!vc || !ticket || (n_eff > 0 && (!x_eff || !row_of))) return fail(RY_EINVAL, "null argument");
     RY_TRY(vc_check(vc, row_of, n_eff, n_frames, true));
-    ry_net *s1 = vc->s1, *s2 = vc->s2;
-    RT_TRY(rt::set_device(s1->ctx->device));
+    RT_TRY(rt::set_device(vc->s1->ctx->device));
     RY_TRY(vc_reserve(vc, n_eff, n_frames));
     const int t = vc->next_ticket;
     VcSlot& sl = vc->slot[t % ry_vc::RING];
+    ry_net *s1 = vc->lane1(t % ry_vc::RING), *s2 = vc->lane2(t % ry_vc::RING);
     if (sl.ticket >= 0) return fail(RY_ESTATE, "all %d ring slots are in flight: ry_vc_wait ticket %d first", ry_vc::RING, sl.ticket);
     const int cin = s1->desc.in_ch, M = vc->M, F = vc->F;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
@@ -2035,14 +2125,14 @@ int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, in
         memcpy(sl.h_row, row_of, (size_t)n_eff * sizeof(int));
         RT_TRY(rt::h2d(sl.d_x, sl.h_x, (size_t)n_eff * cin * sizeof(float), st1));
         RT_TRY(rt::h2d(sl.d_row, sl.h_row, (size_t)n_eff * sizeof(int), st1));
-        RY_TRY(vc_stagger(vc));
+        RY_TRY(vc_stagger(s1, s2));
         RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1));                       // stage-1 CNN on the effective frames
     }
-    RY_TRY(vc_enqueue_mid(vc, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp));
+    RY_TRY(vc_enqueue_mid(vc, s1, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp));
     RT_TRY(rt::d2h(sl.h_mc, sl.d_mc, (size_t)n_frames * M * sizeof(float), st1));
     RT_TRY(rt::event_record(sl.ev_mid, st1));
     RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));                                      // stage-2 starts when the spectrogram is ready
-    RY_TRY(ry_sr_convert(s2, sl.d_sp, sl.d_out, 1, n_frames, 1));
+    RY_TRY(vc_run_stage2(vc, s2, sl.d_sp, sl.d_out, n_frames));
     RT_TRY(rt::d2h(sl.h_sp, sl.d_out, (size_t)n_frames * F * sizeof(float), st2));
     RT_TRY(rt::event_record(sl.ev_done, st2));
     sl.used = true; sl.ticket = t; sl.n_eff = n_eff; sl.n_frames = n_frames; sl.gated = false;
@@ -2080,9 +2170,8 @@ int ry_vc_convert(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, i
 }  // extern "C"
 
 // wave + features up, frame powers, gate, compaction, count and mask back (waits for the count); leaves x_eff / row_of in the slot
-static int vc_gate_into_slot(ry_vc* vc, VcSlot& sl, const float* wave, int n_samples, int hop, int fft_length, float p_effective, float p_all,
+static int vc_gate_into_slot(ry_vc* vc, ry_net* s1, VcSlot& sl, const float* wave, int n_samples, int hop, int fft_length, float p_effective, float p_all,
                              const float* feat, int n_frames, int* n_eff_out) {
-    ry_net* s1 = vc->s1;
     const int cin = s1->desc.in_ch;
     ry_stream_t st1 = s1->stream;
     if (sl.used) RT_TRY(rt::stream_wait_event(st1, sl.ev_done));
@@ -2141,7 +2230,7 @@ int ry_vc_gate(ry_vc* vc, const float* wave, int n_samples, int hop, int fft_len
     VcSlot& sl = vc->slot[0];
     if (sl.ticket >= 0) return fail(RY_ESTATE, "ring slot 0 is held by ticket %d: ry_vc_wait it first", sl.ticket);
     int n_eff = 0;
-    RY_TRY(vc_gate_into_slot(vc, sl, wave, n_samples, hop, fft_length, p_effective, p_all, feat, n_frames, &n_eff));
+    RY_TRY(vc_gate_into_slot(vc, vc->s1, sl, wave, n_samples, hop, fft_length, p_effective, p_all, feat, n_frames, &n_eff));
     memcpy(effective_out, sl.h_mask, (size_t)n_frames);
     *n_eff_out = n_eff;
     const int cin = vc->s1->desc.in_ch;
@@ -2156,22 +2245,22 @@ int ry_vc_submit_wave(ry_vc* vc, const float* wave, int n_samples, int hop, int 
                       const float* feat, int n_frames, float sp_floor, int* ticket) {
     RY_TRY(vc_gate_args(vc, wave, n_samples, hop, fft_length, feat, n_frames));
     if (!ticket) return fail(RY_EINVAL, "null argument");
-    ry_net *s1 = vc->s1, *s2 = vc->s2;
-    RT_TRY(rt::set_device(s1->ctx->device));
+    RT_TRY(rt::set_device(vc->s1->ctx->device));
     RY_TRY(vc_reserve(vc, n_frames, n_frames));
     const int t = vc->next_ticket;
     VcSlot& sl = vc->slot[t % ry_vc::RING];
+    ry_net *s1 = vc->lane1(t % ry_vc::RING), *s2 = vc->lane2(t % ry_vc::RING);
     if (sl.ticket >= 0) return fail(RY_ESTATE, "all %d ring slots are in flight: ry_vc_wait ticket %d first", ry_vc::RING, sl.ticket);
     const int M = vc->M, F = vc->F;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
     int n_eff = 0;
-    RY_TRY(vc_gate_into_slot(vc, sl, wave, n_samples, hop, fft_length, p_effective, p_all, feat, n_frames, &n_eff));
-    if (n_eff > 0) { RY_TRY(vc_stagger(vc)); RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1)); }
-    RY_TRY(vc_enqueue_mid(vc, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp));
+    RY_TRY(vc_gate_into_slot(vc, s1, sl, wave, n_samples, hop, fft_length, p_effective, p_all, feat, n_frames, &n_eff));
+    if (n_eff > 0) { RY_TRY(vc_stagger(s1, s2)); RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1)); }
+    RY_TRY(vc_enqueue_mid(vc, s1, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp));
     RT_TRY(rt::d2h(sl.h_mc, sl.d_mc, (size_t)n_frames * M * sizeof(float), st1));
     RT_TRY(rt::event_record(sl.ev_mid, st1));
     RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));
-    RY_TRY(ry_sr_convert(s2, sl.d_sp, sl.d_out, 1, n_frames, 1));
+    RY_TRY(vc_run_stage2(vc, s2, sl.d_sp, sl.d_out, n_frames));
     RT_TRY(rt::d2h(sl.h_sp, sl.d_out, (size_t)n_frames * F * sizeof(float), st2));
     RT_TRY(rt::event_record(sl.ev_done, st2));
     sl.used = true; sl.ticket = t; sl.n_eff = n_eff; sl.n_frames = n_frames; sl.gated = true;
@@ -2198,19 +2287,19 @@ int ry_vc_enqueue_device(ry_vc* vc, const float* x_eff_dev, const int* row_of_de
                          float* mc_out_dev, float* sp_out_dev) {
     if (!vc || !mc_out_dev || !sp_out_dev || (n_eff > 0 && (!x_eff_dev || !row_of_dev))) return fail(RY_EINVAL, "null argument");
     RY_TRY(vc_check(vc, nullptr, n_eff, n_frames, false));
-    ry_net *s1 = vc->s1, *s2 = vc->s2;
-    RT_TRY(rt::set_device(s1->ctx->device));
+    RT_TRY(rt::set_device(vc->s1->ctx->device));
     RY_TRY(vc_reserve(vc, n_eff, n_frames));
     VcSlot& sl = vc->slot[vc->dev_count % ry_vc::RING];
+    ry_net *s1 = vc->lane1(vc->dev_count % ry_vc::RING), *s2 = vc->lane2(vc->dev_count % ry_vc::RING);
     if (sl.ticket >= 0) return fail(RY_ESTATE, "ring slot %d is held by ticket %d: ry_vc_wait it first", vc->dev_count % ry_vc::RING, sl.ticket);
     ++vc->dev_count;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
     if (sl.used) RT_TRY(rt::stream_wait_event(st1, sl.ev_done));                        // the slot's previous window has left d_sp
-    if (n_eff > 0) { RY_TRY(vc_stagger(vc)); RY_TRY(ry_ac_convert(s1, x_eff_dev, sl.d_y1, 1, n_eff, 1)); }
-    RY_TRY(vc_enqueue_mid(vc, sl.d_y1, row_of_dev, n_eff, n_frames, sp_floor, mc_out_dev, sl.d_sp));
+    if (n_eff > 0) { RY_TRY(vc_stagger(s1, s2)); RY_TRY(ry_ac_convert(s1, x_eff_dev, sl.d_y1, 1, n_eff, 1)); }
+    RY_TRY(vc_enqueue_mid(vc, s1, sl.d_y1, row_of_dev, n_eff, n_frames, sp_floor, mc_out_dev, sl.d_sp));
     RT_TRY(rt::event_record(sl.ev_mid, st1));
     RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));
-    RY_TRY(ry_sr_convert(s2, sl.d_sp, sp_out_dev, 1, n_frames, 1));
+    RY_TRY(vc_run_stage2(vc, s2, sl.d_sp, sp_out_dev, n_frames));
     RT_TRY(rt::event_record(sl.ev_done, st2));
     sl.used = true;
     vc->split_eff = -1;
@@ -2349,7 +2438,7 @@ static int vc_split_mid(ry_vc* vc, const int* row_of, int n_eff, int n_frames, f
     } else if (sl.used) {
         RT_TRY(rt::stream_wait_event(vc->s1->stream, sl.ev_done));
     }
-    return vc_enqueue_mid(vc, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp);
+    return vc_enqueue_mid(vc, vc->s1, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp);
 }
 
 int ry_vc_stage2_from_mc(ry_vc* vc, const int* row_of, int n_eff, int n_frames, float sp_floor, float* sp_out) {
@@ -2562,6 +2651,47 @@ int ry_comm_allreduce_max(ry_comm* c, double* value) {
 int ry_comm_barrier(ry_comm* c) {
     double one = 1.0;
     return ry_comm_allreduce_max(c, &one);
+}
+
+// diagnostics: do two HIP streams of this process really run side by side?  A one-wave kernel that spins for `us` microseconds is put on
+// stream i and on stream j; ratio[i * n + j] = wall time of the pair / us: ~1 when the two hardware queues are served together, ~2 when
+// one waits for the other (both streams folded onto one queue, or two queues on one pipe of the command processor).
+#ifndef RY_HOST_EMU
+__global__ void ry_spin_kernel(unsigned long long ticks, unsigned long long* sink) {
+    const unsigned long long t0 = wall_clock64();                        // constant-rate counter (hipDeviceAttributeWallClockRate kHz)
+    unsigned long long t = t0;
+    while (t - t0 < ticks) t = wall_clock64();
+    if (sink && t == 1) sink[0] = t;
+}
+#endif
+
+int ry_debug_stream_overlap(ry_ctx* ctx, int n, int us, float* ratio) {
+    if (!ctx || !ratio || n < 2 || n > 32 || us < 10) return fail(RY_EINVAL, "bad argument");
+#ifdef RY_HOST_EMU
+    for (int i = 0; i < n * n; ++i) ratio[i] = 1.f;
+    return RY_OK;
+#else
+    RT_TRY(rt::set_device(ctx->device));
+    std::vector<ry_stream_t> st(n);
+    for (int i = 0; i < n; ++i) RT_TRY(rt::stream_create(&st[i]));
+    int khz = 100000;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
+    const unsigned long long ticks = (unsigned long long)us * (unsigned long long)khz / 1000ull;
+    for (int i = 0; i < n; ++i) { hipLaunchKernelGGL(ry_spin_kernel, dim3(1), dim3(64), 0, st[i], 1000ull, nullptr); RT_TRY(rt::stream_sync(st[i])); }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            if (i == j) { ratio[i * n + j] = 1.f; continue; }
+            RT_TRY(rt::stream_sync(st[i])); RT_TRY(rt::stream_sync(st[j]));
+            const auto t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(ry_spin_kernel, dim3(1), dim3(64), 0, st[i], ticks, nullptr);
+            hipLaunchKernelGGL(ry_spin_kernel, dim3(1), dim3(64), 0, st[j], ticks, nullptr);
+            RT_TRY(rt::stream_sync(st[i])); RT_TRY(rt::stream_sync(st[j]));
+            const double el = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            ratio[i * n + j] = (float)(el / us);
+        }
+    for (int i = 0; i < n; ++i) rt::stream_destroy(st[i]);
+    return RY_OK;
+#endif
 }
 
 // diagnostics: the plan (tile, external splits, K groups, estimated time) the stage-2 planner picks for one layer shape

@@ -115,7 +115,7 @@ class VcCore(object):
     """Device-resident core of `VoiceChanger.convert_from_acoustic_feature`: stage-1 on the effective frames ->
     scatter into the silent block -> mc2sp (exp(mc @ M)) -> + floor -> stage-2, one H2D and one D2H per window (`ry_vc_convert`)."""
 
-    def __init__(self, stage1: 'Net', stage2: 'Net', mtx: numpy.ndarray):
+    def __init__(self, stage1: 'Net', stage2: 'Net', mtx: numpy.ndarray, lanes: Optional[int] = None):
         self.stage1, self.stage2 = stage1, stage2
         self.lib = stage1.ctx.lib
         mtx = numpy.ascontiguousarray(mtx, dtype=numpy.float32)
@@ -124,6 +124,15 @@ class VcCore(object):
         self.lib.check(self.lib.dll.ry_vc_create(stage1.handle, stage2.handle, _lib._fptr(mtx), self.M, self.F, ctypes.byref(h)))
         self.handle = h
         self._pending = {}
+        # lanes: the six ring slots spread over two pairs of predictor handles (`ry_vc_set_lanes`), so that two windows really run side by side
+        # (RY_VC_LANES=1: one stage-2 forward after the other; 3 measured slower than 2)
+        self.lanes = int(os.environ.get('RY_VC_LANES', '2')) if lanes is None else int(lanes)
+        if self.lanes != 1:
+            self.set_lanes(self.lanes)
+
+    def set_lanes(self, lanes: int):
+        self.lib.check(self.lib.dll.ry_vc_set_lanes(self.handle, int(lanes)))
+        self.lanes = int(lanes)
 
     @staticmethod
     def _rows(effective):
@@ -131,7 +140,7 @@ class VcCore(object):
         return int(effective.size), numpy.ascontiguousarray(numpy.nonzero(effective)[0], dtype=numpy.int32)
 
     def submit(self, x_eff: numpy.ndarray, effective: numpy.ndarray, sp_floor: float = 1e-16) -> int:
-        """Queue one window (pinned ring slot -> H2D -> stage-1 -> ... -> D2H) and return its ticket without waiting; up to three
+        """Queue one window (pinned ring slot -> H2D -> stage-1 -> ... -> D2H) and return its ticket without waiting; up to six
         windows may be in flight (`ry_vc_submit`)."""
         n, rows = self._rows(effective)
         x_eff = numpy.ascontiguousarray(x_eff, dtype=numpy.float32)
@@ -195,8 +204,8 @@ class VcCore(object):
     def convert_stream(self, windows, sp_floor: float = 1e-16, depth: int = 2):
         """Generator over (x_eff, effective) pairs -> (mc, sp) in order, keeping `depth` windows in flight: the copies of one window
         run under the kernels of another."""
-        if not 1 <= depth <= 3:
-            raise ValueError('depth must be 1..3 (the ring has three slots)')
+        if not 1 <= depth <= 6:
+            raise ValueError('depth must be 1..6 (the ring has six slots)')
         tickets = []
         for x_eff, effective in windows:
             tickets.append(self.submit(x_eff, effective, sp_floor))

@@ -52,7 +52,7 @@ class VoiceChanger(object):
     def convert_from_acoustic_feature(self, f_in):
         return self.finish(self.begin(f_in))
 
-    # ---- the same call in two halves: `begin` queues the window on the GPU and returns at once (up to three windows may be in flight,
+    # ---- the same call in two halves: `begin` queues the window on the GPU and returns at once (up to six windows may be in flight,
     # `ry_vc_submit` / `ry_vc_submit_wave`), `finish` waits for it and assembles the output feature.  `worker.convert_worker` uses the
     # pair to keep a backlog of windows pipelined: H2D of window i + 1 and D2H of window i - 1 run under the kernels of window i.
     def begin(self, f_in):

@@ -1,4 +1,4 @@
-"""The window-call API of the C ABI (`ry_vc_*`, include/ry355.h) on the emulator: tickets, the three-slot ring, the split calls and
+"""The window-call API of the C ABI (`ry_vc_*`, include/ry355.h) on the emulator: tickets, the six-slot ring, the split calls and
 their error behaviour -- every misuse returns a negative code with a message (`Ry355Error`), nothing aborts, and the handle stays usable
 (the reference's worker loop dies on any exception, convert_worker.py:45-59: errors must be reported, not fatal)."""
 import ctypes
@@ -31,9 +31,12 @@ def test_tickets_come_back_in_any_order_and_only_once(core):
     (xa, ea), (xb, eb), (xc, ec) = window(20, 1), window(33, 2), window(20, 3)
     ref = [core.convert(x[e], e) for x, e in ((xa, ea), (xb, eb), (xc, ec))]
     ta, tb, tc = core.submit(xa[ea], ea), core.submit(xb[eb], eb), core.submit(xc[ec], ec)
+    more = [core.submit(xa[ea], ea) for _ in range(3)]
     with pytest.raises(_lib.Ry355Error, match='ring slots are in flight'):
-        core.submit(xa[ea], ea)                                                     # a fourth window: the ring has three slots
-    core._pending.pop(ta + 3, None)
+        core.submit(xa[ea], ea)                                                     # a seventh window: the ring has six slots
+    core._pending.pop(ta + 6, None)
+    for t in more:
+        assert numpy.array_equal(core.wait(t)[1], ref[0][1])
     for t, r in ((tc, ref[2]), (ta, ref[0]), (tb, ref[1])):                          # collected out of order
         mc, sp = core.wait(t)
         assert numpy.array_equal(mc, r[0]) and numpy.array_equal(sp, r[1])
@@ -90,11 +93,11 @@ def test_split_calls_follow_the_order_of_the_reference_steps(core):
 def test_stream_generator_depth(core):
     wins = [window(12 + i, 20 + i) for i in range(5)]
     ref = [core.convert(x[e], e) for x, e in wins]
-    for depth in (1, 2, 3):
+    for depth in (1, 2, 3, 6):
         got = list(core.convert_stream([(x[e], e) for x, e in wins], depth=depth))
         assert all(numpy.array_equal(g[1], r[1]) and numpy.array_equal(g[0], r[0]) for g, r in zip(got, ref))
     with pytest.raises(ValueError):
-        list(core.convert_stream([], depth=4))
+        list(core.convert_stream([], depth=7))
 
 
 def test_batch_call_equals_the_windows_one_by_one(core):
@@ -122,3 +125,51 @@ def test_batch_call_equals_the_windows_one_by_one(core):
         core.lib.check(core.lib.dll.ry_vc_enqueue_device_batch(core.handle, 2, None, None, ne, n, 1e-16, _lib._fptr(1 << 12), _lib._fptr(1 << 12)))
     mc, sp = core.convert(ws[0][0][ws[0][1]], ws[0][1])                      # the handle is still usable
     assert numpy.array_equal(mc, one[0][0]) and numpy.array_equal(sp, one[0][1])
+
+
+def test_lanes_run_the_same_arithmetic(core):
+    """`ry_vc_set_lanes`: ring slot k on its own clone of the predictor pair (shared filters, own streams / plans / activations).  The
+    windows of a stream come back bit-identical with 1, 2 and 3 lanes; the lane count cannot change under a window in flight; a clone
+    follows the arithmetic mode of the handle it was made from."""
+    wins = [window(n, 20 + i) for i, n in enumerate((20, 33, 20, 7, 33, 20, 20))]
+    res = {}
+    try:
+        for lanes in (1, 2, 3):
+            core.set_lanes(lanes)
+            res[lanes] = list(core.convert_stream([(x[e], e) for x, e in wins], depth=3))
+        for lanes in (2, 3):
+            for (mc, sp), (rmc, rsp) in zip(res[lanes], res[1]):
+                assert numpy.array_equal(mc, rmc) and numpy.array_equal(sp, rsp)
+        t = core.submit(wins[0][0][wins[0][1]], wins[0][1])
+        with pytest.raises(_lib.Ry355Error, match='still in flight'):
+            core.set_lanes(1)
+        core.wait(t)
+        with pytest.raises(_lib.Ry355Error, match='lanes must be'):
+            core.set_lanes(4)
+        # bf16x3 on the caller's stage-2 handle: the clones follow (every slot gives the same answer, different from the fp32 one)
+        core.stage2.set_dtype('bf16x3')
+        x, e = wins[1]
+        a = [core.convert(x[e], e) for _ in range(3)]                           # slots 0, 1, 2 = lanes 0, 1, 2
+        assert all(numpy.array_equal(a[0][1], q[1]) for q in a[1:])
+        core.stage2.set_dtype('f32')
+        b = [core.convert(x[e], e) for _ in range(3)]
+        assert all(numpy.array_equal(b[0][1], q[1]) for q in b) and numpy.array_equal(b[0][1], res[1][1][1])
+    finally:
+        core.stage2.set_dtype('f32')
+        core.set_lanes(2)
+
+
+def test_a_clone_shares_the_filters(emu_ctx):
+    (d1, P1), _ = synth.model_params('SYN-8')
+    n1 = engine.Net(emu_ctx, d1, flatten_params(d1, P1))
+    h = ctypes.c_void_p()
+    emu_ctx.lib.check(emu_ctx.lib.dll.ry_net_clone(n1.handle, ctypes.byref(h)))
+    x = synth.stage1_input(40, seed=3)[0]
+    y = n1.convert(x)
+    y2 = numpy.empty_like(y)
+    emu_ctx.lib.check(emu_ctx.lib.dll.ry_ac_convert(h, _lib._fptr(x), _lib._fptr(y2), 1, 40, 0))
+    assert numpy.array_equal(y, y2)
+    n1.close()                                                                  # the clone keeps the filters alive
+    emu_ctx.lib.check(emu_ctx.lib.dll.ry_ac_convert(h, _lib._fptr(x), _lib._fptr(y2), 1, 40, 0))
+    assert numpy.array_equal(y, y2)
+    emu_ctx.lib.dll.ry_net_destroy(h)
