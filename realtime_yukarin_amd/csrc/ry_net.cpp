@@ -2123,23 +2123,17 @@ int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, in
     if (n_eff > 0) {
         memcpy(sl.h_x, x_eff, (size_t)n_eff * cin * sizeof(float));
         memcpy(sl.h_row, row_of, (size_t)n_eff * sizeof(int));
-        static const int dbg2 = getenv("RY_VC_DBG") ? atoi(getenv("RY_VC_DBG")) : 0;   // diagnostics: 2 = H2D only the first time
-        static int h2d_done = 0;
-        if (!(dbg2 & 2) || h2d_done < 12) {
-        ++h2d_done;
         RT_TRY(rt::h2d(sl.d_x, sl.h_x, (size_t)n_eff * cin * sizeof(float), st1));
         RT_TRY(rt::h2d(sl.d_row, sl.h_row, (size_t)n_eff * sizeof(int), st1));
-        }
         RY_TRY(vc_stagger(s1, s2));
         RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1));                       // stage-1 CNN on the effective frames
     }
     RY_TRY(vc_enqueue_mid(vc, s1, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp));
-    static const int dbg = getenv("RY_VC_DBG") ? atoi(getenv("RY_VC_DBG")) : 0;   // diagnostics (wrong results): 1 = no D2H copies
-    if (!(dbg & 1)) RT_TRY(rt::d2h(sl.h_mc, sl.d_mc, (size_t)n_frames * M * sizeof(float), st1));
+    RT_TRY(rt::d2h(sl.h_mc, sl.d_mc, (size_t)n_frames * M * sizeof(float), st1));
     RT_TRY(rt::event_record(sl.ev_mid, st1));
     RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));                                      // stage-2 starts when the spectrogram is ready
     RY_TRY(vc_run_stage2(vc, s2, sl.d_sp, sl.d_out, n_frames));
-    if (!(dbg & 1)) RT_TRY(rt::d2h(sl.h_sp, sl.d_out, (size_t)n_frames * F * sizeof(float), st2));
+    RT_TRY(rt::d2h(sl.h_sp, sl.d_out, (size_t)n_frames * F * sizeof(float), st2));
     RT_TRY(rt::event_record(sl.ev_done, st2));
     sl.used = true; sl.ticket = t; sl.n_eff = n_eff; sl.n_frames = n_frames; sl.gated = false;
     vc->split_eff = -1;

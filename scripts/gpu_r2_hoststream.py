@@ -14,9 +14,9 @@ n1 = engine.Net(ctx, d1, flatten_params(d1, synthetic_params(d1, synth.SEED_STAG
 n2 = engine.Net(ctx, d2, flatten_params(d2, synthetic_params(d2, synth.SEED_STAGE2)), width=synth.FFT_BINS - 1)
 mtx = sptk.mc2sp_matrix(d1.out_ch - 1, sptk.mcepalpha(16000), 2 * (synth.FFT_BINS - 1))
 xh = synth.stage1_input(N, 1)[0]; eff = numpy.ones(N, bool)
-for lanes in (2,):
+for lanes in (1, 2):
     core = engine.VcCore(n1, n2, mtx, lanes=lanes)
-    for depth in (2, 6):
+    for depth in (1, 2, 3, 6):
         for _ in core.convert_stream([(xh, eff)] * 12, depth=depth):
             pass
         res = []
