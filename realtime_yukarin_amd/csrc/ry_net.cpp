@@ -529,7 +529,7 @@ static void tile_dims(int tile, int* bm, int* bn) {
 
 
 static int g_vc_stagger = 1;  // RY_VC_STAGGER=0: stage 1 of the next window starts at once instead of under the bottom layers of the previous window's stage 2
-static int g_s2_crop = 1;     // RY_S2_CROP=0: every decoder layer of the convert wrapper computes all padded rows (A/B of the dead-row crop); 2: crop one-round grids too
+static int g_s2_crop = 2;     // RY_S2_CROP=0: every decoder layer of the convert wrapper computes all padded rows (A/B of the dead-row crop); 1: only grids of more than one workgroup per CU
 static int g_last_band = 1;   // RY_LAST_BAND=0: raster-order workgroups in ry_sr_last (A/B of the per-XCD row bands)
 static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
 static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
@@ -1244,8 +1244,9 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
                 if (bm % tw == 0 && Mw % tw == 0 && Mh % (bm / tw) == 0) { const int th = bm / tw; rows = (rows + th - 1) / th * th; break; }
             if (rows >= lp.Hi) break;
             // measured at 300 frames (scripts/gpu_r2_ab3.sh): decoder c6 (1536 -> 1216 workgroups, six per CU -> five) 208 -> 177 us, decoder c5
-            // (512 -> 416, two per CU) 198 -> 193 us, decoder c4 (256 -> 224, one per CU) 196 -> 194 us: a grid of one workgroup per
-            // CU gains nothing and only leaves CUs idle, so it runs whole (RY_S2_CROP=2 crops it too)
+            // (512 -> 416, two per CU) 198 -> 193 us, decoder c4 (256 -> 224, one per CU) 196 -> 194 us: a grid of one workgroup per CU
+            // gains nothing by itself, but the CUs it leaves idle go to the window on the other lane (ry_vc_set_lanes): 1.160 -> 1.137 ms
+            // per window with two lanes, so it is cropped too (RY_S2_CROP=1 keeps such grids whole)
             const long wgs = (long)(((long)B * Mh * Mw + bm - 1) / bm) * (l.cout / bn) * (l.deconv ? 4 : 1) * lp.splits;
             if (g_s2_crop >= 2 || wgs > 256) { crop[i] = rows; need = rows; }
             else need = lp.Hi;                                       // this layer runs whole: it reads every row of its producer
