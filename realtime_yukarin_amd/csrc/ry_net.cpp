@@ -1890,6 +1890,11 @@ struct VcSlot {
     unsigned char *h_mask = nullptr, *d_mask = nullptr;
     int *h_count = nullptr, *d_count = nullptr;
     int cap_wave = 0;
+    // every slot owns its buffers and grows on its own: a longer window never touches a slot that still holds a window in flight
+    Arena bufs;
+    std::vector<void*> pinned;
+    int cap_eff = 0, cap_frames = 0;
+    void free_pinned() { for (void* q : pinned) rt::hfree(q); pinned.clear(); }
     bool gated = false;      // the window in the slot came through ry_vc_submit_wave
     float *d_x = nullptr, *d_y1 = nullptr, *d_mc = nullptr, *d_sp = nullptr, *d_out = nullptr;
     int* d_row = nullptr;
@@ -1908,10 +1913,6 @@ struct ry_vc {
     int M = 0, F = 0;
     Arena arena;
     float* d_mtx = nullptr;
-    // per-shape buffers (re-allocated when a larger window arrives)
-    Arena bufs;
-    std::vector<void*> pinned;
-    int cap_eff = 0, cap_frames = 0;
     VcSlot slot[RING];
     bool has_ev = false;
     int next_ticket = 0;
@@ -1944,52 +1945,61 @@ struct ry_vc {
     size_t b_cap_y1 = 0, b_cap_sp = 0;
     rt::Event b_mid, b_done;
     bool b_ev = false, b_used = false;
-    void free_pinned() { for (void* q : pinned) rt::hfree(q); pinned.clear(); }
+    void free_pinned() { for (VcSlot& sl : slot) sl.free_pinned(); }
 };
 
-static int vc_halloc(ry_vc* vc, void** p, size_t bytes) {
+static int vc_halloc(VcSlot& sl, void** p, size_t bytes) {
     rt::err_t e = rt::hmalloc(p, bytes);
     if (e != 0) return fail(RY_ENOMEM, "pinned host allocation of %zu bytes failed: %s", bytes, rt::err_str(e));
-    vc->pinned.push_back(*p);
+    sl.pinned.push_back(*p);
     return RY_OK;
 }
 
-static int vc_reserve(ry_vc* vc, int n_eff, int n_frames) {
-    if (n_eff <= vc->cap_eff && n_frames <= vc->cap_frames) return RY_OK;
-    for (VcSlot& sl : vc->slot)
-        if (sl.ticket >= 0) return fail(RY_ESTATE, "a larger window arrived while ticket %d is still in flight: ry_vc_wait it first", sl.ticket);
-    vc->sync_lanes();
-    vc->bufs.release(); vc->free_pinned();
-    const int ce = n_eff > vc->cap_eff ? n_eff : vc->cap_eff, cf = n_frames > vc->cap_frames ? n_frames : vc->cap_frames;
+// Size ONE ring slot for a window (grown on demand; the other slots, and the windows they may hold, are not touched).
+static int vc_reserve_slot(ry_vc* vc, VcSlot& sl, int n_eff, int n_frames) {
+    if (n_eff <= sl.cap_eff && n_frames <= sl.cap_frames) return RY_OK;
+    if (sl.ticket >= 0) return fail(RY_ESTATE, "ring slot is held by ticket %d: ry_vc_wait it first", sl.ticket);
+    if (sl.used) RT_TRY(rt::event_sync(sl.ev_done));           // a device-pointer window may still be running on the slot's buffers
+    if (&sl == &vc->slot[0]) { rt::stream_sync(vc->s1->stream); rt::stream_sync(vc->s2->stream); }   // the split calls work on slot 0 without events
+    sl.bufs.release(); sl.free_pinned();
+    const int ce = n_eff > sl.cap_eff ? n_eff : sl.cap_eff, cf = n_frames > sl.cap_frames ? n_frames : sl.cap_frames;
+    sl.cap_eff = sl.cap_frames = 0;
     const int cin = vc->s1->desc.in_ch;
     const size_t e1 = (size_t)(ce > 0 ? ce : 1);
-    for (VcSlot& sl : vc->slot) {
-        float* rowbuf = nullptr;
-        RY_TRY(vc->bufs.alloc(&sl.d_x, e1 * cin));
-        RY_TRY(vc->bufs.alloc(&sl.d_y1, e1 * vc->M));
-        RY_TRY(vc->bufs.alloc(&rowbuf, e1));
-        RY_TRY(vc->bufs.alloc(&sl.d_mc, (size_t)cf * vc->M));
-        RY_TRY(vc->bufs.alloc(&sl.d_sp, (size_t)cf * vc->F));
-        RY_TRY(vc->bufs.alloc(&sl.d_out, (size_t)cf * vc->F));
-        sl.d_row = (int*)rowbuf;
-        RY_TRY(vc_halloc(vc, (void**)&sl.h_x, e1 * cin * sizeof(float)));
-        RY_TRY(vc_halloc(vc, (void**)&sl.h_row, e1 * sizeof(int)));
-        RY_TRY(vc_halloc(vc, (void**)&sl.h_mc, (size_t)cf * vc->M * sizeof(float)));
-        RY_TRY(vc_halloc(vc, (void**)&sl.h_sp, (size_t)cf * vc->F * sizeof(float)));
-        // gate buffers: the feature block of ALL frames, one power per frame, the mask and the count (the wave buffer is sized on demand)
-        float* q = nullptr;
-        RY_TRY(vc->bufs.alloc(&sl.d_feat, (size_t)cf * cin));
-        RY_TRY(vc->bufs.alloc(&sl.d_pow, (size_t)cf + 8));
-        RY_TRY(vc->bufs.alloc(&q, (size_t)cf / 4 + 4)); sl.d_mask = (unsigned char*)q;
-        RY_TRY(vc->bufs.alloc(&q, 4)); sl.d_count = (int*)q;
-        RY_TRY(vc_halloc(vc, (void**)&sl.h_feat, (size_t)cf * cin * sizeof(float)));
-        RY_TRY(vc_halloc(vc, (void**)&sl.h_mask, (size_t)cf + 16));
-        RY_TRY(vc_halloc(vc, (void**)&sl.h_count, 16));
-        sl.h_wave = nullptr; sl.d_wave = nullptr; sl.cap_wave = 0;
-        sl.used = false;
-    }
-    vc->cap_eff = ce; vc->cap_frames = cf;
-    vc->split_eff = -1;
+    float* rowbuf = nullptr;
+    RY_TRY(sl.bufs.alloc(&sl.d_x, e1 * cin));
+    RY_TRY(sl.bufs.alloc(&sl.d_y1, e1 * vc->M));
+    RY_TRY(sl.bufs.alloc(&rowbuf, e1));
+    RY_TRY(sl.bufs.alloc(&sl.d_mc, (size_t)cf * vc->M));
+    RY_TRY(sl.bufs.alloc(&sl.d_sp, (size_t)cf * vc->F));
+    RY_TRY(sl.bufs.alloc(&sl.d_out, (size_t)cf * vc->F));
+    sl.d_row = (int*)rowbuf;
+    RY_TRY(vc_halloc(sl, (void**)&sl.h_x, e1 * cin * sizeof(float)));
+    RY_TRY(vc_halloc(sl, (void**)&sl.h_row, e1 * sizeof(int)));
+    RY_TRY(vc_halloc(sl, (void**)&sl.h_mc, (size_t)cf * vc->M * sizeof(float)));
+    RY_TRY(vc_halloc(sl, (void**)&sl.h_sp, (size_t)cf * vc->F * sizeof(float)));
+    // gate buffers: the feature block of ALL frames, one power per frame, the mask and the count (the wave buffer is sized on demand)
+    float* q = nullptr;
+    RY_TRY(sl.bufs.alloc(&sl.d_feat, (size_t)cf * cin));
+    RY_TRY(sl.bufs.alloc(&sl.d_pow, (size_t)cf + 8));
+    RY_TRY(sl.bufs.alloc(&q, (size_t)cf / 4 + 4)); sl.d_mask = (unsigned char*)q;
+    RY_TRY(sl.bufs.alloc(&q, 4)); sl.d_count = (int*)q;
+    RY_TRY(vc_halloc(sl, (void**)&sl.h_feat, (size_t)cf * cin * sizeof(float)));
+    RY_TRY(vc_halloc(sl, (void**)&sl.h_mask, (size_t)cf + 16));
+    RY_TRY(vc_halloc(sl, (void**)&sl.h_count, 16));
+    sl.h_wave = nullptr; sl.d_wave = nullptr; sl.cap_wave = 0;
+    sl.used = false;
+    sl.cap_eff = ce; sl.cap_frames = cf;
+    if (&sl == &vc->slot[0]) vc->split_eff = -1;
+    return RY_OK;
+}
+
+// every slot (ry_vc_reserve_frames: ahead of time, nothing may be in flight)
+static int vc_reserve(ry_vc* vc, int n_eff, int n_frames) {
+    for (VcSlot& sl : vc->slot)
+        if (sl.ticket >= 0 && (n_eff > sl.cap_eff || n_frames > sl.cap_frames))
+            return fail(RY_ESTATE, "ticket %d is still in flight: ry_vc_wait it before reserving a larger ring", sl.ticket);
+    for (VcSlot& sl : vc->slot) RY_TRY(vc_reserve_slot(vc, sl, n_eff, n_frames));
     return RY_OK;
 }
 
@@ -2113,11 +2123,11 @@ int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, in
     if (!vc || !ticket || (n_eff > 0 && (!x_eff || !row_of))) return fail(RY_EINVAL, "null argument");
     RY_TRY(vc_check(vc, row_of, n_eff, n_frames, true));
     RT_TRY(rt::set_device(vc->s1->ctx->device));
-    RY_TRY(vc_reserve(vc, n_eff, n_frames));
     const int t = vc->next_ticket;
     VcSlot& sl = vc->slot[t % ry_vc::RING];
     ry_net *s1 = vc->lane1(t % ry_vc::RING), *s2 = vc->lane2(t % ry_vc::RING);
     if (sl.ticket >= 0) return fail(RY_ESTATE, "all %d ring slots are in flight: ry_vc_wait ticket %d first", ry_vc::RING, sl.ticket);
+    RY_TRY(vc_reserve_slot(vc, sl, n_eff, n_frames));
     const int cin = s1->desc.in_ch, M = vc->M, F = vc->F;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
     if (sl.used) RT_TRY(rt::stream_wait_event(st1, sl.ev_done));                        // (a device-pointer call may have used the slot last)
@@ -2179,8 +2189,8 @@ static int vc_gate_into_slot(ry_vc* vc, ry_net* s1, VcSlot& sl, const float* wav
     if (n_samples > sl.cap_wave) {                              // wave staging of this slot, grown on demand (owned by the ring's arenas)
         RT_TRY(rt::stream_sync(st1));
         const int cap = n_samples + n_samples / 4 + 1024;
-        RY_TRY(vc->bufs.alloc(&sl.d_wave, (size_t)cap));
-        RY_TRY(vc_halloc(vc, (void**)&sl.h_wave, (size_t)cap * sizeof(float)));
+        RY_TRY(sl.bufs.alloc(&sl.d_wave, (size_t)cap));
+        RY_TRY(vc_halloc(sl, (void**)&sl.h_wave, (size_t)cap * sizeof(float)));
         sl.cap_wave = cap;
     }
     memcpy(sl.h_wave, wave, (size_t)n_samples * sizeof(float));
@@ -2227,7 +2237,7 @@ int ry_vc_gate(ry_vc* vc, const float* wave, int n_samples, int hop, int fft_len
     RY_TRY(vc_gate_args(vc, wave, n_samples, hop, fft_length, feat, n_frames));
     if (!effective_out || !n_eff_out) return fail(RY_EINVAL, "null argument");
     RT_TRY(rt::set_device(vc->s1->ctx->device));
-    RY_TRY(vc_reserve(vc, n_frames, n_frames));
+    RY_TRY(vc_reserve_slot(vc, vc->slot[0], n_frames, n_frames));
     VcSlot& sl = vc->slot[0];
     if (sl.ticket >= 0) return fail(RY_ESTATE, "ring slot 0 is held by ticket %d: ry_vc_wait it first", sl.ticket);
     int n_eff = 0;
@@ -2247,11 +2257,11 @@ int ry_vc_submit_wave(ry_vc* vc, const float* wave, int n_samples, int hop, int 
     RY_TRY(vc_gate_args(vc, wave, n_samples, hop, fft_length, feat, n_frames));
     if (!ticket) return fail(RY_EINVAL, "null argument");
     RT_TRY(rt::set_device(vc->s1->ctx->device));
-    RY_TRY(vc_reserve(vc, n_frames, n_frames));
     const int t = vc->next_ticket;
     VcSlot& sl = vc->slot[t % ry_vc::RING];
     ry_net *s1 = vc->lane1(t % ry_vc::RING), *s2 = vc->lane2(t % ry_vc::RING);
     if (sl.ticket >= 0) return fail(RY_ESTATE, "all %d ring slots are in flight: ry_vc_wait ticket %d first", ry_vc::RING, sl.ticket);
+    RY_TRY(vc_reserve_slot(vc, sl, n_frames, n_frames));
     const int M = vc->M, F = vc->F;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
     int n_eff = 0;
@@ -2289,10 +2299,10 @@ int ry_vc_enqueue_device(ry_vc* vc, const float* x_eff_dev, const int* row_of_de
     if (!vc || !mc_out_dev || !sp_out_dev || (n_eff > 0 && (!x_eff_dev || !row_of_dev))) return fail(RY_EINVAL, "null argument");
     RY_TRY(vc_check(vc, nullptr, n_eff, n_frames, false));
     RT_TRY(rt::set_device(vc->s1->ctx->device));
-    RY_TRY(vc_reserve(vc, n_eff, n_frames));
     VcSlot& sl = vc->slot[vc->dev_count % ry_vc::RING];
     ry_net *s1 = vc->lane1(vc->dev_count % ry_vc::RING), *s2 = vc->lane2(vc->dev_count % ry_vc::RING);
     if (sl.ticket >= 0) return fail(RY_ESTATE, "ring slot %d is held by ticket %d: ry_vc_wait it first", vc->dev_count % ry_vc::RING, sl.ticket);
+    RY_TRY(vc_reserve_slot(vc, sl, n_eff, n_frames));
     ++vc->dev_count;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
     if (sl.used) RT_TRY(rt::stream_wait_event(st1, sl.ev_done));                        // the slot's previous window has left d_sp
@@ -2393,7 +2403,7 @@ int ry_vc_stage1(ry_vc* vc, const float* x_eff, int n_eff, float* y1_out) {
     if (!vc || !x_eff || !y1_out || n_eff < 1) return fail(RY_EINVAL, "bad argument");
     ry_net* s1 = vc->s1;
     RT_TRY(rt::set_device(s1->ctx->device));
-    RY_TRY(vc_reserve(vc, n_eff, n_eff));
+    RY_TRY(vc_reserve_slot(vc, vc->slot[0], n_eff, n_eff));
     VcSlot& sl = vc->slot[0];
     if (sl.ticket >= 0) return fail(RY_ESTATE, "ring slot 0 is held by ticket %d: ry_vc_wait it first", sl.ticket);
     const int cin = s1->desc.in_ch;
@@ -2410,15 +2420,15 @@ int ry_vc_stage1(ry_vc* vc, const float* x_eff, int n_eff, float* y1_out) {
 
 // the window is longer than the ring was sized for: grow it without losing the rows stage 1 left in slot 0
 static int vc_grow_keep_rows(ry_vc* vc, int n_frames) {
-    if (n_frames <= vc->cap_frames) return RY_OK;
+    if (n_frames <= vc->slot[0].cap_frames) return RY_OK;
     const int keep = vc->split_eff;
-    if (keep <= 0) return vc_reserve(vc, vc->cap_eff, n_frames);
+    if (keep <= 0) return vc_reserve_slot(vc, vc->slot[0], vc->slot[0].cap_eff, n_frames);
     Arena tmp;
     float* t = nullptr;
     RY_TRY(tmp.alloc(&t, (size_t)keep * vc->M));
     RT_TRY(rt::d2d(t, vc->slot[0].d_y1, (size_t)keep * vc->M * sizeof(float), vc->s1->stream));
     RT_TRY(rt::stream_sync(vc->s1->stream));
-    RY_TRY(vc_reserve(vc, vc->cap_eff, n_frames));
+    RY_TRY(vc_reserve_slot(vc, vc->slot[0], vc->slot[0].cap_eff, n_frames));
     RT_TRY(rt::d2d(vc->slot[0].d_y1, t, (size_t)keep * vc->M * sizeof(float), vc->s1->stream));
     RT_TRY(rt::stream_sync(vc->s1->stream));
     vc->split_eff = keep;

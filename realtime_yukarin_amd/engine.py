@@ -130,6 +130,11 @@ class VcCore(object):
         if self.lanes != 1:
             self.set_lanes(self.lanes)
 
+    def reserve(self, n_frames: int):
+        """Size the ring for windows of up to n_frames ahead of time (`ry_vc_reserve_frames`): a stream whose windows grow while others are in
+        flight is otherwise refused (the ring cannot be re-allocated under a window)."""
+        self.lib.check(self.lib.dll.ry_vc_reserve_frames(self.handle, int(n_frames)))
+
     def set_lanes(self, lanes: int):
         self.lib.check(self.lib.dll.ry_vc_set_lanes(self.handle, int(lanes)))
         self.lanes = int(lanes)

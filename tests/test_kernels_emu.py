@@ -197,7 +197,7 @@ def test_stage2_dead_row_crop_emu(emu_ctx, monkeypatch):
     net = engine.Net(emu_ctx, d, flatten_params(d, P), width=16)
     reread = lambda: emu_ctx.lib.check(emu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
     try:
-        for n in (11, 30, 127):
+        for n in (11, 127):
             sp = numpy.exp(numpy.random.default_rng(40 + n).normal(-6.0, 1.5, (n, 17))).astype('f4')
             monkeypatch.setenv('RY_S2_CROP', '0'); reread()
             whole = net.convert(sp)
@@ -206,7 +206,7 @@ def test_stage2_dead_row_crop_emu(emu_ctx, monkeypatch):
             cropped = net.convert(sp)
             g_crop = {q['layer']: q['grid'] for q in net.profile(1, n, 1, window=True)}
             assert numpy.array_equal(whole, cropped), n
-            if n == 30:                                                 # two windows in one call: a row prefix of EVERY image
+            if n == 11:                                                 # two windows in one call: a row prefix of EVERY image
                 sp2 = numpy.stack([sp, sp[::-1]])
                 both = net.convert(sp2)
                 assert numpy.array_equal(both[0], cropped)
