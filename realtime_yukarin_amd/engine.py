@@ -135,6 +135,15 @@ class VcCore(object):
         flight is otherwise refused (the ring cannot be re-allocated under a window)."""
         self.lib.check(self.lib.dll.ry_vc_reserve_frames(self.handle, int(n_frames)))
 
+    def warm(self, n_frames: int, rounds: int = 2):
+        """Build the launch plans and capture the graphs of every ring slot for windows of n_frames before the first real window
+        arrives (each slot otherwise pays them on its first window: tens of milliseconds, once).  Silence-gated windows of another
+        effective length still build their stage-1 plan on first sight."""
+        x = numpy.zeros((int(n_frames), self.stage1.desc.in_ch), numpy.float32)
+        eff = numpy.ones(int(n_frames), bool)
+        for _ in range(6 * int(rounds)):
+            self.convert(x, eff)
+
     def set_lanes(self, lanes: int):
         self.lib.check(self.lib.dll.ry_vc_set_lanes(self.handle, int(lanes)))
         self.lanes = int(lanes)

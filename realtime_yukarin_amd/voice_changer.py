@@ -41,6 +41,8 @@ class VoiceChanger(object):
             mtx = ac.mc2sp_matrix()
             self._core = engine.VcCore(ac._get_net(), sr._get_net(mtx.shape[1]), mtx)
             self._core_pid = key
+            if os.environ.get('RY_VC_WARM'):                   # e.g. RY_VC_WARM=300: plans and graphs of every ring slot before the first window
+                self._core.warm(int(os.environ['RY_VC_WARM']))
         return self._core
 
     def close(self) -> None:
