@@ -215,12 +215,23 @@ def main(argv=None):
         for _ in range(args.warmup):
             step()
         fence()
+        # The opening barrier leaves the chip idle for as long as the slowest rank (and the collective itself) takes; after >= 10 ms of idling
+        # the first millisecond or two of work runs at ramping clocks (measured: 40 steps 1.13 -> 1.19 ms per step after a 10 ms pause, with or
+        # without torch.distributed; under torch.distributed 1.173 / 1.145 / 1.137 ms with 0 / 2 / 8 such steps).  Four more untimed steps and a LOCAL synchronize put every rank back at working clocks; the clock starts
+        # microseconds later, with the ranks as aligned as the barrier left them.
+        for _ in range(4):
+            step()
+        sync_all()
         t0 = time.perf_counter()
         ctx.timer_start()
         for _ in range(args.steps):
             step()
+        sync_all()                              # this rank's K steps are done: its clock stops here; the ranks started together (fence above) and
+        el = time.perf_counter() - t0           # the job time is the maximum over the ranks (comm.max below) -- the closing barrier itself is not work
         fence()
-        el = time.perf_counter() - t0
+        el_fenced = time.perf_counter() - t0
+        if os.environ.get('BENCH_DEBUG_FENCE'):
+            print('rank %d: %.3f ms for the steps, %.3f ms with the closing barrier' % (rank, el * 1e3, el_fenced * 1e3), file=sys.stderr, flush=True)
         # device-side stamp AFTER the fence: ry_timer_stop while the lanes still have work queued (an event record on every predictor
         # stream plus cross-stream waits) was measured to cost the two lanes their overlap for the whole run (1.33 vs 1.16 ms per window)
         dms = ctx.timer_stop()
