@@ -214,11 +214,12 @@ def main(argv=None):
         # W untimed warm-up steps, then exactly K steps between barrier + synchronize fences; the maximum over the ranks
         for _ in range(args.warmup):
             step()
+        # Opening bracket: barrier + synchronize (fence), then four more untimed steps and a LOCAL synchronize.  The barrier leaves the chip
+        # idle for as long as the slowest rank and the collective take, and what runs right behind it runs slower for a millisecond or two
+        # (measured: 40 steps at 1.13 -> 1.19 ms per step after a 10 ms pause, with or without torch.distributed; behind a torch.distributed
+        # barrier 1.173 / 1.145 / 1.137 ms with 0 / 2 / 8 such steps; queueing the steps UNDER the barrier instead does not help: 1.179).
+        # The clock starts microseconds after the chip last worked, the ranks as aligned as the barrier left them four steps earlier.
         fence()
-        # The opening barrier leaves the chip idle for as long as the slowest rank (and the collective itself) takes; after >= 10 ms of idling
-        # the first millisecond or two of work runs at ramping clocks (measured: 40 steps 1.13 -> 1.19 ms per step after a 10 ms pause, with or
-        # without torch.distributed; under torch.distributed 1.173 / 1.145 / 1.137 ms with 0 / 2 / 8 such steps).  Four more untimed steps and a LOCAL synchronize put every rank back at working clocks; the clock starts
-        # microseconds later, with the ranks as aligned as the barrier left them.
         for _ in range(4):
             step()
         sync_all()
