@@ -368,6 +368,29 @@ def main(argv=None):
                                              'the headline step is one 0.5 s buffer at a time, as the reference converts'}
             for q in (d_bx, d_br, d_bmc, d_bsp):
                 ctx.dev_free(q)
+            # the same step when the caller announces the frames it will throw away (ConvertStream.process keeps the buffer in the middle of
+            # the window it converted; worker.convert_worker passes its pad): stage 2 computes the kept rows only.  NOT the headline -- the
+            # headline returns every frame of every window -- but what a live stream built on the mirror worker runs.
+            if extra > 0:
+                core.set_discard(extra, extra)
+                for _ in range(12):
+                    step()
+                sync_all()
+                td = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                sync_all()
+                d_ms = (time.perf_counter() - td) / args.steps / Wn * 1e3
+                spd = numpy.empty_like(sp_gpu); ctx.dev_download(d_sp[turn['w0']], spd)
+                core.set_discard(0, 0)
+                for _ in range(12):
+                    step()
+                sync_all()
+                out['discard_hint'] = {'discard_front_back': [extra, extra], 'ms_per_window': round(d_ms, 4),
+                                       'effective_x_realtime': round((N - 2 * extra) * 0.005 / (d_ms * 1e-3), 1),
+                                       'kept_rows_bit_identical_to_the_full_step': bool(numpy.array_equal(spd[extra:N - extra], sp_gpu[extra:N - extra])),
+                                       'note': 'ry_vc_set_discard: the decoder layers of stage 2 run on the row range the kept frames depend on; '
+                                               'encoder and bottom of the U-Net whole; stage 1 whole; not the headline (the headline returns all frames)'}
             # the silence gate on this box's host (is it worth a kernel?)
             compat_dir = ROOT / 'realtime_yukarin_amd' / 'compat'
             sys.path.insert(0, str(compat_dir))

@@ -92,6 +92,10 @@ int ry_ac_convert(ry_net* stage1, const float* x, float* y, int batch, int n_fra
 /* `SuperResolution.convert` (voice_changer.py:41): sp [batch][n_frames][width+1] -> pad 'minimum' -> log ->
  * drop last bin -> SRPredictor -> edge-pad one bin -> exp -> crop -> out [batch][n_frames][width+1]. */
 int ry_sr_convert(ry_net* stage2, const float* sp, float* out, int batch, int n_frames, int on_device);
+/* ry_sr_convert for a caller that discards the first `discard_front` / last `discard_back` frames of every window: rows
+ * [discard_front, n_frames - discard_back) of `out` are written (bit-identical to ry_sr_convert); the others come back as zeros
+ * (host arrays) or are left untouched (device pointers). */
+int ry_sr_convert_rows(ry_net* net, const float* sp, float* out, int batch, int n_frames, int discard_front, int discard_back, int on_device);
 
 /* ---- single operators (the Chainer links of SURVEY.md section 2.1), host pointers, Chainer weight layouts ---- */
 /* L.ConvolutionND(1) / L.DeconvolutionND(1) [+ L.BatchNormalization] [+ activation].  x [B][L][Cin] ->
@@ -124,6 +128,12 @@ int ry_vc_convert(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, i
  * a ticket WITHOUT waiting; ry_vc_wait blocks for that ticket and copies the results out.  H2D of window i + 1 and D2H of window i - 1
  * run under the kernels of window i.  ry_vc_convert == submit + wait.  RY_ESTATE when all slots are in flight. */
 int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, int n_frames, float sp_floor, int* ticket);
+/* The caller will throw away the first `front` and the last `back` frames of every window it gets back -- ConvertStream.process converts
+ * buffer + 2 x extra_time and picks the buffer (realtime_voice_conversion/stream/convert_stream.py:40-42).  Stage 2 then computes only the
+ * rows that are kept (decoder layers on the row range they depend on; encoder and bottom of the U-Net whole); the kept rows are bit-identical
+ * to the full result, the discarded rows of the returned spectrogram are zero (device-pointer calls: left untouched), mc is always complete.
+ * Applies to every following ry_vc_submit / ry_vc_submit_wave / ry_vc_enqueue_device until changed; (0, 0) = everything. */
+int ry_vc_set_discard(ry_vc* vc, int front, int back);
 /* Lanes: with `lanes` = 2 or 3 the ring slots run on their own predictor handles (ry_net_clone of the pair given to ry_vc_create: one
  * copy of the filters, separate streams / launch plans / activations), so that the windows in flight execute side by side instead of
  * one stage-2 forward after the other.  Same results.  Device-pointer callers (ry_vc_enqueue_device) must then give windows that are in

@@ -1098,9 +1098,11 @@ struct RySrLastParams {
     const float* w;             // [9][C1+C2]
     const float* scale;         // [1]
     const float* shift;         // [1]
-    float* out;                 // [B][rows_valid][out_cols]
+    float* out;                 // [B][out_rows][out_cols]
     int B, H, W;
-    int rows_valid;             // rows >= rows_valid are padding and are not computed
+    int rows_valid;             // number of output rows computed: rows row0 .. row0 + rows_valid - 1 (the padding behind the real frames is never computed)
+    int row0;                   // first output row (> 0 when the caller discards the leading frames of the window, ry_sr_convert_rows)
+    int out_rows;               // rows per image of `out` (the real frames of the window)
     int out_cols;               // W, or W + 1 with the last bin repeated (pad mode 'edge')
     int do_exp;
     int x3;                     // sources are split-bf16 copies [pixel][hi | lo] (rolling form only)
@@ -1115,7 +1117,7 @@ RY_KERNEL(256) void ry_sr_last_gather(RySrLastParams p) {
     const bool live = pix < total;
     const long long pp = live ? pix : 0;
     const int x = (int)(pp % p.W);
-    const int y = (int)((pp / p.W) % p.rows_valid);
+    const int y = (int)((pp / p.W) % p.rows_valid) + p.row0;
     const int b = (int)(pp / ((long long)p.W * p.rows_valid));
     const int Ctot = p.C1 + p.C2;
     float acc = 0.f;
@@ -1139,7 +1141,7 @@ RY_KERNEL(256) void ry_sr_last_gather(RySrLastParams p) {
     if (live && l == 0) {
         float v = fmaf(acc, p.scale[0], p.shift[0]);
         if (p.do_exp) v = expf(v);
-        float* o = p.out + ((size_t)b * p.rows_valid + y) * p.out_cols;
+        float* o = p.out + ((size_t)b * p.out_rows + y) * p.out_cols;
         o[x] = v;
         if (x == p.W - 1 && p.out_cols > p.W) o[p.W] = v;
     }
@@ -1171,7 +1173,7 @@ RY_KERNEL(256, 2) void ry_sr_last(RySrLastParams p) {
     const bool live = sid < total;
     const long long ss = live ? sid : 0;
     const int x0 = (int)(ss % strips) * SW;
-    const int y = (int)((ss / strips) % p.rows_valid);
+    const int y = (int)((ss / strips) % p.rows_valid) + p.row0;
     const int b = (int)(ss / ((long long)strips * p.rows_valid));
     const int c = l * 4;
     const bool first = c < p.C1;
@@ -1254,7 +1256,7 @@ RY_KERNEL(256, 2) void ry_sr_last(RySrLastParams p) {
         const int x = x0 + col;
         float v = fmaf(r1, p.scale[0], p.shift[0]);
         if (p.do_exp) v = expf(v);
-        float* o = p.out + ((size_t)b * p.rows_valid + y) * p.out_cols;
+        float* o = p.out + ((size_t)b * p.out_rows + y) * p.out_cols;
         o[x] = v;
         if (x == p.W - 1 && p.out_cols > p.W) o[p.W] = v;
     }

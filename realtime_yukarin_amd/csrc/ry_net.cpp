@@ -372,7 +372,9 @@ struct LayerPlan {
     float* slabs = nullptr;
     int crop_hi = 0;                          // > 0 (set per enqueue, one window): the layer runs on the first crop_hi input rows only -- the rows behind them feed nothing but
                                               // output rows the convert wrapper throws away (dead padding rows, see enqueue_forward)
+    int crop_lo = 0;                          // ... starting at this input row (> 0 when the caller discards the leading frames of the window too)
     int last_rows = 0, last_cols = 0, last_exp = 0;   // PATH_LAST: fused exp / edge-pad / crop
+    int last_row0 = 0, last_out_rows = 0;     // PATH_LAST: first output row computed, rows per image of the caller's block (0: last_rows)
     bool last_x3 = false;                     // PATH_LAST in split-bf16 mode: reads the producers' [hi | lo] copies instead of fp32 ones
     double flops = 0, bytes = 0;
 };
@@ -381,6 +383,7 @@ struct Plan {
     int B = 0, T = 0;
     int mode = 0;                             // 0 = forward, 1 = convert wrapper
     int n_frames = 0;
+    int disc_front = 0, disc_back = 0;        // convert mode, stage 2: the caller throws away this many leading / trailing frames of every window (ry_sr_convert_rows)
     Arena arena;
     std::vector<LayerPlan> lp;
     float* user_in = nullptr;                 // staging of the caller's input
@@ -395,7 +398,7 @@ struct Plan {
     // one captured graph per (input, output) address pair the plan has been run with: host callers (plan staging), device callers
     // and the ring slots of ry_vc each keep their own, so switching between them neither re-captures nor destroys an exec that
     // may still be in flight
-    struct GraphSlot { const float* in; float* out; hipGraphExec_t gexec; hipGraphExec_t gexec2; bool tried; int graph_n, last_n; unsigned long long used; };
+    struct GraphSlot { const float* in; float* out; hipGraphExec_t gexec; hipGraphExec_t gexec2; bool tried; long long graph_n, last_n; unsigned long long used; };
     std::vector<GraphSlot> gslots;
     unsigned long long gclock = 0;
     ~Plan() { for (GraphSlot& g : gslots) { if (g.gexec) hipGraphExecDestroy(g.gexec); if (g.gexec2) hipGraphExecDestroy(g.gexec2); } }
@@ -503,12 +506,17 @@ static void fill_geom(RyConvGeom& g, const Layer& l, const LayerPlan& lp, int B,
     if (lp.path == PATH_IGEMM_BF16 && lp.x3) { g.C1 = 3 * C1; g.C2 = 3 * C2; g.S1 = 2 * C1; g.S2 = 2 * C2; }   // K = [hi | lo | hi(wrapped)] over [hi | lo] pixels
     g.B = B; g.Hi = lp.Hi; g.Wi = lp.Wi; g.Ho = lp.Ho; g.Wo = lp.Wo;
     g.Hs = lp.Hi; g.Hos = lp.Ho;
-    if (lp.crop_hi > 0) { g.Hi = lp.crop_hi; g.Ho = l.deconv ? 2 * lp.crop_hi : lp.crop_hi; }   // a row prefix of every image in the same buffers; rows from crop_hi on read as padding
+    if (lp.crop_hi > 0) { g.Hi = lp.crop_hi; g.Ho = l.deconv ? 2 * lp.crop_hi : lp.crop_hi; }   // a row range of every image in the same buffers; the rows around it read as padding
     if (l.deconv) { g.Mh = g.Hi; g.Mw = lp.Wi; g.stride = 1; g.pad = 0; g.ostride = 2; }
     else { g.Mh = g.Ho; g.Mw = lp.Wo; g.stride = l.stride; g.pad = l.pad; g.ostride = 1; }
     g.nphases = t.nphases; g.ntaps = t.ntaps; g.N = l.cout; g.kw = l.deconv ? 2 : l.k; g.dil = l.deconv ? 1 : l.dil;
     const size_t esize = lp.path == PATH_IGEMM_BF16 ? 2 : 4;                  // implicit-GEMM sources end in a zeroed tail (ZTAIL floats)
     g.zoff1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * g.S1 * esize); g.zoff2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * g.S2 * esize);
+    if (lp.crop_hi > 0 && lp.crop_lo > 0) {                                   // the range starts crop_lo rows into every image: move the bases, keep the zero tails where they are
+        const size_t o1 = (size_t)lp.crop_lo * lp.Wi * g.S1 * esize, o2 = (size_t)lp.crop_lo * lp.Wi * g.S2 * esize;
+        g.src1 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(s1) + o1); g.zoff1 -= (unsigned)o1;
+        if (s2) { g.src2 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(s2) + o2); g.zoff2 -= (unsigned)o2; }
+    }
     for (int ph = 0; ph < 4; ++ph) {
         g.pdy[ph] = (signed char)t.pdy[ph]; g.pdx[ph] = (signed char)t.pdx[ph];
         for (int tt = 0; tt < 16; ++tt) { g.tdy[ph][tt] = (signed char)t.dy[ph][tt]; g.tdx[ph][tt] = (signed char)t.dx[ph][tt]; }
@@ -699,8 +707,10 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         p.x3 = lp.o16x3 ? 1 : 0;
         p.splits = lp.splits; p.act = l.act; p.slope = slope;
         p.slab_stride = (long long)B * lp.Ho * lp.Wo * l.cout;
-        p.out = lp.splits > 1 ? lp.slabs : (lp.w32 ? lp.out : nullptr);
-        p.out16 = (lp.splits == 1 && lp.w16) ? lp.out16 : nullptr;
+        // output rows start (2 x for the sub-pixel form) crop_lo rows into every image
+        const size_t oo = lp.crop_hi > 0 ? (size_t)(l.deconv ? 2 : 1) * lp.crop_lo * lp.Wo * l.cout : 0;
+        p.out = lp.splits > 1 ? lp.slabs + oo : (lp.w32 ? lp.out + oo : nullptr);
+        p.out16 = (lp.splits == 1 && lp.w16) ? lp.out16 + oo * (lp.o16x3 ? 2 : 1) : nullptr;
         int bm, bn; tile_dims(lp.tile, &bm, &bn);
         p.mtiles = (M + bm - 1) / bm; p.ntiles = l.cout / bn;
         p.tw = 0;
@@ -800,8 +810,9 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         RY_TRY(Lc.end());
         if (lp.splits > 1) {
             RyReduceParams r;
-            r.slabs = lp.slabs; r.splits = lp.splits; r.slab_stride = p.slab_stride;
-            r.scale = l.scale; r.shift = l.shift; r.out = lp.w32 ? lp.out : nullptr; r.out16 = lp.w16 ? lp.out16 : nullptr;
+            const size_t ro = B == 1 ? oo : 0;                                    // one window: only the rows this launch wrote
+            r.slabs = lp.slabs + ro; r.splits = lp.splits; r.slab_stride = p.slab_stride;
+            r.scale = l.scale; r.shift = l.shift; r.out = lp.w32 ? lp.out + ro : nullptr; r.out16 = lp.w16 ? lp.out16 + ro * (lp.o16x3 ? 2 : 1) : nullptr;
             r.x3 = lp.o16x3 ? 1 : 0;
             r.total = B == 1 ? (long long)g.Ho * lp.Wo * l.cout : p.slab_stride; r.N = l.cout;      // one window: only the rows this launch wrote (a prefix when cropped)
             r.act = l.act; r.slope = slope;
@@ -836,6 +847,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         p.src1 = s1; p.src2 = s2; p.C1 = C1; p.C2 = C2; p.w = l.wdir; p.scale = l.scale; p.shift = l.shift;
         p.out = lp.out; p.B = B; p.H = lp.Hi; p.W = lp.Wi;
         p.rows_valid = lp.last_rows; p.out_cols = lp.last_cols; p.do_exp = lp.last_exp;
+        p.row0 = lp.last_row0; p.out_rows = lp.last_out_rows > 0 ? lp.last_out_rows : lp.last_rows;
         const long long total = (long long)B * p.rows_valid * lp.Wi;
         dim3 grid((unsigned)((total + 7) / 8));
         if (C1 + C2 == 128 && lp.Wi % 16 == 0) {
@@ -1218,38 +1230,48 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
         else RY_LAUNCH(ry_pad_min_rows<16>, pg, 256, Lc.stream, q);
         RY_TRY(Lc.end());
     }
-    // Stage 2, convert wrapper: the wrapper pads every window to T rows and keeps n_frames of the result
-    // (SuperResolution.convert crops), so the last layer reads rows [0, n_frames + 1) of decoder c6 and nothing ever reads the
-    // rows behind them.  Walking back through the decoder: R correct output rows of a k4 s2 p1 deconvolution need input rows
-    // [0, ceil((R + 1) / 2)) (output row 2m + 1 takes input row m + 1).  Rows are the outermost axis of the NHWC buffers, so a
-    // layer simply runs on a row prefix of the same buffers (LayerPlan::crop_hi; the first dropped row reads as zero padding, which
-    // only reaches rows that are not needed).  The encoder feeds the bottom of the U-Net and stays whole.
-    int crop[16];
-    for (int i = 0; i < 16; ++i) crop[i] = 0;
+    // Stage 2, convert wrapper: the wrapper pads every window to T rows and keeps n_frames of the result (SuperResolution.convert crops);
+    // a caller that will itself throw away the first / last frames of the window (ConvertStream.process picks the middle of what it
+    // converted) can say so (ry_sr_convert_rows).  The last layer then computes output rows [k0, k1) only, reads rows [k0 - 1, k1 + 1) of
+    // decoder c6, and nothing ever reads the other rows.  Walking back through the decoder: correct output rows [a, b) of a k4 s2 p1
+    // deconvolution need input rows [floor((a - 1) / 2), floor(b / 2) + 1) (output row 2m takes input rows m - 1 and m, row 2m + 1 rows m
+    // and m + 1).  Rows are the outermost axis of the NHWC buffers, so a layer simply runs on a row RANGE of the same buffers
+    // (LayerPlan::crop_lo / crop_hi; the rows next to the range read as zero padding, which only reaches rows that are not needed).
+    // Every layer demands from its producer exactly the (tile-rounded) rows it reads.  The encoder feeds the bottom of the U-Net and stays whole.
+    int crop[16], crop0[16];
+    for (int i = 0; i < 16; ++i) crop[i] = crop0[i] = 0;
+    int k0 = 0, k1 = P.n_frames;
+    if (nd == 2 && P.mode == 1 && P.lp[15].path == PATH_LAST) {
+        k0 = P.disc_front < P.n_frames ? P.disc_front : 0;
+        k1 = P.n_frames - P.disc_back > k0 ? P.n_frames - P.disc_back : P.n_frames;
+        if (k1 <= k0) { k0 = 0; k1 = P.n_frames; }
+    }
     if (nd == 2 && P.mode == 1 && g_s2_crop && P.lp[15].path == PATH_LAST && net->layers[15].src_a == 14) {
-        int need = P.n_frames + 1;                                   // correct rows wanted from layer i's output
+        int need0 = k0 > 0 ? k0 - 1 : 0, need1 = k1 + 1;             // correct rows [need0, need1) wanted from layer i's output
         for (int i = 14; i >= 8; --i) {
             const Layer& l = net->layers[i];
             const LayerPlan& lp = P.lp[i];
-            if (need >= lp.Ho) break;
+            if (need1 > lp.Ho) need1 = lp.Ho;
+            if (need0 <= 0 && need1 >= lp.Ho) break;
             if (lp.path != PATH_IGEMM && lp.path != PATH_IGEMM_BF16) break;
             if (l.src_a != i - 1) break;
-            int rows;
-            if (l.deconv) rows = (need + 2) / 2;                    // ceil((need + 1) / 2)
-            else if (l.k == 1 && l.stride == 1) rows = need;
+            int r0, r1;
+            if (l.deconv) { r0 = need0 > 0 ? (need0 - 1) / 2 : 0; r1 = need1 / 2 + 1; }
+            else if (l.k == 1 && l.stride == 1) { r0 = need0; r1 = need1; }
             else break;
             int bm, bn; tile_dims(lp.tile, &bm, &bn);
             const int Mw = l.deconv ? lp.Wi : lp.Wo, Mh = l.deconv ? lp.Hi : lp.Ho;
             for (int tw = 16; tw >= 4; tw >>= 1)                      // keep the 2-D pixel tiles of launch_conv2d: whole tile rows
-                if (bm % tw == 0 && Mw % tw == 0 && Mh % (bm / tw) == 0) { const int th = bm / tw; rows = (rows + th - 1) / th * th; break; }
-            if (rows >= lp.Hi) break;
+                if (bm % tw == 0 && Mw % tw == 0 && Mh % (bm / tw) == 0) { const int th = bm / tw; r0 = r0 / th * th; r1 = (r1 + th - 1) / th * th; break; }
+            if (r1 > lp.Hi) r1 = lp.Hi;
+            if (r0 <= 0 && r1 >= lp.Hi) break;
             // measured at 300 frames (scripts/gpu_r2_ab3.sh): decoder c6 (1536 -> 1216 workgroups, six per CU -> five) 208 -> 177 us, decoder c5
             // (512 -> 416, two per CU) 198 -> 193 us, decoder c4 (256 -> 224, one per CU) 196 -> 194 us: a grid of one workgroup per CU
             // gains nothing by itself, but the CUs it leaves idle go to the window on the other lane (ry_vc_set_lanes): 1.160 -> 1.137 ms
             // per window with two lanes, so it is cropped too (RY_S2_CROP=1 keeps such grids whole)
             const long wgs = (long)(((long)B * Mh * Mw + bm - 1) / bm) * (l.cout / bn) * (l.deconv ? 4 : 1) * lp.splits;
-            if (g_s2_crop >= 2 || wgs > 256) { crop[i] = rows; need = rows; }
-            else need = lp.Hi;                                       // this layer runs whole: it reads every row of its producer
+            if (g_s2_crop >= 2 || wgs > 256) { crop0[i] = r0; crop[i] = r1 - r0; need0 = r0; need1 = r1; }
+            else { need0 = 0; need1 = lp.Hi; }                      // this layer runs whole: it reads every row of its producer
         }
     }
     for (int i = lo; i < hi; ++i) {
@@ -1270,8 +1292,8 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
             const float* s2 = l.src_b < 0 ? nullptr : in16 ? reinterpret_cast<const float*>(P.lp[l.src_b].out16) : P.lp[l.src_b].out;
             LayerPlan lq = lp;
             if (i == 15 && (P.mode == 0 || lp.path == PATH_LAST)) lq.out = P.cur_out;   // last layer writes the caller's block
-            if (i == 15 && P.mode == 1 && lp.path == PATH_LAST) lq.last_rows = P.n_frames;
-            if (crop[i] > 0) { lq.crop_hi = crop[i]; lq.flops = lp.flops * crop[i] / lp.Hi; lq.bytes = lp.bytes * crop[i] / lp.Hi; }
+            if (i == 15 && P.mode == 1 && lp.path == PATH_LAST) { lq.last_rows = k1 - k0; lq.last_row0 = k0; lq.last_out_rows = P.n_frames; lq.flops = lp.flops * (k1 - k0) / lp.Ho; }
+            if (crop[i] > 0) { lq.crop_hi = crop[i]; lq.crop_lo = crop0[i]; lq.flops = lp.flops * crop[i] / lp.Hi; lq.bytes = lp.bytes * crop[i] / lp.Hi; }
             RY_TRY(launch_conv2d(Lc, l, lq, B, s1, l.cin_a, s2, l.cin_b, slope));
         }
     }
@@ -1434,13 +1456,15 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
     G->used = ++P.gclock;
     // the captured graph bakes n_frames into the wrapper kernels: replay only for the same n; a new n runs eagerly once and is
     // captured when it repeats (live windows have a constant n; windows cut by the silence gate vary)
-    if (G->gexec && G->graph_n != P.n_frames && G->last_n == P.n_frames) {
+    // (the shape a graph bakes in: the real frames and the frames the caller discards at either end)
+    const long long shape = (long long)P.n_frames + ((long long)P.disc_front << 20) + ((long long)P.disc_back << 40);
+    if (G->gexec && G->graph_n != shape && G->last_n == shape) {
         RT_TRY(rt::stream_sync(net->stream));             // the exec being replaced may still be running
         hipGraphExecDestroy(G->gexec); G->gexec = nullptr; G->tried = false;
         if (G->gexec2) { hipGraphExecDestroy(G->gexec2); G->gexec2 = nullptr; }
     }
-    const bool capture_now = net->use_graph && !G->tried && (P.mode == 0 || G->last_n == P.n_frames || G->last_n < 0);
-    G->last_n = P.n_frames;
+    const bool capture_now = net->use_graph && !G->tried && (P.mode == 0 || G->last_n == shape || G->last_n < 0);
+    G->last_n = shape;
     const bool split = net->split_at > 0 && net->split_at < 16;
     auto capture = [&](int part, hipGraphExec_t* ex) -> int {
         hipGraph_t graph = nullptr;
@@ -1458,14 +1482,14 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
     };
     if (capture_now) {
         G->tried = true;
-        G->graph_n = P.n_frames;
+        G->graph_n = shape;
         RY_TRY(capture(split ? 1 : 0, &G->gexec));
         if (split && G->gexec) {
             RY_TRY(capture(2, &G->gexec2));
             if (!G->gexec2) { hipGraphExecDestroy(G->gexec); G->gexec = nullptr; }
         }
     }
-    if (G->gexec && G->graph_n == P.n_frames) {
+    if (G->gexec && G->graph_n == shape) {
         RT_TRY(hipGraphLaunch(G->gexec, net->stream));
         if (split) {
             RT_TRY(rt::event_record(net->mid, net->stream)); net->mid_recorded = true;
@@ -1805,14 +1829,29 @@ int ry_net_forward(ry_net* net, const float* x, float* y, int batch, int frames,
     return run_plan(net, *P, x, y, on_device);
 }
 
-static int convert_common(ry_net* net, int want_ndim, const float* x, float* y, int batch, int n_frames, int on_device) {
+static int convert_common(ry_net* net, int want_ndim, const float* x, float* y, int batch, int n_frames, int on_device,
+                          int disc_front = 0, int disc_back = 0) {
     if (!net || !x || !y) return fail(RY_EINVAL, "null argument");
     if (net->desc.ndim != want_ndim) return fail(RY_EINVAL, "wrong predictor: this call needs a stage-%d net", want_ndim);
     if (n_frames < 1) return fail(RY_EINVAL, "n_frames must be positive (got %d)", n_frames);
+    if (disc_front < 0 || disc_back < 0) return fail(RY_EINVAL, "discarded frame counts must not be negative (got %d, %d)", disc_front, disc_back);
+    if (disc_front >= (1 << 20) || disc_back >= (1 << 20)) return fail(RY_EINVAL, "discarded frame counts are limited to 2^20");
     const int T = n_frames + (128 - n_frames % 128);
     Plan* P = nullptr;
     RY_TRY(get_plan(net, batch, T, 1, n_frames, &P));
-    return run_plan(net, *P, x, y, on_device);
+    P->disc_front = disc_front; P->disc_back = disc_back;
+    RY_TRY(run_plan(net, *P, x, y, on_device));
+    if (!on_device && want_ndim == 2 && (disc_front > 0 || disc_back > 0)) {       // host arrays: the rows that were not computed come back as zeros
+        const int k0 = disc_front < n_frames ? disc_front : 0;
+        const int k1 = n_frames - disc_back > k0 ? n_frames - disc_back : n_frames;
+        const size_t cols = (size_t)net->desc.width + 1;
+        for (int b = 0; b < batch; ++b) {
+            float* yb = y + (size_t)b * n_frames * cols;
+            if (k0 > 0) memset(yb, 0, (size_t)k0 * cols * sizeof(float));
+            if (k1 < n_frames) memset(yb + (size_t)k1 * cols, 0, (size_t)(n_frames - k1) * cols * sizeof(float));
+        }
+    }
+    return RY_OK;
 }
 
 int ry_ac_convert(ry_net* net, const float* x, float* y, int batch, int n_frames, int on_device) {
@@ -1821,6 +1860,13 @@ int ry_ac_convert(ry_net* net, const float* x, float* y, int batch, int n_frames
 
 int ry_sr_convert(ry_net* net, const float* sp, float* out, int batch, int n_frames, int on_device) {
     return convert_common(net, 2, sp, out, batch, n_frames, on_device);
+}
+
+// The same for a caller that will throw away the first `discard_front` and the last `discard_back` frames of every window (the live
+// caller: ConvertStream.process picks [pad, -pad) of what it converted, realtime_voice_conversion/stream/convert_stream.py:40-42):
+// rows [discard_front, n_frames - discard_back) of `out` are written, bit-identical to ry_sr_convert; the other rows are left untouched.
+int ry_sr_convert_rows(ry_net* net, const float* sp, float* out, int batch, int n_frames, int discard_front, int discard_back, int on_device) {
+    return convert_common(net, 2, sp, out, batch, n_frames, on_device, discard_front, discard_back);
 }
 
 static int profile_plan(ry_net* net, Plan* P, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats);
@@ -1836,6 +1882,7 @@ int ry_net_profile_window(ry_net* net, int n_frames, int reps, ry_kernel_stat* s
     if (!net || !stats || !n_stats || reps < 1 || n_frames < 1) return fail(RY_EINVAL, "bad argument");
     Plan* P = nullptr;
     RY_TRY(get_plan(net, 1, n_frames + (128 - n_frames % 128), 1, n_frames, &P));
+    P->disc_front = P->disc_back = 0;
     return profile_plan(net, P, reps, stats, max_stats, n_stats);
 }
 
@@ -1903,6 +1950,7 @@ struct VcSlot {
     bool used = false;       // ev_done has been recorded at least once
     int ticket = -1;         // ticket of the window occupying the slot (submit .. wait), -1 = free
     int n_eff = 0, n_frames = 0;
+    int k0 = 0, k1 = 0;      // rows of the spectrogram this window really computed (ry_vc_set_discard): the others come back as zeros
 };
 
 struct ry_vc {
@@ -1921,6 +1969,7 @@ struct ry_vc {
     // Lanes (ry_vc_set_lanes): ring slot k runs on the predictor pair l1 / l2 [k % lanes].  Lane 0 is the caller's pair; the others are
     // clones (same filters, own streams / plans / activations), so that the windows in flight really run side by side: the tails of one
     // window's one-round grids and its weight-streaming bottom layers are filled by the other windows' kernels.
+    int disc_front = 0, disc_back = 0;   // ry_vc_set_discard: frames of every window the caller throws away (stage 2 does not compute them)
     int lanes = 1;
     int stagger_at = 0;      // > 0 with several lanes: every stage-2 forward runs as two graphs cut before layer `stagger_at`, and the forward of the
                              // next window (other lane) starts when this one reaches the cut: the two windows in flight are always in different halves
@@ -2031,7 +2080,7 @@ static int vc_enqueue_mid(ry_vc* vc, ry_net* s1, const float* y1, const int* row
 static int vc_run_stage2(ry_vc* vc, ry_net* s2, const float* sp_in, float* sp_out, int n_frames) {
     if (vc->lanes > 1 && vc->stagger_at > 0 && vc->last_s2 && vc->last_s2 != s2 && vc->last_s2->mid_recorded)
         RT_TRY(rt::stream_wait_event(s2->stream, vc->last_s2->mid));
-    RY_TRY(ry_sr_convert(s2, sp_in, sp_out, 1, n_frames, 1));
+    RY_TRY(ry_sr_convert_rows(s2, sp_in, sp_out, 1, n_frames, vc->disc_front, vc->disc_back, 1));
     vc->last_s2 = s2;
     return RY_OK;
 }
@@ -2051,6 +2100,12 @@ static int vc_check(const ry_vc* vc, const int* row_of, int n_eff, int n_frames,
         for (int i = 0; i < n_eff; ++i)
             if (row_of[i] < 0 || row_of[i] >= n_frames) return fail(RY_EINVAL, "row_of[%d] = %d is outside the window", i, row_of[i]);
     return RY_OK;
+}
+
+// the rows of a window's spectrogram that are computed under the current ry_vc_set_discard (the same clipping as enqueue_forward)
+static void vc_keep_rows(const ry_vc* vc, int n_frames, int* k0, int* k1) {
+    *k0 = vc->disc_front < n_frames ? vc->disc_front : 0;
+    *k1 = n_frames - vc->disc_back > *k0 ? n_frames - vc->disc_back : n_frames;
 }
 
 extern "C" {
@@ -2083,6 +2138,19 @@ void ry_vc_destroy(ry_vc* vc) {
     if (vc->b_ev) { rt::event_destroy(vc->b_mid); rt::event_destroy(vc->b_done); }
     vc->free_pinned();
     delete vc;
+}
+
+// The caller will throw away the first `front` and the last `back` frames of every window it gets back (ConvertStream.process does:
+// it converts buffer + 2 x extra_time and picks the buffer, convert_stream.py:40-42).  Stage 2 then computes only the rows that are
+// kept -- the decoder layers run on the row range those rows depend on, the encoder and the bottom of the U-Net stay whole -- and the
+// discarded rows of the returned spectrogram are zero.  The kept rows are bit-identical to the full result; mc is always complete.
+// Applies to every following ry_vc_submit / ry_vc_submit_wave / ry_vc_enqueue_device until changed; (0, 0) = everything.  The split calls of
+// the unchanged reference class and the batch call always compute every frame.
+int ry_vc_set_discard(ry_vc* vc, int front, int back) {
+    if (!vc) return fail(RY_EINVAL, "null argument");
+    if (front < 0 || back < 0 || front >= (1 << 20) || back >= (1 << 20)) return fail(RY_EINVAL, "bad discard counts (%d, %d)", front, back);
+    vc->disc_front = front; vc->disc_back = back;
+    return RY_OK;
 }
 
 // 1 .. 3 lanes: ring slot k runs on its own pair of predictor handles (clones of the caller's: same filters, own streams, plans,
@@ -2144,7 +2212,8 @@ int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, in
     RT_TRY(rt::event_record(sl.ev_mid, st1));
     RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));                                      // stage-2 starts when the spectrogram is ready
     RY_TRY(vc_run_stage2(vc, s2, sl.d_sp, sl.d_out, n_frames));
-    RT_TRY(rt::d2h(sl.h_sp, sl.d_out, (size_t)n_frames * F * sizeof(float), st2));
+    vc_keep_rows(vc, n_frames, &sl.k0, &sl.k1);
+    RT_TRY(rt::d2h(sl.h_sp + (size_t)sl.k0 * F, sl.d_out + (size_t)sl.k0 * F, (size_t)(sl.k1 - sl.k0) * F * sizeof(float), st2));
     RT_TRY(rt::event_record(sl.ev_done, st2));
     sl.used = true; sl.ticket = t; sl.n_eff = n_eff; sl.n_frames = n_frames; sl.gated = false;
     vc->split_eff = -1;
@@ -2161,7 +2230,10 @@ int ry_vc_wait(ry_vc* vc, int ticket, float* mc_out, float* sp_out) {
     RT_TRY(rt::set_device(vc->s1->ctx->device));
     RT_TRY(rt::event_sync(sl.ev_done));            // ev_done follows ev_mid in stream order (stage-2 waited for it)
     memcpy(mc_out, sl.h_mc, (size_t)sl.n_frames * vc->M * sizeof(float));
-    memcpy(sp_out, sl.h_sp, (size_t)sl.n_frames * vc->F * sizeof(float));
+    const size_t F = (size_t)vc->F;
+    if (sl.k0 > 0) memset(sp_out, 0, (size_t)sl.k0 * F * sizeof(float));                       // frames the caller said it discards: not computed
+    memcpy(sp_out + (size_t)sl.k0 * F, sl.h_sp + (size_t)sl.k0 * F, (size_t)(sl.k1 - sl.k0) * F * sizeof(float));
+    if (sl.k1 < sl.n_frames) memset(sp_out + (size_t)sl.k1 * F, 0, (size_t)(sl.n_frames - sl.k1) * F * sizeof(float));
     sl.ticket = -1;
     return RY_OK;
 }
@@ -2272,7 +2344,8 @@ int ry_vc_submit_wave(ry_vc* vc, const float* wave, int n_samples, int hop, int 
     RT_TRY(rt::event_record(sl.ev_mid, st1));
     RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));
     RY_TRY(vc_run_stage2(vc, s2, sl.d_sp, sl.d_out, n_frames));
-    RT_TRY(rt::d2h(sl.h_sp, sl.d_out, (size_t)n_frames * F * sizeof(float), st2));
+    vc_keep_rows(vc, n_frames, &sl.k0, &sl.k1);
+    RT_TRY(rt::d2h(sl.h_sp + (size_t)sl.k0 * F, sl.d_out + (size_t)sl.k0 * F, (size_t)(sl.k1 - sl.k0) * F * sizeof(float), st2));
     RT_TRY(rt::event_record(sl.ev_done, st2));
     sl.used = true; sl.ticket = t; sl.n_eff = n_eff; sl.n_frames = n_frames; sl.gated = true;
     vc->split_eff = -1;

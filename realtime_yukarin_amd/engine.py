@@ -124,6 +124,7 @@ class VcCore(object):
         self.lib.check(self.lib.dll.ry_vc_create(stage1.handle, stage2.handle, _lib._fptr(mtx), self.M, self.F, ctypes.byref(h)))
         self.handle = h
         self._pending = {}
+        self.discard = (0, 0)
         # lanes: the six ring slots spread over two pairs of predictor handles (`ry_vc_set_lanes`), so that two windows really run side by side
         # (RY_VC_LANES=1: one stage-2 forward after the other; 3 measured slower than 2)
         self.lanes = int(os.environ.get('RY_VC_LANES', '2')) if lanes is None else int(lanes)
@@ -143,6 +144,12 @@ class VcCore(object):
         eff = numpy.ones(int(n_frames), bool)
         for _ in range(6 * int(rounds)):
             self.convert(x, eff)
+
+    def set_discard(self, front: int, back: int):
+        """The caller will throw away the first `front` / last `back` frames of every following window (`ry_vc_set_discard`): stage 2
+        does not compute them, their spectrogram rows come back as zeros; (0, 0) = everything."""
+        self.lib.check(self.lib.dll.ry_vc_set_discard(self.handle, int(front), int(back)))
+        self.discard = (int(front), int(back))
 
     def set_lanes(self, lanes: int):
         self.lib.check(self.lib.dll.ry_vc_set_lanes(self.handle, int(lanes)))
@@ -360,9 +367,11 @@ class Net(object):
         self.ctx.lib.check(self.ctx.lib.dll.ry_net_forward(self.handle, _lib._fptr(x), _lib._fptr(y), B, T, 0))
         return y
 
-    def convert(self, x: numpy.ndarray) -> numpy.ndarray:
+    def convert(self, x: numpy.ndarray, discard=(0, 0)) -> numpy.ndarray:
         """The wrapper arithmetic + predictor: stage-1 `AcousticConverter.convert` array part
-        ((B,) N, in_ch) -> ((B,) N, out_ch); stage-2 `SuperResolution.convert` ((B,) N, width+1) -> same."""
+        ((B,) N, in_ch) -> ((B,) N, out_ch); stage-2 `SuperResolution.convert` ((B,) N, width+1) -> same.
+        discard = (front, back), stage 2 only: the caller will throw away that many leading / trailing frames of every window
+        (`ry_sr_convert_rows`): they are not computed and come back as zeros, the others are bit-identical to the full call."""
         x = numpy.ascontiguousarray(x, dtype=numpy.float32)
         squeeze = x.ndim == 2
         if squeeze:
@@ -378,7 +387,10 @@ class Net(object):
                 raise ValueError('stage-2 input needs %d bins, got %d' % (self.width + 1, C))
             y = numpy.empty((B, N, C), dtype=numpy.float32)
             fn = self.ctx.lib.dll.ry_sr_convert
-        self.ctx.lib.check(fn(self.handle, _lib._fptr(x), _lib._fptr(y), B, N, 0))
+        if self.desc.ndim == 2 and tuple(discard) != (0, 0):
+            self.ctx.lib.check(self.ctx.lib.dll.ry_sr_convert_rows(self.handle, _lib._fptr(x), _lib._fptr(y), B, N, int(discard[0]), int(discard[1]), 0))
+        else:
+            self.ctx.lib.check(fn(self.handle, _lib._fptr(x), _lib._fptr(y), B, N, 0))
         return y[0] if squeeze else y
 
     # ---- device-pointer API (inputs already resident in HBM; only enqueues on the context stream) ----

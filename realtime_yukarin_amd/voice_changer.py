@@ -51,13 +51,17 @@ class VoiceChanger(object):
             self._core.close()
         self._core, self._core_pid = None, None
 
-    def convert_from_acoustic_feature(self, f_in):
-        return self.finish(self.begin(f_in))
+    def convert_from_acoustic_feature(self, f_in, discard=(0, 0)):
+        return self.finish(self.begin(f_in, discard))
 
     # ---- the same call in two halves: `begin` queues the window on the GPU and returns at once (up to six windows may be in flight,
     # `ry_vc_submit` / `ry_vc_submit_wave`), `finish` waits for it and assembles the output feature.  `worker.convert_worker` uses the
     # pair to keep a backlog of windows pipelined: H2D of window i + 1 and D2H of window i - 1 run under the kernels of window i.
-    def begin(self, f_in):
+    def begin(self, f_in, discard=(0, 0)):
+        """discard = (front, back): the caller will throw away that many leading / trailing frames of the result (`ConvertStream.process`
+        picks [pad, -pad) of what it converted, convert_stream.py:40-42; `worker.convert_worker` passes its pad).  On the device-resident
+        path stage 2 then does not compute them (`ry_vc_set_discard`): their spectrogram rows come back as zeros, every kept row is
+        bit-identical to the full result, mc / f0 / ap are always complete.  Ignored on the generic path."""
         core = self._fused_core()
         if core is None:                       # generic path: the reference's step order, one call per step (nothing to overlap)
             f_out = self._stage1(f_in)
@@ -66,6 +70,9 @@ class VoiceChanger(object):
         # device-resident path: everything in one window call.  The silence gate runs on the device too (ry_vc_submit_wave) when it
         # can restate the host arithmetic bit for bit (float32 wave, absolute reference, power-of-two frame length); otherwise the
         # mask is taken on the host (it reads the raw wave) and only the effective rows go up (ry_vc_submit).
+        discard = (int(discard[0]), int(discard[1])) if os.environ.get('RY_DISCARD_HINT', '1') != '0' else (0, 0)
+        if core.discard != discard:
+            core.set_discard(*discard)
         ac = self.acoustic_converter
         from . import gate
         from yukarin.wave import default_effective_ref

@@ -11,7 +11,9 @@ at call time) and on this package's `VoiceChanger`.  Two differences, both on th
   loop has no exit and is killed with its parent);
 * `ConvertStream.process` (convert_stream.py:32-44) is taken in its two halves -- fetch + queue the window on the GPU, collect + pick --
   so that a backlog of items keeps `depth` windows in flight on the pinned ring of `ry_vc_submit` (copies of one window under the
-  kernels of another); a live stream without backlog behaves exactly like the synchronous loop."""
+  kernels of another); a live stream without backlog behaves exactly like the synchronous loop;
+* the frames `pick` throws away (the `extra_time` context on either side of the buffer, two thirds of a window in the reference's
+  configuration) are announced to the window call (`VoiceChanger.begin(..., discard=(pad, pad))`): stage 2 does not compute them."""
 import logging
 import time
 
@@ -65,5 +67,5 @@ def convert_worker(acoustic_converter, super_resolution, time_length: float, ext
         # ConvertStream.process (convert_stream.py:32-44) in two halves: fetch + queue now, convert result + pick when it is collected
         in_feature = stream.fetch(start_time=stream_wrapper._current_time, time_length=time_length, extra_time=extra_time)
         stream_wrapper._current_time += time_length
-        pending.append((item, vc.begin(in_feature), start))
+        pending.append((item, vc.begin(in_feature, discard=(pad, pad)), start))     # the rows `pick` drops below are not computed by stage 2
         stream.remove(end_time=retire_time(stream_wrapper._current_time, time_length, extra_time))

@@ -158,6 +158,24 @@ def test_stage2_dead_row_crop_is_bit_identical(syn64, gpu_ctx, monkeypatch, n_fr
         reread(); n2.set_dtype('f32')
 
 
+@pytest.mark.parametrize('n_frames,discard', [(300, (100, 100)), (300, (0, 37)), (300, (150, 0)), (100, (20, 20)), (600, (200, 200)), (257, (1, 1))])
+def test_stage2_discarded_frames_are_not_computed(syn64, n_frames, discard):
+    """`ry_sr_convert_rows` (the frames a caller like ConvertStream.process throws away are announced): kept rows bit-identical to the full
+    call -- launch by launch, under graph replay, and for three windows per call --, discarded rows zero, and the decoder grids shrink."""
+    _, (n2, _) = syn64
+    sp = synth.stage2_input(n_frames)[0]
+    full = n2.convert(sp)
+    k0, k1 = discard[0], n_frames - discard[1]
+    for _ in range(3):                                                    # eager, then the captured graph
+        part = n2.convert(sp, discard=discard)
+        assert numpy.array_equal(part[k0:k1], full[k0:k1])
+        assert not part[:k0].any() and not part[k1:].any()
+    three = n2.convert(numpy.stack([sp, sp[::-1], sp]), discard=discard)
+    assert numpy.array_equal(three[0], three[2]) and float(numpy.abs(three[0][k0:k1] / full[k0:k1] - 1).max()) < 1e-5
+    assert not three[1][:k0].any() and not three[1][k1:].any()
+    assert numpy.array_equal(n2.convert(sp), full)                        # the full call afterwards is the full call
+
+
 def test_stage2_syn64_against_the_c_restatement(syn64):
     """Full-size stage 2 against the plain-C loop nests (oracle/ops_ref.c), float and double sums: the HIP path sits as close
     to the double-sum result as the fp32 CPU restatement does."""

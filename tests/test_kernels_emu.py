@@ -219,6 +219,32 @@ def test_stage2_dead_row_crop_emu(emu_ctx, monkeypatch):
     net.close()
 
 
+@pytest.mark.parametrize('discard', [(4, 3), (0, 5), (6, 0), (10, 10), (200, 0)])
+def test_stage2_discarded_frames_are_not_computed_emu(emu_ctx, discard):
+    """`ry_sr_convert_rows`: a caller that throws away the first / last frames of a window (ConvertStream.process picks the middle of what it
+    converted) says so; the decoder then runs on the row RANGE the kept rows depend on.  Kept rows: bit-identical to the full call;
+    discarded rows: zeros; a discard that leaves nothing is ignored; one and two windows per call."""
+    d = NetDesc(2, 1, 1, 64, 3)
+    P = synthetic_params(d, 435, bias_std=0.05)
+    net = engine.Net(emu_ctx, d, flatten_params(d, P), width=16)
+    n = 23
+    sp = numpy.exp(numpy.random.default_rng(61).normal(-6.0, 1.5, (2, n, 17))).astype('f4')
+    full = net.convert(sp[0])
+    part = net.convert(sp[0], discard=discard)
+    k0 = discard[0] if discard[0] < n else 0
+    k1 = n - discard[1] if n - discard[1] > k0 else n
+    assert numpy.array_equal(part[k0:k1], full[k0:k1])
+    assert not part[:k0].any() and not part[k1:].any()
+    if discard == (4, 3):
+        g_full = {q['layer']: q['grid'] for q in net.profile(1, n, 1, window=True)}
+        both = net.convert(sp, discard=discard)
+        assert numpy.array_equal(both[0], part)
+        assert numpy.array_equal(both[1][k0:k1], net.convert(sp[1])[k0:k1]) and not both[1][:k0].any()
+        assert numpy.array_equal(net.convert(sp[0]), full)              # ... and the full call afterwards is the full call
+        assert g_full == {q['layer']: q['grid'] for q in net.profile(1, n, 1, window=True)}
+    net.close()
+
+
 def test_autotuned_plans_stay_correct_emu(emu_ctx, monkeypatch):
     """RY_AUTOTUNE=1 (opt-in): candidate launch plans of every implicit-GEMM layer are run on the device when a plan is built and
     the fastest replaces the planner's pick.  The emulator has no clock, so RY_AUTOTUNE_PICK forces a non-default candidate per

@@ -325,9 +325,10 @@ def test_convert_worker_mirror_matches_the_reference_loop_and_stays_bounded(mode
     flight = {'now': 0, 'max': 0}
     real_begin, real_finish = MirrorVC.begin, MirrorVC.finish
 
-    def begin(self, f):
+    def begin(self, f, discard=(0, 0)):
         flight['now'] += 1; flight['max'] = max(flight['max'], flight['now'])
-        return real_begin(self, f)
+        flight['discard'] = discard
+        return real_begin(self, f, discard)
 
     def finish(self, h):
         flight['now'] -= 1
@@ -345,6 +346,7 @@ def test_convert_worker_mirror_matches_the_reference_loop_and_stays_bounded(mode
         assert got.index == i and float(numpy.abs(got.item.sp / want[i].sp - 1).max()) < 2e-5 and numpy.array_equal(got.item.f0, want[i].f0)
     t2.join(timeout=30)
     assert not t2.is_alive() and flight['max'] == 2 and flight['now'] == 0
+    assert flight['discard'] == (20, 20)                                      # the worker announces the frames `pick` drops: stage 2 does not compute them
     q_in.close(); q_out.close()
     for m in [k for k in sys.modules if k.startswith('realtime_voice_conversion')]:
         sys.modules.pop(m)
