@@ -2144,8 +2144,8 @@ void ry_vc_destroy(ry_vc* vc) {
 // it converts buffer + 2 x extra_time and picks the buffer, convert_stream.py:40-42).  Stage 2 then computes only the rows that are
 // kept -- the decoder layers run on the row range those rows depend on, the encoder and the bottom of the U-Net stay whole -- and the
 // discarded rows of the returned spectrogram are zero.  The kept rows are bit-identical to the full result; mc is always complete.
-// Applies to every following ry_vc_submit / ry_vc_submit_wave / ry_vc_enqueue_device until changed; (0, 0) = everything.  The split calls of
-// the unchanged reference class and the batch call always compute every frame.
+// Applies to every following ry_vc_submit / ry_vc_submit_wave / ry_vc_enqueue_device / ry_vc_enqueue_device_batch until changed; (0, 0) =
+// everything.  The split calls of the unchanged reference class always compute every frame.
 int ry_vc_set_discard(ry_vc* vc, int front, int back) {
     if (!vc) return fail(RY_EINVAL, "null argument");
     if (front < 0 || back < 0 || front >= (1 << 20) || back >= (1 << 20)) return fail(RY_EINVAL, "bad discard counts (%d, %d)", front, back);
@@ -2459,7 +2459,7 @@ int ry_vc_enqueue_device_batch(ry_vc* vc, int n_windows, const float* x_eff_dev,
     }
     RT_TRY(rt::event_record(vc->b_mid, st1));
     RT_TRY(rt::stream_wait_event(st2, vc->b_mid));
-    RY_TRY(ry_sr_convert(s2, vc->b_sp, sp_out_dev, n_windows, n_frames, 1));
+    RY_TRY(ry_sr_convert_rows(s2, vc->b_sp, sp_out_dev, n_windows, n_frames, vc->disc_front, vc->disc_back, 1));
     RT_TRY(rt::event_record(vc->b_done, st2));
     vc->b_used = true;
     vc->split_eff = -1;

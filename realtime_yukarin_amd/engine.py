@@ -272,6 +272,10 @@ class VcCore(object):
             ctx.sync()
             mc = numpy.empty((W, n, self.M), numpy.float32); sp = numpy.empty((W, n, self.F), numpy.float32)
             ctx.dev_download(d_mc, mc); ctx.dev_download(d_sp, sp)
+            if self.discard != (0, 0):                                   # rows the caller said it throws away were not computed: zeros
+                k0 = self.discard[0] if self.discard[0] < n else 0
+                k1 = n - self.discard[1] if n - self.discard[1] > k0 else n
+                sp[:, :k0] = 0; sp[:, k1:] = 0
         finally:
             for q in (d_x, d_r, d_mc, d_sp):
                 ctx.dev_free(q)

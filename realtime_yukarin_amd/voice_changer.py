@@ -115,7 +115,7 @@ class VoiceChanger(object):
             f0 = ac.f0_converter.convert(f_eff).f0
         return AcousticFeature(f0=f0, ap=f_eff.ap, voiced=f_eff.voiced, mc=numpy.zeros((n, ac.desc.out_ch), numpy.float32))
 
-    def convert_windows(self, f_ins: List) -> List:
+    def convert_windows(self, f_ins: List, discard=(0, 0)) -> List:
         """Independent windows: stage-1 per window (its length is data dependent after the silence split),
         stage-2 for all equal-length windows in one batched GPU call -- everything on the device when both converters are the MI355X shims."""
         core = self._fused_core()
@@ -123,6 +123,9 @@ class VoiceChanger(object):
             # device-resident: one call for all windows (`ry_vc_enqueue_device_batch`): stage 1 per window or as a batch, the hop between
             # the CNNs on the device, stage 2 as one batch
             ac = self.acoustic_converter
+            discard = (int(discard[0]), int(discard[1])) if os.environ.get('RY_DISCARD_HINT', '1') != '0' else (0, 0)
+            if core.discard != discard:
+                core.set_discard(*discard)
             split = [ac.separate_effective(wave=f.wave, feature=f, threshold=self.threshold) for f in f_ins]
             res = core.convert_batch([(numpy.asarray(f_eff.mc, dtype=numpy.float32), effective) for f_eff, effective in split], SP_FLOOR)
             outs = []

@@ -119,6 +119,17 @@ def test_batch_call_equals_the_windows_one_by_one(core):
         rmc, rsp = core.convert(x, e)
         assert float(numpy.abs(mc - rmc).max()) <= 1e-5 * float(numpy.abs(rmc).max())
         assert float(numpy.abs(sp / rsp - 1).max()) < 1e-5
+    core.set_discard(3, 4)                                                    # the frames the caller throws away: not computed, zeros
+    try:
+        gd = core.convert_batch(full)
+        one_d = core.convert(*full[0])
+        for (mc, sp), (x, e) in zip(gd, full):
+            rmc, rsp = core.convert(x, e)
+            assert float(numpy.abs(sp[3:n - 4] / rsp[3:n - 4] - 1).max()) < 1e-5 and not sp[:3].any() and not sp[n - 4:].any()
+        assert not one_d[1][:3].any() and not one_d[1][n - 4:].any()
+    finally:
+        core.set_discard(0, 0)
+    assert numpy.array_equal(core.convert(*full[0])[1][3:n - 4], one_d[1][3:n - 4]) and core.convert(*full[0])[1][:3].any()
     with pytest.raises(ValueError, match='one length'):
         core.convert_batch([(ws[0][0][ws[0][1]], ws[0][1]), window(21, 5)])
     ne = (ctypes.c_int * 2)(3, 99)
