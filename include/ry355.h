@@ -132,7 +132,8 @@ int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, in
  * buffer + 2 x extra_time and picks the buffer (realtime_voice_conversion/stream/convert_stream.py:40-42).  Stage 2 then computes only the
  * rows that are kept (decoder layers on the row range they depend on; encoder and bottom of the U-Net whole); the kept rows are bit-identical
  * to the full result, the discarded rows of the returned spectrogram are zero (device-pointer calls: left untouched), mc is always complete.
- * Applies to every following ry_vc_submit / ry_vc_submit_wave / ry_vc_enqueue_device(_batch) until changed; (0, 0) = everything. */
+ * Applies to every following ry_vc_submit / ry_vc_submit_wave / ry_vc_enqueue_device(_batch) / ry_vc_stage2_from_mc until changed;
+ * (0, 0) = everything. */
 int ry_vc_set_discard(ry_vc* vc, int front, int back);
 /* Lanes: with `lanes` = 2 or 3 the ring slots run on their own predictor handles (ry_net_clone of the pair given to ry_vc_create: one
  * copy of the filters, separate streams / launch plans / activations), so that the windows in flight execute side by side instead of

@@ -62,11 +62,26 @@ class SuperResolution(object):
             self._net_pid, self._bins = os.getpid(), bins
         return self._net
 
+    @staticmethod
+    def discard_frames():
+        """RY_SR_DISCARD="front,back" (opt-in, for run.py / check.py unchanged): the caller throws away that many leading / trailing frames of
+        every converted window -- `ConvertStream.process` picks [pad, -pad) with pad = extra_time / frame_period
+        (realtime_voice_conversion/stream/convert_stream.py:40-42), so a maintainer who runs with convert_extra_time 0.5 s at 5 ms frames sets
+        RY_SR_DISCARD=100,100.  Those rows are then not computed (zeros); every other row is bit-identical.  Default: every frame."""
+        v = os.environ.get('RY_SR_DISCARD', '')
+        if not v:
+            return (0, 0)
+        a, b = (int(q) for q in v.split(','))
+        if a < 0 or b < 0:
+            raise ValueError('RY_SR_DISCARD must be "front,back" with non-negative counts, not %r' % v)
+        return (a, b)
+
     def convert(self, input: numpy.ndarray) -> numpy.ndarray:
         """(N, fft_size/2 + 1) float32 spectrogram -> same shape."""
+        discard = self.discard_frames()
         if isinstance(input, fusion.LazySpectrogram):          # the spectrogram is still on the GPU (fusion.py): continue there
-            out = input.convert_with(self)
+            out = input.convert_with(self, discard)
             if out is not None:
                 return out
         sp = numpy.ascontiguousarray(numpy.asarray(input), dtype=numpy.float32)
-        return self._get_net(sp.shape[1]).convert(sp)
+        return self._get_net(sp.shape[1]).convert(sp, discard=discard)

@@ -2145,7 +2145,7 @@ void ry_vc_destroy(ry_vc* vc) {
 // kept -- the decoder layers run on the row range those rows depend on, the encoder and the bottom of the U-Net stay whole -- and the
 // discarded rows of the returned spectrogram are zero.  The kept rows are bit-identical to the full result; mc is always complete.
 // Applies to every following ry_vc_submit / ry_vc_submit_wave / ry_vc_enqueue_device / ry_vc_enqueue_device_batch until changed; (0, 0) =
-// everything.  The split calls of the unchanged reference class always compute every frame.
+// everything (ry_vc_stage2_from_mc included; ry_vc_mid_sp returns every row of the intermediate spectrogram).
 int ry_vc_set_discard(ry_vc* vc, int front, int back) {
     if (!vc) return fail(RY_EINVAL, "null argument");
     if (front < 0 || back < 0 || front >= (1 << 20) || back >= (1 << 20)) return fail(RY_EINVAL, "bad discard counts (%d, %d)", front, back);
@@ -2533,12 +2533,17 @@ int ry_vc_stage2_from_mc(ry_vc* vc, const int* row_of, int n_eff, int n_frames, 
     ry_net* s2 = vc->s2;
     RT_TRY(rt::event_record(sl.ev_mid, vc->s1->stream));
     RT_TRY(rt::stream_wait_event(s2->stream, sl.ev_mid));
-    RY_TRY(ry_sr_convert(s2, sl.d_sp, sl.d_out, 1, n_frames, 1));
-    RT_TRY(rt::d2h(sl.h_sp, sl.d_out, (size_t)n_frames * vc->F * sizeof(float), s2->stream));
+    int k0 = 0, k1 = n_frames;
+    vc_keep_rows(vc, n_frames, &k0, &k1);                       // ry_vc_set_discard: the rows the caller throws away are not computed
+    const size_t F = (size_t)vc->F;
+    RY_TRY(ry_sr_convert_rows(s2, sl.d_sp, sl.d_out, 1, n_frames, vc->disc_front, vc->disc_back, 1));
+    RT_TRY(rt::d2h(sl.h_sp + (size_t)k0 * F, sl.d_out + (size_t)k0 * F, (size_t)(k1 - k0) * F * sizeof(float), s2->stream));
     RT_TRY(rt::event_record(sl.ev_done, s2->stream));
     sl.used = true;
     RT_TRY(rt::event_sync(sl.ev_done));
-    memcpy(sp_out, sl.h_sp, (size_t)n_frames * vc->F * sizeof(float));
+    if (k0 > 0) memset(sp_out, 0, (size_t)k0 * F * sizeof(float));
+    memcpy(sp_out + (size_t)k0 * F, sl.h_sp + (size_t)k0 * F, (size_t)(k1 - k0) * F * sizeof(float));
+    if (k1 < n_frames) memset(sp_out + (size_t)k1 * F, 0, (size_t)(n_frames - k1) * F * sizeof(float));
     vc->split_eff = keep;                                     // the rows stay valid until the next stage-1 call
     return RY_OK;
 }

@@ -125,11 +125,15 @@ class LazySpectrogram(object):
         return self.shape[0]
 
     # ---- the fused continuation
-    def convert_with(self, sr):
-        """`sr.convert(self)` on the device when this object was built for that shim and its rows are still there; else None."""
+    def convert_with(self, sr, discard=(0, 0)):
+        """`sr.convert(self)` on the device when this object was built for that shim and its rows are still there; else None.
+        discard: frames the caller throws away (RY_SR_DISCARD of the shim): not computed, zeros."""
         t = self._token
         if self._array is None and t.current() and t.link.alive(sr):
-            return t.link.core.stage2_from_mc(t.effective, self._floor)
+            core = t.link.core
+            if core.discard != tuple(discard):
+                core.set_discard(*discard)
+            return core.stage2_from_mc(t.effective, self._floor)
         return None
 
     # ---- everything else sees the array

@@ -225,7 +225,7 @@ def test_unchanged_reference_class_keeps_the_data_on_the_device_between_the_cnns
         real = getattr(engine.VcCore, name)
         monkeypatch.setattr(engine.VcCore, name, (lambda real, key: lambda self, *a, **k: calls.__setitem__(key, calls[key] + 1) or real(self, *a, **k))(real, key))
     real_nc = engine.Net.convert
-    monkeypatch.setattr(engine.Net, 'convert', lambda self, x: calls.__setitem__('net_convert', calls['net_convert'] + 1) or real_nc(self, x))
+    monkeypatch.setattr(engine.Net, 'convert', lambda self, x, discard=(0, 0): calls.__setitem__('net_convert', calls['net_convert'] + 1) or real_nc(self, x, discard))
     real_fast = sptk.mc2sp_fast
     monkeypatch.setattr(sptk, 'mc2sp_fast', lambda *a, **k: calls.__setitem__('host_mc2sp', calls['host_mc2sp'] + 1) or real_fast(*a, **k))
 
@@ -263,6 +263,18 @@ def test_unchanged_reference_class_keeps_the_data_on_the_device_between_the_cnns
     ac.convert(f_eff)
     stale = numpy.asarray(g.sp)
     assert float(numpy.abs(stale / host - 1).max()) < 1e-12 and stale.dtype == numpy.float64
+    # RY_SR_DISCARD (opt-in, for run.py unchanged): the frames ConvertStream.process picks away are not computed -- through the fused
+    # continuation (ry_vc_stage2_from_mc) and through the plain array call of the shim; the kept rows do not move by a bit
+    monkeypatch.setenv('RY_SR_DISCARD', '7,5')
+    part = run()
+    assert numpy.array_equal(part.sp[7:N - 5], out.sp[7:N - 5]) and not part.sp[:7].any() and not part.sp[N - 5:].any()
+    assert numpy.array_equal(part.mc, out.mc)
+    arr_part = sr.convert(numpy.asarray(plain.sp, dtype=numpy.float32))
+    monkeypatch.delenv('RY_SR_DISCARD')
+    arr_full = sr.convert(numpy.asarray(plain.sp, dtype=numpy.float32))
+    assert numpy.array_equal(arr_part[7:N - 5], arr_full[7:N - 5]) and not arr_part[:7].any() and arr_full[:7].any()
+    again = run()
+    assert numpy.array_equal(again.sp, out.sp)                                        # ... and without the variable every frame is back
     for m in [k for k in sys.modules if k.startswith('realtime_voice_conversion')]:
         sys.modules.pop(m)
 
