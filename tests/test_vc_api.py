@@ -194,7 +194,7 @@ def test_a_longer_window_may_arrive_while_others_are_in_flight(emu_ctx):
     n1 = engine.Net(emu_ctx, d1, flatten_params(d1, P1))
     n2 = engine.Net(emu_ctx, d2, flatten_params(d2, P2), width=128)
     c = engine.VcCore(n1, n2, sptk.mc2sp_matrix(8, sptk.mcepalpha(16000), 256))
-    wins = [window(n, 50 + i) for i, n in enumerate((5, 9, 30, 12, 41, 8))]
+    wins = [window(n, 50 + i) for i, n in enumerate((5, 9, 30, 41))]
     ref = [c.convert(x[e], e) for x, e in wins[:1]]                         # the ring starts small
     got = list(c.convert_stream([(x[e], e) for x, e in wins], depth=3))     # 30 and 41 arrive under shorter windows in flight
     c2 = engine.VcCore(n1, n2, sptk.mc2sp_matrix(8, sptk.mcepalpha(16000), 256), lanes=1)

@@ -292,7 +292,7 @@ def test_convert_worker_mirror_matches_the_reference_loop_and_stays_bounded(mode
     from realtime_yukarin_amd import worker
     from realtime_yukarin_amd.transport import FeatureQueue
     ac, sr = build_converters(models)
-    time_length, extra_time, n_items = 0.3, 0.1, 7
+    time_length, extra_time, n_items = 0.3, 0.1, 5
     rng = numpy.random.default_rng(5)
     inputs = []
     for _ in range(n_items):
