@@ -47,7 +47,18 @@ for it in range(iters):
     elif kind < 3:                                      # one window through the fused core, data-dependent effective count
         eff = rng.random(n) < rng.choice([0.0, 0.5, 0.9, 1.0], p=[0.05, 0.25, 0.4, 0.3])
         x = rng.normal(size=(n, d1.in_ch)).astype('f4')
-        mc, sp = core.convert(x[eff], eff)
+        if kind == 2:                                   # ... the caller discards frames at both ends (ry_vc_set_discard): kept rows equal the full call
+            front, back = int(rng.integers(0, n // 2)), int(rng.integers(0, n // 3))
+            full = core.convert(x[eff], eff)
+            core.set_discard(front, back)
+            mc, sp = core.convert(x[eff], eff)
+            core.set_discard(0, 0)
+            k1 = n - back if n - back > front else n
+            k0 = front if k1 > front else 0
+            assert numpy.array_equal(sp[k0:k1], full[1][k0:k1]) and not sp[:k0].any() and not sp[k1:].any() and numpy.array_equal(mc, full[0]), (n, front, back)
+            sp = full[1]
+        else:
+            mc, sp = core.convert(x[eff], eff)
         assert sp.shape == (n, synth.FFT_BINS) and numpy.isfinite(sp).all() and not mc[~eff].any()
     else:                                               # a batch of windows through stage 2 alone (plan cache keys: batch x length)
         b = int(rng.integers(1, 5))
