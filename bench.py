@@ -382,12 +382,19 @@ def main(argv=None):
                 sync_all()
                 d_ms = (time.perf_counter() - td) / args.steps / Wn * 1e3
                 spd = numpy.empty_like(sp_gpu); ctx.dev_download(d_sp[turn['w0']], spd)
+                for _ in core.convert_stream([(xh, eff)] * 12, depth=6):          # the same through the pinned ring, host arrays in and out
+                    pass
+                th = time.perf_counter()
+                for _ in core.convert_stream([(xh, eff)] * 60, depth=6):
+                    pass
+                d_stream_ms = (time.perf_counter() - th) / 60 * 1e3
                 core.set_discard(0, 0)
                 for _ in range(12):
                     step()
                 sync_all()
                 out['discard_hint'] = {'discard_front_back': [extra, extra], 'ms_per_window': round(d_ms, 4),
                                        'effective_x_realtime': round((N - 2 * extra) * 0.005 / (d_ms * 1e-3), 1),
+                                       'host_stream_ms_per_window': round(d_stream_ms, 4),
                                        'kept_rows_bit_identical_to_the_full_step': bool(numpy.array_equal(spd[extra:N - extra], sp_gpu[extra:N - extra])),
                                        'note': 'ry_vc_set_discard: the decoder layers of stage 2 run on the row range the kept frames depend on; '
                                                'encoder and bottom of the U-Net whole; stage 1 whole; not the headline (the headline returns all frames)'}
