@@ -75,8 +75,8 @@ def test_thresholds_reproduce_the_host_gate_at_the_boundary():
 
 def test_device_gate_masks_are_bit_equal_emu(emu_ctx):
     # (the emulator runs a 1024-fiber workgroup per window: a subset here, the full cross product on the GPU)
-    assert run_all(emu_ctx, 'SYN-8', only=('speech60', 'ramp40', 'short', 'tiny', 'one_hop', 'ragged', 'all_silent', 'all_loud', 'loud_clamp'),
-                   chain=False) >= 200
+    assert run_all(emu_ctx, 'SYN-8', only=('speech60', 'short', 'one_hop', 'ragged', 'all_silent', 'loud_clamp'),
+                   chain=False) >= 130
     assert run_all(emu_ctx, 'SYN-8', fft_lengths=(1024,), thrs=(60,), deltas=(0,), only=('speech60', 'tiny', 'all_silent')) == 3
 
 
