@@ -294,6 +294,44 @@ def test_device_resident_voice_changer_core(syn64):
     core.close()
 
 
+def test_window_call_lanes_discard_and_batch(syn64):
+    """The window call on the real GPU: windows in flight over the two lanes (clones of the predictor pair) return the same bits as one
+    lane; `ry_vc_set_discard` leaves every kept row of the spectrogram bit-identical (host ring and device-pointer call alike), zeros in
+    the discarded rows, mc complete; the batch call agrees with the windows one by one."""
+    from realtime_yukarin_amd import sptk
+    (n1, _), (n2, _) = syn64
+    n = 300
+    rng = numpy.random.default_rng(77)
+    wins = []
+    for i in range(5):
+        e = rng.random(n) > (0.0 if i % 2 else 0.3)
+        wins.append((synth.stage1_input(n, seed=500 + i)[0][e], e))
+    mtx = sptk.mc2sp_matrix(8, sptk.mcepalpha(16000), 1024)
+    one = engine.VcCore(n1, n2, mtx, lanes=1)
+    ref = [one.convert(x, e) for x, e in wins]
+    one.close()
+    core = engine.VcCore(n1, n2, mtx)                                           # default: two lanes
+    assert core.lanes == 2
+    for rep in range(2):                                                        # eager, then graph replay, six in flight
+        got = list(core.convert_stream(wins + wins[:1], depth=6))
+        for (mc, sp), (rmc, rsp) in zip(got, ref + ref[:1]):
+            assert numpy.array_equal(mc, rmc) and numpy.array_equal(sp, rsp)
+    core.set_discard(100, 100)
+    for (x, e), (rmc, rsp) in zip(wins[:3], ref):
+        mc, sp = core.convert(x, e)
+        assert numpy.array_equal(sp[100:200], rsp[100:200]) and not sp[:100].any() and not sp[200:].any() and numpy.array_equal(mc, rmc)
+    batch = core.convert_batch(wins[:3])
+    for (mc, sp), (rmc, rsp) in zip(batch, ref):
+        assert float(numpy.abs(sp[100:200] / rsp[100:200] - 1).max()) < 1e-5 and not sp[:100].any() and not sp[200:].any()
+    core.set_discard(0, 0)
+    batch = core.convert_batch(wins[:3])
+    for (mc, sp), (rmc, rsp) in zip(batch, ref):
+        assert float(numpy.abs(sp / rsp - 1).max()) < 1e-5 and float(numpy.abs(mc - rmc).max()) <= 1e-5 * float(numpy.abs(rmc).max())
+    mc, sp = core.convert(*wins[0])
+    assert numpy.array_equal(sp, ref[0][1])
+    core.close()
+
+
 def test_errors_are_reported_not_fatal(gpu_ctx):
     d = NetDesc(1, 9, 9, 8, 8)
     P = synthetic_params(d, 1)
