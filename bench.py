@@ -227,12 +227,13 @@ def main(argv=None):
         ctx.timer_start()
         for _ in range(args.steps):
             step()
+        t_enq = time.perf_counter() - t0
         sync_all()                              # this rank's K steps are done: its clock stops here; the ranks started together (fence above) and
         el = time.perf_counter() - t0           # the job time is the maximum over the ranks (comm.max below) -- the closing barrier itself is not work
         fence()
         el_fenced = time.perf_counter() - t0
         if os.environ.get('BENCH_DEBUG_FENCE'):
-            print('rank %d: %.3f ms for the steps, %.3f ms with the closing barrier' % (rank, el * 1e3, el_fenced * 1e3), file=sys.stderr, flush=True)
+            print('rank %d: %.3f ms for the steps (%.3f ms to enqueue them), %.3f ms with the closing barrier' % (rank, el * 1e3, t_enq * 1e3, el_fenced * 1e3), file=sys.stderr, flush=True)
         # device-side stamp AFTER the fence: ry_timer_stop while the lanes still have work queued (an event record on every predictor
         # stream plus cross-stream waits) was measured to cost the two lanes their overlap for the whole run (1.33 vs 1.16 ms per window)
         dms = ctx.timer_stop()
