@@ -497,16 +497,16 @@ def main(argv=None):
 def cpu_baseline(args, torch, d1, d2, x, mc_gpu, sp_gpu, N, gpu_value):
     """Bounded sample of the same workload on the host cores: the torch/oneDNN restatement (oracle/torch_ref.py) of stage-1 -> mc2sp ->
     stage-2 on the window the GPU just converted -- all threads, then one thread -- and the GPU result checked against it."""
-    from oracle import torch_ref
-    from realtime_yukarin_amd import sptk, synth
+    from oracle import mc2sp as omc, torch_ref
+    from realtime_yukarin_amd import synth
     from realtime_yukarin_amd.weights import synthetic_params
     P1 = synthetic_params(d1, synth.SEED_STAGE1); P2 = synthetic_params(d2, synth.SEED_STAGE2)
     t1n, t2n = torch_ref.TorchUNet(P1), torch_ref.TorchUNet(P2)
-    alpha = sptk.mcepalpha(16000)
+    alpha = omc.mcepalpha(16000)
 
     def chain(xw):
         mc = torch_ref.stage1_convert_core(t1n, xw)
-        sp_mid = (sptk.mc2sp_fast(mc, alpha, 1024) + SP_FLOOR).astype(numpy.float32)
+        sp_mid = (omc.mc2sp(mc, alpha, 1024) + SP_FLOOR).astype(numpy.float32)
         return mc, torch_ref.stage2_convert(t2n, sp_mid)
     mc_ref, sp_ref = chain(x)                                  # warm-up + the check
     err_sp = float(numpy.abs(sp_gpu.astype(numpy.float64) / sp_ref - 1).max())

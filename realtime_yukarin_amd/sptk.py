@@ -1,8 +1,9 @@
-"""Host-side restatement of the two SPTK routines `AcousticConverter.decode_spectrogram` uses ([MEM]:
+"""Host-side forms of the two SPTK routines `AcousticConverter.decode_spectrogram` uses ([MEM]:
 `pysptk.mc2sp(mc, alpha=pysptk.util.mcepalpha(out_rate), fftlen=1024)`, reached from
-/root/reference/realtime_voice_conversion/yukarin_wrapper/voice_changer.py:38).  In the reference this runs on
-the CPU in SPTK C between the two CNNs; it stays on the host here (SURVEY.md section 8(f) row 1 lists the device
-version as the next row after the CNNs)."""
+/root/reference/realtime_voice_conversion/yukarin_wrapper/voice_changer.py:38).  In the reference this runs on the CPU in SPTK C
+between the two CNNs.  Here the window call forms the spectrogram on the device (`ry_mc2sp`: exp(mc @ M), M = `mc2sp_matrix`
+below, built once per converter); the host recursion `mc2sp` / the host matrix form `mc2sp_fast` remain for callers that read the
+intermediate spectrogram on the host.  The checker of all three is `oracle/mc2sp.py`, which shares no code with this file."""
 import numpy
 
 

@@ -269,7 +269,8 @@ def test_stage2_syn64_x3_variant(gpu_ctx):
 
 def test_device_resident_voice_changer_core(syn64):
     """stage-1 -> combine_silent -> mc2sp -> +1e-16 -> stage-2 in one `ry_vc_convert` against the
-    step-by-step composition: torch oracle CNNs + the freqt/rfft restatement of pysptk.mc2sp (float64)."""
+    step-by-step composition: torch oracle CNNs + the independent restatement of pysptk.mc2sp (oracle/mc2sp.py, float64)."""
+    from oracle import mc2sp as omc
     from realtime_yukarin_amd import sptk
     (n1, t1), (n2, t2) = syn64
     n = 300
@@ -282,7 +283,7 @@ def test_device_resident_voice_changer_core(syn64):
     mc_ref = numpy.zeros((n, synth.MC_DIMS), numpy.float32)
     mc_ref[effective] = torch_ref.stage1_convert_core(t1, x[effective])
     assert rel_max(mc, mc_ref) < cases.TOL and not mc[~effective].any()
-    sp_mid = (sptk.mc2sp(mc_ref, alpha, 1024) + 1e-16).astype(numpy.float32)
+    sp_mid = (omc.mc2sp(mc_ref, omc.mcepalpha(16000), 1024) + 1e-16).astype(numpy.float32)
     sp_ref = torch_ref.stage2_convert(t2, sp_mid)
     assert float(numpy.abs(sp / sp_ref - 1).max()) < cases.TOL
     # repeated calls with a varying number of effective frames (graph re-use / eager switching) stay consistent

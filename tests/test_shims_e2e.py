@@ -2,7 +2,7 @@
 `become_yukarin.SuperResolution` shims -> pickle round trip (run.py ships them to a child Process) -> the mirror
 `VoiceChanger.convert_from_acoustic_feature` (/root/reference/realtime_voice_conversion/yukarin_wrapper/voice_changer.py:24-42) in
 its fused and step-by-step forms and `convert_windows`, against the COMPOSED ORACLE: the independent loop-per-frame silence gate
-(oracle/effective_frame.py), the torch/oneDNN CNNs (oracle/torch_ref.py) and the freqt / rfft restatement of pysptk.mc2sp, element
+(oracle/effective_frame.py), the torch/oneDNN CNNs (oracle/torch_ref.py) and the independent restatement of pysptk.mc2sp (oracle/mc2sp.py), element
 by element.  The same body runs on the real GPU with SYN-64 at the BASELINE config #3 window (-m gpu) and on the emulator with SYN-8
 (CPU suite), plus `SuperResolution.convert` alone at the config #1 / #2 windows and for a batch of 8 windows."""
 import json
@@ -12,8 +12,9 @@ import numpy
 import pytest
 
 from oracle import effective_frame as oef
+from oracle import mc2sp as omc
 from oracle import torch_ref
-from realtime_yukarin_amd import compat, engine, sptk, synth
+from realtime_yukarin_amd import compat, engine, synth
 from realtime_yukarin_amd.weights import save_npz
 
 compat.install()
@@ -80,7 +81,7 @@ def expected(t1, t2, f0c, wave, feat, n, threshold):
     conv = numpy.exp((numpy.sqrt(0.09) / numpy.sqrt(0.04)) * (lf - numpy.log(200.0)) + numpy.log(300.0))
     f0[eff] = numpy.where(feat['f0'] > 0, conv, 0.0).astype(numpy.float32)[eff]
     ap = numpy.zeros((n, 513), numpy.float32); ap[eff] = feat['ap'][eff]
-    sp_mid = (sptk.mc2sp(mc, alpha=sptk.mcepalpha(FS), fftlen=1024) + 1e-16).astype(numpy.float32)
+    sp_mid = (omc.mc2sp(mc, omc.mcepalpha(FS), 1024) + 1e-16).astype(numpy.float32)
     return dict(eff=eff, mc=mc, f0=f0, ap=ap, sp=torch_ref.stage2_convert(t2, sp_mid))
 
 

@@ -13,6 +13,7 @@ import numpy
 import pytest
 
 from oracle import effective_frame as oef
+from oracle import mc2sp as omc
 from oracle import unet
 from realtime_yukarin_amd import compat, engine, sptk
 from realtime_yukarin_amd.netspec import NetDesc
@@ -83,7 +84,7 @@ def expected(models, ac, wave, feat):
     mc[eff] = unet.stage1_convert_core(feat['mc'][eff], P1)
     f0 = numpy.zeros((N, 1), numpy.float32)
     f0[eff] = ac.f0_converter.convert(feat['f0'][eff])
-    sp = sptk.mc2sp(mc, alpha=sptk.mcepalpha(FS), fftlen=1024) + 1e-16
+    sp = omc.mc2sp(mc, omc.mcepalpha(FS), 1024) + 1e-16
     return dict(f0=f0, mc=mc, sp=unet.stage2_convert(sp.astype(numpy.float32), P2), eff=eff)
 
 
@@ -97,11 +98,11 @@ def check(out, exp, feat):
 
 
 def test_device_mc2sp_matches_the_sptk_recursion(emu_ctx):
-    """`decode_spectrogram`: exp(mc @ M) on the device vs the freqt / rfft restatement of pysptk.mc2sp."""
+    """`decode_spectrogram`: exp(mc @ M) on the device vs the independent scalar-loop restatement of pysptk.mc2sp (oracle/mc2sp.py)."""
     rng = numpy.random.default_rng(3)
     mc = (rng.normal(size=(37, 9)) * [4, 1, .5, .5, .3, .3, .2, .2, .2]).astype(numpy.float32)
     alpha = sptk.mcepalpha(FS)
-    ref = sptk.mc2sp(mc, alpha, 1024)
+    ref = omc.mc2sp_sptk(mc, omc.mcepalpha(FS), 1024)
     got = emu_ctx.mc2sp(mc, sptk.mc2sp_matrix(8, alpha, 1024))
     assert got.shape == (37, 513) and float(numpy.abs(got / ref - 1).max()) < 5e-5
     assert float(numpy.abs(sptk.mc2sp_fast(mc, alpha, 1024) / ref - 1).max()) < 1e-12
