@@ -9,6 +9,7 @@ must never cross a fork.
 """
 import ctypes
 import os
+import weakref
 from typing import Dict, List, Optional
 
 import numpy
@@ -123,6 +124,7 @@ class VcCore(object):
         h = ctypes.c_void_p()
         self.lib.check(self.lib.dll.ry_vc_create(stage1.handle, stage2.handle, _lib._fptr(mtx), self.M, self.F, ctypes.byref(h)))
         self.handle = h
+        stage1._dependents.add(self); stage2._dependents.add(self)       # `ry_vc` holds raw pointers to both predictors: they must outlive it (Net.close)
         self._pending = {}
         self.discard = (0, 0)
         # lanes: the six ring slots spread over two pairs of predictor handles (`ry_vc_set_lanes`), so that two windows really run side by side
@@ -306,9 +308,18 @@ class VcCore(object):
         return sp
 
     def close(self):
-        if self.handle is not None and self.stage1.ctx.handle is not None and self.stage1.ctx.pid == os.getpid():
+        """`ry_vc_destroy` dereferences both predictors (their context, the lane clones): it only runs while both are alive.  `Net.close`
+        closes its dependent cores first, so the order the caller closes things in does not matter."""
+        if (self.handle is not None and self.stage1.handle is not None and self.stage2.handle is not None
+                and self.stage1.ctx.handle is not None and self.stage1.ctx.pid == os.getpid()):
             self.lib.dll.ry_vc_destroy(self.handle)
         self.handle = None
+        self.stage1._dependents.discard(self); self.stage2._dependents.discard(self)
+
+    def alive_on(self, stage1: 'Net', stage2: 'Net') -> bool:
+        """True while this core is open and still sits on exactly these two (open) predictors."""
+        return (self.handle is not None and self.stage1 is stage1 and self.stage2 is stage2
+                and stage1.handle is not None and stage2.handle is not None)
 
 
 _contexts: Dict = {}
@@ -346,6 +357,7 @@ class Net(object):
             blob = numpy.ascontiguousarray(blob, dtype=numpy.float32)
             lib.check(lib.dll.ry_net_create(ctx.handle, ctypes.byref(self.cdesc), _lib._fptr(blob), blob.size, 0, ctypes.byref(h)))
         self.handle = h
+        self._dependents = weakref.WeakSet()                  # VcCores built on this predictor (they hold raw pointers to it)
 
     def set_dtype(self, dtype: str):
         """'f32' (exact fp32 MFMA, default), 'bf16' (stage-2 only: bf16 operands, fp32 accumulate -- BASELINE config #5) or
@@ -354,6 +366,8 @@ class Net(object):
         self.ctx.lib.check(self.ctx.lib.dll.ry_net_set_dtype(self.handle, {'f32': 0, 'bf16': 1, 'bf16x3': 2}[dtype]))
 
     def close(self):
+        for core in list(self._dependents):                    # a window core on a freed predictor is a use-after-free in `ry_vc_*`: it goes first
+            core.close()
         if self.handle is not None and self.ctx.handle is not None and self.ctx.pid == os.getpid():
             self.ctx.lib.dll.ry_net_destroy(self.handle)
         self.handle = None

@@ -58,7 +58,7 @@ class Link(object):
     def alive(self, sr=None) -> bool:
         s = self.sr_ref()
         return (self.pid == os.getpid() and s is not None and s._net is self.sr_net and self.core.handle is not None
-                and (sr is None or s is sr))
+                and self.core.stage1.handle is not None and self.sr_net.handle is not None and (sr is None or s is sr))
 
     def close(self):
         self.core.close()

@@ -37,9 +37,13 @@ class VoiceChanger(object):
             return None
         from . import engine
         key = os.getpid()
+        mtx = ac.mc2sp_matrix()
+        n1, n2 = ac._get_net(), sr._get_net(mtx.shape[1])
+        if getattr(self, '_core_pid', None) == key and not self._core.alive_on(n1, n2):
+            self._core.close()                                 # a converter was closed / rebuilt (another bin count) under the core: never submit on a freed predictor
+            self._core_pid = None
         if getattr(self, '_core_pid', None) != key:
-            mtx = ac.mc2sp_matrix()
-            self._core = engine.VcCore(ac._get_net(), sr._get_net(mtx.shape[1]), mtx)
+            self._core = engine.VcCore(n1, n2, mtx)
             self._core_pid = key
             if os.environ.get('RY_VC_WARM'):                   # e.g. RY_VC_WARM=300: plans and graphs of every ring slot before the first window
                 self._core.warm(int(os.environ['RY_VC_WARM']))

@@ -118,7 +118,23 @@ def test_stage1_syn64_convert(syn64, n_frames):
     assert rel_max(y, torch_ref.stage1_convert_core(t1, x)) < cases.TOL
 
 
-@pytest.mark.parametrize('n_frames', [100, 300])                      # BASELINE configs #3/#4
+@pytest.mark.parametrize('n_frames', [100, 300, 1000])
+def test_stage1_syn64_stress_input_523_channels(gpu_ctx, n_frames):
+    """SURVEY.md 8(d) stress variant "mel + f0 + ap": C_in = 9 + 1 + 513 = 523 -> C_out = 9 at the full SYN-64 width (the first layer
+    walks 523 input channels per lane set; the base-16 form is in SMALL_NETS)."""
+    (d1, P1), _ = synth.model_params('SYN-64', stage1_in=523)
+    net = engine.Net(gpu_ctx, d1, flatten_params(d1, P1))
+    x = synth.stage1_input(n_frames, stress=True)[0]
+    assert x.shape == (n_frames, 523)
+    y = net.convert(x)
+    r = torch_ref.stage1_convert_core(torch_ref.TorchUNet(P1), x)
+    assert y.shape == (n_frames, synth.MC_DIMS) and rel_max(y, r) < cases.TOL
+    net.close()
+
+
+# BASELINE configs #3/#4 (100, 300), #5 (200, 400), and the windows whose length is already a multiple of 128: `pad = 128 - n % 128` is then
+# a WHOLE extra block of 128 rows (numpy.pad mode 'minimum'), the case in which the default dead-row crop (RY_S2_CROP=2) removes the most
+@pytest.mark.parametrize('n_frames', [100, 300, 128, 256, 384, 200, 400])
 def test_stage2_syn64_convert(syn64, n_frames):
     _, (n2, t2) = syn64
     sp = synth.stage2_input(n_frames)[0]

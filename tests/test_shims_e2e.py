@@ -29,7 +29,7 @@ def rel_elem(y, ref, floor):
     return float((numpy.abs(y - ref) / numpy.maximum(numpy.abs(ref), floor)).max())
 
 
-def write_models(d, name):
+def write_models(d, name, out_rate=FS):
     (d1, P1), (d2, P2) = synth.model_params(name)
     save_npz(d / 's1.npz', P1)
     save_npz(d / 's2.npz', P2)
@@ -38,23 +38,28 @@ def write_models(d, name):
                     'in_features': ['mc'], 'out_features': ['mc']},
         'model': {'in_channels': 9, 'out_channels': 9, 'generator_base_channels': d1.base, 'generator_extensive_layers': 8}}))
     (d / 's2.json').write_text(json.dumps({
-        'dataset': {'param': {'voice_param': {'sample_rate': FS}, 'acoustic_feature_param': {'frame_period': FRAME_PERIOD, 'order': 8}}},
+        'dataset': {'param': {'voice_param': {'sample_rate': out_rate}, 'acoustic_feature_param': {'frame_period': FRAME_PERIOD, 'order': 8}}},
         'model': {'generator_base_channels': d2.base, 'generator_extensive_layers': 8}}))
     numpy.save(str(d / 'in_stat.npy'), {'mean': numpy.log(200.0), 'var': 0.04})
     numpy.save(str(d / 'tg_stat.npy'), {'mean': numpy.log(300.0), 'var': 0.09})
     return P1, P2
 
 
-def build_converters(d):
+def build_converters(d, out_rate=FS):
     from become_yukarin import SuperResolution
     from become_yukarin.config.sr_config import create_from_json as create_sr_config
     from yukarin import AcousticConverter
     from yukarin.config import create_from_json as create_config
     from yukarin.f0_converter import F0Converter
     f0c = F0Converter(input_statistics=d / 'in_stat.npy', target_statistics=d / 'tg_stat.npy')
-    ac = AcousticConverter(create_config(d / 's1.json'), d / 's1.npz', gpu=0, f0_converter=f0c, out_sampling_rate=FS)
+    ac = AcousticConverter(create_config(d / 's1.json'), d / 's1.npz', gpu=0, f0_converter=f0c, out_sampling_rate=out_rate)
     sr = SuperResolution(create_sr_config(d / 's2.json'), d / 's2.npz', gpu=0)
     return pickle.loads(pickle.dumps(ac)), pickle.loads(pickle.dumps(sr))          # what crosses the Process boundary in run.py:69-79
+
+
+def vc_alpha(ac):
+    ac.mc2sp_matrix()
+    return round(ac._alpha_out, 3)
 
 
 def make_window(n, seed):
@@ -70,7 +75,7 @@ def make_window(n, seed):
     return wave, feat
 
 
-def expected(t1, t2, f0c, wave, feat, n, threshold):
+def expected(t1, t2, f0c, wave, feat, n, threshold, out_rate=FS):
     """voice_changer.py:24-42 step by step on the oracle."""
     eff = oef.separate_effective_mask(wave, FS, n, threshold, 1024, FRAME_PERIOD)
     mc = numpy.zeros((n, 9), numpy.float32)
@@ -81,7 +86,7 @@ def expected(t1, t2, f0c, wave, feat, n, threshold):
     conv = numpy.exp((numpy.sqrt(0.09) / numpy.sqrt(0.04)) * (lf - numpy.log(200.0)) + numpy.log(300.0))
     f0[eff] = numpy.where(feat['f0'] > 0, conv, 0.0).astype(numpy.float32)[eff]
     ap = numpy.zeros((n, 513), numpy.float32); ap[eff] = feat['ap'][eff]
-    sp_mid = (omc.mc2sp(mc, omc.mcepalpha(FS), 1024) + 1e-16).astype(numpy.float32)
+    sp_mid = (omc.mc2sp(mc, omc.mcepalpha(out_rate), 1024) + 1e-16).astype(numpy.float32)
     return dict(eff=eff, mc=mc, f0=f0, ap=ap, sp=torch_ref.stage2_convert(t2, sp_mid))
 
 
@@ -97,12 +102,13 @@ def check(out, exp, n, tag, sp_tol=TOL):
     assert 0 < exp['eff'].sum() < n
 
 
-def run_voice_changer_e2e(d, name, n, dtype_env=None, sp_tol=TOL):
+def run_voice_changer_e2e(d, name, n, dtype_env=None, sp_tol=TOL, out_rate=FS):
     from realtime_yukarin_amd.voice_changer import VoiceChanger
     from yukarin import AcousticFeature, Wave
-    P1, P2 = write_models(d, name)
+    P1, P2 = write_models(d, name, out_rate)
     t1, t2 = torch_ref.TorchUNet(P1), torch_ref.TorchUNet(P2)
-    ac, sr = build_converters(d)
+    ac, sr = build_converters(d, out_rate)
+    assert vc_alpha(ac) == {16000: 0.41, 24000: 0.466}[out_rate]
 
     class Wrapped(AcousticFeature):                                              # AcousticFeatureWrapper equivalent
         pass
@@ -111,7 +117,7 @@ def run_voice_changer_e2e(d, name, n, dtype_env=None, sp_tol=TOL):
         f = Wrapped(**{k: v.copy() for k, v in feat.items()}); f.wave = Wave(wave=wave, sampling_rate=FS)
         return f
     wave, feat = make_window(n, 21)
-    exp = expected(t1, t2, ac.f0_converter, wave, feat, n, 60)
+    exp = expected(t1, t2, ac.f0_converter, wave, feat, n, 60, out_rate)
     vc = VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60)
     assert vc._fused_core() is not None
     out = vc.convert_from_acoustic_feature(f_in(wave, feat))
@@ -124,7 +130,7 @@ def run_voice_changer_e2e(d, name, n, dtype_env=None, sp_tol=TOL):
     wins = [make_window(n, 30 + i) for i in range(3)]
     outs = vc.convert_windows([f_in(w, f) for w, f in wins])
     for i, (w, f) in enumerate(wins):
-        check(outs[i], expected(t1, t2, ac.f0_converter, w, f, n, 60), n, '%s convert_windows[%d]' % (name, i), sp_tol)
+        check(outs[i], expected(t1, t2, ac.f0_converter, w, f, n, 60, out_rate), n, '%s convert_windows[%d]' % (name, i), sp_tol)
     return sr, t2
 
 
@@ -139,11 +145,30 @@ def test_shims_end_to_end_emu(tmp_path, on_emulator):
     run_voice_changer_e2e(tmp_path, 'SYN-8', 60)
 
 
+def test_shims_end_to_end_24khz_emu(tmp_path, on_emulator):
+    """out_sampling_rate = 24000 -> alpha 0.466: the rate converter/yukarin_converter.py:46 hard-codes for run.py."""
+    run_voice_changer_e2e(tmp_path, 'SYN-8', 60, out_rate=24000)
+
+
 # ---------------------------------------------------------------- GPU suite: SYN-64 at BASELINE's windows
 @pytest.mark.gpu
 def test_shims_end_to_end_gpu(tmp_path, gpu_ctx):
     """BASELINE config #3 window (0.5 s buffer + 2 x 0.5 s extra = 300 frames), exact fp32."""
     run_voice_changer_e2e(tmp_path, 'SYN-64', 300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_frames', [100, 400, 600])      # config #3 / #4 core, config #5 (1.0 s + 2 x 0.5 s), config #1 (check.py)
+def test_shims_end_to_end_gpu_other_windows(tmp_path, gpu_ctx, n_frames):
+    """The chained core (fused, step by step through the lazy spectrogram, convert_windows) at the other BASELINE windows."""
+    run_voice_changer_e2e(tmp_path, 'SYN-64', n_frames)
+
+
+@pytest.mark.gpu
+def test_shims_end_to_end_gpu_24khz(tmp_path, gpu_ctx):
+    """The whole path with out_sampling_rate = 24000 (alpha = 0.466), the value /root/reference/realtime_voice_conversion/converter/
+    yukarin_converter.py:46 hard-codes for run.py: the fused core's mc2sp matrix is built for that rate."""
+    run_voice_changer_e2e(tmp_path, 'SYN-64', 300, out_rate=24000)
 
 
 @pytest.mark.gpu

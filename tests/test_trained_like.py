@@ -1,0 +1,68 @@
+"""Parity under weights with TRAINED-model statistics (oracle/trained_like.py): BatchNormalization `avg_var` spanning decades (the
+folded per-channel scale gamma / sqrt(avg_var + eps) from ~ 1e-2 to > 1e2), gamma of both signs, non-zero conv bias / beta / avg_mean.
+Every other full-size test uses the pix2pix-init synthetic weights, whose folded scales are all ~ 1.  Loaded by the constructors the
+reference calls at /root/reference/realtime_voice_conversion/converter/yukarin_converter.py:40-55.  Emulator (SYN-8, CPU suite) and
+the real GPU (SYN-64, -m gpu), both wrappers, against the torch / oneDNN oracle AND its float64 evaluation (so that the bar is not
+spent on the oracle's own fp32 rounding)."""
+import numpy
+import pytest
+import torch
+
+from oracle import torch_ref, trained_like
+from realtime_yukarin_amd import engine, synth
+from realtime_yukarin_amd.weights import flatten_params, validate_params
+
+TOL = 1e-4
+
+
+def calib_inputs(n_frames):
+    x = synth.stage1_input(n_frames, seed=811)[0]
+    x1 = numpy.pad(x.T, [(0, 0), (0, 128 - n_frames % 128)], mode='minimum')[numpy.newaxis]
+    sp = synth.stage2_input(n_frames, seed=812)[0]
+    x2 = numpy.log(numpy.pad(sp, [(0, 128 - n_frames % 128), (0, 0)], mode='minimum'))[:, :-1][numpy.newaxis, numpy.newaxis]
+    return x1, x2
+
+
+def run(ctx, name, n_frames, windows):
+    d1, d2 = synth.model_descs(name)
+    x1c, x2c = calib_inputs(n_frames)
+    P1 = trained_like.calibrated_params(d1, 821, x1c)
+    P2 = trained_like.calibrated_params(d2, 822, x2c)
+    validate_params(d1, P1); validate_params(d2, P2)
+    for P in (P1, P2):
+        st = trained_like.describe(P)
+        print(name, st)
+        assert st['avg_var'][1] / st['avg_var'][0] > 1e3 and st['folded_scale'][1] / st['folded_scale'][0] > 1e2 and st['abs_gamma'][1] > 1.5
+    n1 = engine.Net(ctx, d1, flatten_params(d1, P1))
+    n2 = engine.Net(ctx, d2, flatten_params(d2, P2), width=synth.FFT_BINS - 1)
+    t1, t2 = torch_ref.TorchUNet(P1), torch_ref.TorchUNet(P2)
+    t1d, t2d = torch_ref.TorchUNet(P1, dtype=torch.float64), torch_ref.TorchUNet(P2, dtype=torch.float64)
+    try:
+        for n in windows:                                             # other windows than the calibration one
+            x = synth.stage1_input(n, seed=830 + n)[0]
+            y = n1.convert(x)
+            r, rd = torch_ref.stage1_convert_core(t1, x), torch_ref.stage1_convert_core(t1d, x.astype(numpy.float64))
+            e32, e64 = (float(numpy.abs(y - q).max() / numpy.abs(q).max()) for q in (r, rd))
+            o32 = float(numpy.abs(r - rd).max() / numpy.abs(rd).max())
+            print('%s stage-1 n=%d: vs fp32 oracle %.2e, vs float64 oracle %.2e (fp32 oracle vs float64: %.2e)' % (name, n, e32, e64, o32))
+            assert e32 < TOL and e64 < TOL and float(numpy.abs(rd).max()) > 1e-2
+            sp = synth.stage2_input(n, seed=840 + n)[0]
+            y = n2.convert(sp).astype(numpy.float64)
+            r, rd = torch_ref.stage2_convert(t2, sp), torch_ref.stage2_convert(t2d, sp.astype(numpy.float64))
+            e32, e64 = float(numpy.abs(y / r - 1).max()), float(numpy.abs(y / rd - 1).max())
+            print('%s stage-2 n=%d: element-wise vs fp32 oracle %.2e, vs float64 oracle %.2e (fp32 oracle vs float64: %.2e); log-spectrum range %.2f .. %.2f'
+                  % (name, n, e32, e64, float(numpy.abs(r / rd - 1).max()), float(numpy.log(rd).min()), float(numpy.log(rd).max())))
+            assert e32 < TOL and e64 < TOL and numpy.isfinite(y).all()
+            assert float(numpy.log(rd).max() - numpy.log(rd).min()) > 0.05             # the predictor did something
+    finally:
+        n1.close(); n2.close()
+
+
+def test_trained_like_statistics_emu(emu_ctx):
+    run(emu_ctx, 'SYN-8', 60, [60])
+
+
+@pytest.mark.gpu
+def test_trained_like_statistics_gpu(gpu_ctx):
+    """SYN-64, calibrated on a 300-frame window, converted at BASELINE's 300 / 100 / 128-frame windows."""
+    run(gpu_ctx, 'SYN-64', 300, [300, 100, 128])

@@ -212,3 +212,34 @@ def test_a_longer_window_may_arrive_while_others_are_in_flight(emu_ctx):
     mc, sp = c.convert(wins[1][0][wins[1][1]], wins[1][1])
     assert numpy.array_equal(sp, got[1][1])
     c.close(); c2.close(); n1.close(); n2.close()
+
+
+def test_closing_a_predictor_takes_its_window_cores_with_it(emu_ctx, monkeypatch):
+    """`ry_vc` holds raw pointers to both predictors (their context, streams, lane clones): freeing a predictor under a live core and
+    then submitting on it -- or destroying the core afterwards -- would be a use-after-free inside libry355.so.  `Net.close` therefore
+    closes the cores built on it first, a closed core refuses politely, and any close order is safe."""
+    calls = []
+    real_destroy = emu_ctx.lib.dll.ry_vc_destroy
+    (d1, P1), (d2, P2) = synth.model_params('SYN-8')
+    mtx = sptk.mc2sp_matrix(8, sptk.mcepalpha(16000), 256)
+    for order in ('nets first', 'core first', 'one net only'):
+        n1 = engine.Net(emu_ctx, d1, flatten_params(d1, P1))
+        n2 = engine.Net(emu_ctx, d2, flatten_params(d2, P2), width=128)
+        c = engine.VcCore(n1, n2, mtx)
+        x, e = window(12, 7)
+        c.convert(x[e], e)
+        h = c.handle
+        assert c.alive_on(n1, n2)
+        if order == 'nets first':
+            n1.close()                                  # closes c (while n2 is still alive, so ry_vc_destroy may still dereference both)
+            assert c.handle is None and not c.alive_on(n1, n2) and n2.handle is not None
+            n2.close(); c.close()                       # closing again is a no-op
+        elif order == 'core first':
+            c.close(); n1.close(); n2.close()
+        else:
+            n2.close()
+            assert c.handle is None
+            n1.close()
+        assert not n1._dependents and not n2._dependents
+        with pytest.raises(Exception):
+            c.convert(x[e], e)                          # a closed core raises in Python; it never reaches the library with a dangling handle

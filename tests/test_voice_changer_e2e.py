@@ -363,3 +363,29 @@ def test_convert_worker_mirror_matches_the_reference_loop_and_stays_bounded(mode
     q_in.close(); q_out.close()
     for m in [k for k in sys.modules if k.startswith('realtime_voice_conversion')]:
         sys.modules.pop(m)
+
+
+def test_converters_may_be_closed_or_rebuilt_under_the_voice_changer(models, on_emulator):
+    """A converter shim that is closed (or whose predictor is rebuilt for another bin count) while a VoiceChanger still holds the window core
+    built on it: the next window rebuilds the core on the new predictors instead of submitting on freed ones, and `ac.close(); sr.close();
+    vc.close()` in that order is safe (the round-2 advisor's use-after-free)."""
+    from realtime_yukarin_amd.voice_changer import VoiceChanger
+    from yukarin import AcousticFeature
+    ac, sr = build_converters(models)
+    wave, feat = make_input(numpy.random.default_rng(23))
+
+    def f_in():
+        f = AcousticFeature(**{k: v.copy() for k, v in feat.items()}); f.wave = wave
+        return f
+    vc = VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60)
+    first = vc.convert_from_acoustic_feature(f_in())
+    core = vc._fused_core()
+    sr.convert(numpy.full((10, 129), 1e-3, numpy.float32))             # another bin count: the shim frees its predictor and builds a new one
+    assert core.handle is None, 'the core on the freed predictor went with it'
+    again = vc.convert_from_acoustic_feature(f_in())                    # rebuilt on the 513-bin predictor
+    assert vc._fused_core() is not core and numpy.array_equal(again.sp, first.sp) and numpy.array_equal(again.mc, first.mc)
+    ac.close()
+    third = vc.convert_from_acoustic_feature(f_in())
+    assert numpy.array_equal(third.sp, first.sp)
+    ac.close(); sr.close(); vc.close(); vc.close()
+    check(first, expected(models, ac, wave, feat), feat)
