@@ -140,6 +140,10 @@ struct Arena {
         for (void* q : bufs) rt::dfree(q);
         bufs.clear();
     }
+    void free_one(void* q) {               // a buffer that is being replaced by a larger one
+        for (size_t i = 0; i < bufs.size(); ++i)
+            if (bufs[i] == q) { rt::dfree(q); bufs.erase(bufs.begin() + (long)i); return; }
+    }
     ~Arena() { release(); }
 };
 
@@ -1942,6 +1946,10 @@ struct VcSlot {
     std::vector<void*> pinned;
     int cap_eff = 0, cap_frames = 0;
     void free_pinned() { for (void* q : pinned) rt::hfree(q); pinned.clear(); }
+    void free_pinned_one(void* q) {
+        for (size_t i = 0; i < pinned.size(); ++i)
+            if (pinned[i] == q) { rt::hfree(q); pinned.erase(pinned.begin() + (long)i); return; }
+    }
     bool gated = false;      // the window in the slot came through ry_vc_submit_wave
     float *d_x = nullptr, *d_y1 = nullptr, *d_mc = nullptr, *d_sp = nullptr, *d_out = nullptr;
     int* d_row = nullptr;
@@ -2030,13 +2038,12 @@ static int vc_reserve_slot(ry_vc* vc, VcSlot& sl, int n_eff, int n_frames) {
     // gate buffers: the feature block of ALL frames, one power per frame, the mask and the count (the wave buffer is sized on demand)
     float* q = nullptr;
     RY_TRY(sl.bufs.alloc(&sl.d_feat, (size_t)cf * cin));
-    RY_TRY(sl.bufs.alloc(&sl.d_pow, (size_t)cf + 8));
     RY_TRY(sl.bufs.alloc(&q, (size_t)cf / 4 + 4)); sl.d_mask = (unsigned char*)q;
     RY_TRY(sl.bufs.alloc(&q, 4)); sl.d_count = (int*)q;
     RY_TRY(vc_halloc(sl, (void**)&sl.h_feat, (size_t)cf * cin * sizeof(float)));
     RY_TRY(vc_halloc(sl, (void**)&sl.h_mask, (size_t)cf + 16));
     RY_TRY(vc_halloc(sl, (void**)&sl.h_count, 16));
-    sl.h_wave = nullptr; sl.d_wave = nullptr; sl.cap_wave = 0;
+    sl.h_wave = nullptr; sl.d_wave = nullptr; sl.d_pow = nullptr; sl.cap_wave = 0;
     sl.used = false;
     sl.cap_eff = ce; sl.cap_frames = cf;
     if (&sl == &vc->slot[0]) vc->split_eff = -1;
@@ -2143,7 +2150,8 @@ void ry_vc_destroy(ry_vc* vc) {
 // The caller will throw away the first `front` and the last `back` frames of every window it gets back (ConvertStream.process does:
 // it converts buffer + 2 x extra_time and picks the buffer, convert_stream.py:40-42).  Stage 2 then computes only the rows that are
 // kept -- the decoder layers run on the row range those rows depend on, the encoder and the bottom of the U-Net stay whole -- and the
-// discarded rows of the returned spectrogram are zero.  The kept rows are bit-identical to the full result; mc is always complete.
+// discarded rows of the returned spectrogram are zero for the host-array calls (ry_vc_wait / ry_vc_wait_wave / ry_vc_stage2_from_mc); the
+// device-pointer calls (ry_vc_enqueue_device / _batch) leave the discarded rows of the caller's block UNTOUCHED (no memset is queued).  The kept rows are bit-identical to the full result; mc is always complete.
 // Applies to every following ry_vc_submit / ry_vc_submit_wave / ry_vc_enqueue_device / ry_vc_enqueue_device_batch until changed; (0, 0) =
 // everything (ry_vc_stage2_from_mc included; ry_vc_mid_sp returns every row of the intermediate spectrogram).
 int ry_vc_set_discard(ry_vc* vc, int front, int back) {
@@ -2258,10 +2266,16 @@ static int vc_gate_into_slot(ry_vc* vc, ry_net* s1, VcSlot& sl, const float* wav
     const int cin = s1->desc.in_ch;
     ry_stream_t st1 = s1->stream;
     if (sl.used) RT_TRY(rt::stream_wait_event(st1, sl.ev_done));
-    if (n_samples > sl.cap_wave) {                              // wave staging of this slot, grown on demand (owned by the ring's arenas)
+    const int n_wave_frames = n_samples / hop + 1;              // librosa: 1 + (len + 2 * (fft / 2) - fft) / hop
+    if (n_samples > sl.cap_wave) {                              // wave staging of this slot, grown on demand: the previous buffers go
         RT_TRY(rt::stream_sync(st1));
+        if (sl.d_wave) sl.bufs.free_one(sl.d_wave);
+        if (sl.d_pow) sl.bufs.free_one(sl.d_pow);
+        if (sl.h_wave) sl.free_pinned_one(sl.h_wave);
+        sl.d_wave = sl.d_pow = sl.h_wave = nullptr; sl.cap_wave = 0;
         const int cap = n_samples + n_samples / 4 + 1024;
         RY_TRY(sl.bufs.alloc(&sl.d_wave, (size_t)cap));
+        RY_TRY(sl.bufs.alloc(&sl.d_pow, (size_t)cap + 8));       // one power per WAVE frame (<= n_samples + 1 of them, whatever the hop)
         RY_TRY(vc_halloc(sl, (void**)&sl.h_wave, (size_t)cap * sizeof(float)));
         sl.cap_wave = cap;
     }
@@ -2270,8 +2284,9 @@ static int vc_gate_into_slot(ry_vc* vc, ry_net* s1, VcSlot& sl, const float* wav
     RT_TRY(rt::h2d(sl.d_wave, sl.h_wave, (size_t)n_samples * sizeof(float), st1));
     RT_TRY(rt::h2d(sl.d_feat, sl.h_feat, (size_t)n_frames * cin * sizeof(float), st1));
     Launcher Lc{s1, s1->ctx, st1, nullptr, nullptr};
-    int n_wave_frames = n_samples / hop + 1;                    // librosa: 1 + (len + 2 * (fft / 2) - fft) / hop
-    if (n_wave_frames > n_frames) n_wave_frames = n_frames;     // frames past the feature block are never looked at
+    // The power of EVERY wave frame is taken: the host takes log_spec.max() (the top_db clamp) over all len(wave) // hop + 1 frames and
+    // truncates to the feature block afterwards, so a frame past the block can still decide the clamp (a live window has n * hop samples:
+    // always one frame more than features).  The mask and the compaction look at the first n_frames only (ry_gate_compact).
     RyFramePowerParams fp;
     fp.wave = sl.d_wave; fp.n = n_samples; fp.hop = hop; fp.fft = fft_length; fp.n_wave_frames = n_wave_frames; fp.power = sl.d_pow;
     dim3 fg((unsigned)((n_wave_frames + 3) / 4));

@@ -80,6 +80,48 @@ def test_device_gate_masks_are_bit_equal_emu(emu_ctx):
     assert run_all(emu_ctx, 'SYN-8', fft_lengths=(1024,), thrs=(60,), deltas=(0,), only=('speech60', 'tiny', 'all_silent')) == 3
 
 
+def check_the_clamp_is_decided_by_every_wave_frame(ctx, name):
+    """The `top_db` clamp of librosa.power_to_db takes the maximum over ALL len(wave) // hop + 1 wave frames; the feature block of a live
+    window is one frame shorter (n * hop samples -> n + 1 wave frames), so the loudest frame can be the one past the block.  A silent wave
+    with a loud tail, threshold 100 dB: the tail lifts max - 80 dB above -100 dB, every frame passes on the host -- and must on the device
+    (round-2 advisor: the device clipped the frame count before taking the maximum and returned no frame)."""
+    core, n1, n2 = make_core(ctx, name)
+    rng = numpy.random.default_rng(6)
+    cases = 0
+    for fft in (128, 1024):
+        for tail in (16, 3):
+            w = numpy.zeros(50 * HOP, numpy.float32); w[-tail:] = 0.5
+            for delta in (-1, 0, -7):
+                n = len(w) // HOP + 1 + delta
+                feat = (rng.normal(size=(n, 9)) * synth.MC_SCALE).astype(numpy.float32)
+                for thr in (100, 60):
+                    want = oef.separate_effective_mask(w, FS, n, thr, fft, FP, 'abs')
+                    p_eff, p_all = gate.thresholds(thr)
+                    eff, x_eff, rows = core.gate(w, HOP, fft, p_eff, p_all, feat)
+                    assert numpy.array_equal(eff, want), (fft, tail, delta, thr, int(eff.sum()), int(want.sum()))
+                    assert numpy.array_equal(x_eff, feat[want])
+                    if thr == 100 and delta == -1 and fft == 128 and tail == 16:
+                        assert want.all(), 'the case is the one the advisor reproduced: 50 of 50 frames on the host'
+                    cases += 1
+    # a window that grows: the wave staging of the slot is replaced, not leaked; results unaffected
+    w2 = (0.1 * rng.normal(size=400 * HOP)).astype(numpy.float32)
+    feat2 = (rng.normal(size=(400, 9)) * synth.MC_SCALE).astype(numpy.float32)
+    p_eff, p_all = gate.thresholds(60)
+    eff, _, _ = core.gate(w2, HOP, 1024, p_eff, p_all, feat2)
+    assert numpy.array_equal(eff, oef.separate_effective_mask(w2, FS, 400, 60, 1024, FP, 'abs'))
+    core.close(); n1.close(); n2.close()
+    return cases
+
+
+def test_the_clamp_is_decided_by_every_wave_frame_emu(emu_ctx):
+    assert check_the_clamp_is_decided_by_every_wave_frame(emu_ctx, 'SYN-8') == 24
+
+
+@pytest.mark.gpu
+def test_the_clamp_is_decided_by_every_wave_frame_gpu(gpu_ctx):
+    assert check_the_clamp_is_decided_by_every_wave_frame(gpu_ctx, 'SYN-8') == 24
+
+
 def test_mirror_voice_changer_takes_the_device_gate(emu_ctx, monkeypatch, tmp_path):
     """The mirror VoiceChanger uses `submit_wave` for a float32 wave and falls back to the host gate otherwise; same outputs."""
     import test_shims_e2e as e2e
