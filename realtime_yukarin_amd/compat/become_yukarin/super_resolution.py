@@ -47,8 +47,29 @@ class SuperResolution(object):
             self._net.close()
         self._net = None
 
+    # ---- multi-GPU: see yukarin.AcousticConverter.without_weights / adopt_net
+    def without_weights(self) -> 'SuperResolution':
+        import copy
+        c = copy.copy(self)
+        c.__dict__.update(self.__getstate__())
+        c._params = None
+        fusion.register_sr(c)
+        return c
+
+    def adopt_net(self, net: engine.Net) -> None:
+        """Use a device-resident predictor built in THIS process from a broadcast weight blob (its width fixes the bin count)."""
+        if (net.desc.ndim, net.desc.base, net.desc.extensive_layers) != (2, self.desc.base, self.desc.extensive_layers):
+            raise ValueError('adopt_net: predictor %r does not match the config %r' % (net.desc, self.desc))
+        self.close()
+        dtype = os.environ.get('RY_SR_DTYPE', 'f32')
+        if dtype != 'f32':
+            net.set_dtype(dtype)
+        self._net, self._net_pid, self._bins = net, os.getpid(), net.width + 1
+
     def _get_net(self, bins: int) -> engine.Net:
         if self._net is None or self._net_pid != os.getpid() or self._bins != bins:
+            if self._params is None:
+                raise RuntimeError('this SuperResolution copy carries no weights (without_weights) and no adopted predictor for %d bins' % bins)
             self.close()                                       # a predictor for another bin count (or another process) is being replaced: free it
             ctx = engine.get_context(self.device())
             self._net = engine.Net(ctx, self.desc, flatten_params(self.desc, self._params), width=bins - 1)

@@ -54,8 +54,28 @@ class AcousticConverter(object):
     def device(self) -> int:
         return _device_of(self.gpu)
 
+    # ---- multi-GPU: a process that receives the predictor by one RCCL broadcast needs no host copy of the weights (dispatch.py)
+    def without_weights(self) -> 'AcousticConverter':
+        """A copy that carries the config but not the host weights: what the dispatcher ships to the worker processes of GPUs 1 .. G-1,
+        which get the device-resident predictor from the broadcast (`adopt_net`) instead of unpickling another 54 MB each."""
+        import copy
+        c = copy.copy(self)
+        c.__dict__.update(self.__getstate__())
+        c._params = None
+        return c
+
+    def adopt_net(self, net: engine.Net) -> None:
+        """Use a device-resident predictor that was built elsewhere in THIS process (from a broadcast weight blob)."""
+        if (net.desc.ndim, net.desc.in_ch, net.desc.out_ch, net.desc.base, net.desc.extensive_layers) != (
+                self.desc.ndim, self.desc.in_ch, self.desc.out_ch, self.desc.base, self.desc.extensive_layers):
+            raise ValueError('adopt_net: predictor %r does not match the config %r' % (net.desc, self.desc))
+        self.close()
+        self._net, self._net_pid = net, os.getpid()
+
     def _get_net(self) -> engine.Net:
         if self._net is None or self._net_pid != os.getpid():
+            if self._params is None:
+                raise RuntimeError('this AcousticConverter copy carries no weights (without_weights): call adopt_net with the broadcast predictor first')
             ctx = engine.get_context(_device_of(self.gpu))
             self._net = engine.Net(ctx, self.desc, flatten_params(self.desc, self._params))
             self._net_pid = os.getpid()

@@ -1,0 +1,278 @@
+"""Multi-GPU dispatcher of the CHAINED convert path: one stream, G GPUs, window i -> GPU i mod G, results released in `Item.index` order.
+
+north_star: "independent buffer_time chunks are sharded across the 8 GPUs of one node with RCCL broadcast of weights over xGMI and no
+cross-chunk collectives" (BASELINE.json).  What makes that legal is the reference's own structure: `ConvertStream.process` copies the
+overlap context INTO the window it fetches (/root/reference/realtime_voice_conversion/stream/base_stream.py:32-79: `fetch(start_time,
+time_length, extra_time)`) and drops it afterwards (stream/convert_stream.py:40-42), so a window is a pure function of what `fetch`
+returned; the consumer re-establishes the order by `Item.index` (/root/reference/run.py:171-183).  So:
+
+    queue_input --> [dispatcher: ONE ConvertStream: add / fetch / remove] --window k--> worker k mod G (one process per GPU:
+                                                                                        its own HIP context, VoiceChanger, window core)
+    queue_output <-- [dispatcher: release in index order] <----- (index, picked feature) ---- any worker, any order
+
+* the windows travel through `transport.FeatureQueue` rings (shared memory, one copy per hop; one ring into every worker, ONE ring back
+  that all workers write) -- no pickled `gather_object`, no second copy through a pipe;
+* the weights travel ONCE: worker 0 unpickles the converter objects with their host weights (exactly what the reference ships to its
+  single convert worker, /root/reference/run.py:69-79), workers 1 .. G-1 get copies WITHOUT weights (`without_weights`) and receive
+  both predictors by one RCCL broadcast each over xGMI (`dist.NativeComm`: `ry_comm_bcast_weights`, include/ry355.h), then `adopt_net`;
+  `comm='host'` ships full copies instead (no RCCL: the CPU tests on the emulator, or a single GPU);
+* no collective after start-up; every worker keeps `depth` windows in flight on its pinned ring (`VoiceChanger.begin` / `finish`) and
+  announces the frames the stream's `pick` throws away (`discard`), so stage 2 does not compute them;
+* results are released strictly in submission order (= `Item.index` order of run.py), whatever order the GPUs finish in.
+
+`convert_worker_multi_gpu` is the drop-in for the reference's `convert_worker` process target (same arguments + `devices`).
+In the LIVE path windows arrive one per buffer_time, so G GPUs raise throughput (offline conversion, a backlog, many sessions), not the
+latency of one window."""
+import collections
+import logging
+import os
+import shutil
+import tempfile
+import time
+import traceback
+from multiprocessing import get_context
+from typing import Callable, List, Optional, Sequence, Tuple
+
+from . import transport
+
+_STOP = None
+PICK_KEYS = ('f0', 'ap', 'sp', 'voiced')             # FeatureSegmentMethod._keys (segment/feature_segment.py:21): what ConvertStream.process returns
+
+
+def _worker_main(rank: int, world: int, device: int, ac, sr, threshold, comm: str, rendezvous: str, depth: int,
+                 q_in, q_out, hook: Optional[Callable]) -> None:
+    """One GPU: build (or receive) the predictors, then convert windows until the stop item.  Every message on q_out is
+    (kind, rank, index, payload): ('ready', r, -1, None), ('ok', r, index, feature), ('error', r, index, text)."""
+    try:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC for RCCL (before the HIP runtime comes up)
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')               # one hardware queue per stream of the window lanes
+        from . import compat, engine
+        compat.install()
+        per_window = hook(rank) if hook is not None else None         # tests: route the context to the emulator, inject jitter
+        ac.gpu = sr.gpu = device
+        if comm == 'native':
+            from . import dist as rdist
+            ctx = engine.get_context(device)
+            c = rdist.NativeComm(ctx, rank, world, path=rendezvous)
+            n1 = c.broadcast_net(ctx, ac.desc, ac._params if rank == 0 else None)
+            bins = ac.mc2sp_matrix().shape[1]
+            n2 = c.broadcast_net(ctx, sr.desc, sr._params if rank == 0 else None, width=bins - 1)
+            ac.adopt_net(n1); sr.adopt_net(n2)
+            c.close()                                                   # no collective after start-up
+        from .voice_changer import VoiceChanger
+        vc = VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=threshold)
+        vc._fused_core()                                                # contexts, predictors and the window core exist before 'ready'
+        q_out.put(('ready', rank, -1, None))
+        pending = collections.deque()
+
+        def finish_one():
+            index, handle, pick = pending.popleft()
+            out = vc.finish(handle)
+            if pick is not None:
+                out = out.pick(pick[0], pick[1], keys=list(pick[2]))
+            q_out.put(('ok', rank, index, out))
+        while True:
+            if pending and (len(pending) >= depth or q_in.empty()):
+                finish_one()
+                continue
+            msg = q_in.get()
+            if msg is _STOP:
+                while pending:
+                    finish_one()
+                break
+            index, f_in, discard, pick = msg
+            if per_window is not None:
+                per_window(index)
+            pending.append((index, vc.begin(f_in, discard=discard), pick))
+        vc.close(); ac.close(); sr.close()
+    except BaseException:                                               # the parent must hear about it: a silent worker death hangs the stream
+        try:
+            q_out.put(('error', rank, -1, traceback.format_exc()))
+        except Exception:
+            pass
+        raise
+
+
+class ChunkDispatcher(object):
+    """G worker processes, one per entry of `devices`; `submit` hands window k to worker k mod G, `collect` returns finished windows in
+    submission order.  `comm`: 'native' = weights by RCCL broadcast from worker 0 (`ry_comm_*`), 'host' = every worker unpickles its own
+    copy, 'auto' = 'native' when there is more than one device, else 'host'."""
+
+    def __init__(self, acoustic_converter, super_resolution, devices: Sequence[int], threshold: float = 60, comm: str = 'auto',
+                 depth: int = 2, mp_context: str = 'spawn', worker_hook: Optional[Callable] = None, slots: int = 8,
+                 slot_bytes: int = 16 << 20, start_timeout: float = 600.0) -> None:
+        if not devices:
+            raise ValueError('ChunkDispatcher needs at least one device')
+        if comm not in ('auto', 'native', 'host'):
+            raise ValueError("comm must be 'auto', 'native' or 'host'")
+        self.devices = [int(d) for d in devices]
+        self.world = len(self.devices)
+        self.comm = ('native' if self.world > 1 else 'host') if comm == 'auto' else comm
+        self._mp = get_context(mp_context)
+        self._q_in = [transport.FeatureQueue(slots, slot_bytes, ctx=self._mp) for _ in self.devices]
+        self._q_out = transport.FeatureQueue(max(slots, 2 * self.world + 2), slot_bytes, ctx=self._mp)
+        self._dir = tempfile.mkdtemp(prefix='ry355-dispatch-')        # 0700: the RCCL id of this dispatcher's workers lives here
+        self._procs = []
+        self._submitted = 0            # windows handed out so far: window k goes to worker k mod G
+        self._released = 0             # windows returned to the caller so far
+        self._labels = {}              # sequence number -> the caller's index
+        self._done = {}                # sequence number -> result, waiting for its turn
+        self._in_flight = [0] * self.world
+        self.max_out_of_order = 0      # how far ahead of the release point a result has arrived (diagnostics / tests)
+        self.closed = False
+        lean_ac = acoustic_converter.without_weights() if self.comm == 'native' and self.world > 1 else None
+        lean_sr = super_resolution.without_weights() if self.comm == 'native' and self.world > 1 else None
+        for r, dev in enumerate(self.devices):
+            ac = acoustic_converter if (r == 0 or lean_ac is None) else lean_ac
+            sr = super_resolution if (r == 0 or lean_sr is None) else lean_sr
+            p = self._mp.Process(target=_worker_main, name='ry355-gpu%d' % dev, daemon=True,
+                                 args=(r, self.world, dev, ac, sr, threshold, self.comm, os.path.join(self._dir, 'rccl_id'), int(depth),
+                                       self._q_in[r], self._q_out, worker_hook))
+            p.start()
+            self._procs.append(p)
+        ready, t0 = 0, time.time()
+        while ready < self.world:
+            kind, r, _, payload = self._get(start_timeout - (time.time() - t0))
+            if kind != 'ready':
+                self.close()
+                raise RuntimeError('worker %d failed to start:\n%s' % (r, payload))
+            ready += 1
+
+    # ---- plumbing
+    def _get(self, timeout: Optional[float]):
+        """One message from the workers; a worker that died without a word is an error, not a hang."""
+        import queue
+        deadline = None if timeout is None else time.time() + max(timeout, 0.0)
+        while True:
+            try:
+                return self._q_out.get(True, 0.2)
+            except queue.Empty:
+                for r, p in enumerate(self._procs):
+                    if not p.is_alive() and p.exitcode not in (0, None):
+                        return ('error', r, -1, 'worker process %s exited with code %s' % (p.name, p.exitcode))
+                if deadline is not None and time.time() > deadline:
+                    raise TimeoutError('no message from the GPU workers')
+
+    def _take(self, msg) -> None:
+        kind, r, seq, payload = msg
+        if kind == 'error':
+            self.close()
+            raise RuntimeError('GPU worker %d failed:\n%s' % (r, payload))
+        self._in_flight[r] -= 1
+        self._done[seq] = payload
+        self.max_out_of_order = max(self.max_out_of_order, seq - self._released)
+
+    # ---- the caller's side
+    def submit(self, index, f_in, discard: Tuple[int, int] = (0, 0), pick: Optional[Tuple[int, int, Sequence[str]]] = None) -> int:
+        """Hand a fetched window to the next GPU (round robin).  `discard` = (front, back) frames the caller throws away (not computed by
+        stage 2), `pick` = (first, last, keys): the worker returns `feature.pick(first, last, keys)` (only the kept frames travel back).
+        Blocks while that worker's ring is full; never waits for results."""
+        if self.closed:
+            raise RuntimeError('dispatcher is closed')
+        seq = self._submitted
+        r = seq % self.world
+        self._labels[seq] = index
+        self._q_in[r].put((seq, f_in, (int(discard[0]), int(discard[1])), pick))
+        self._in_flight[r] += 1
+        self._submitted += 1
+        return r
+
+    def pending(self) -> int:
+        return self._submitted - self._released
+
+    def collect(self, block: bool = False, timeout: Optional[float] = None) -> List[Tuple[object, object]]:
+        """[(index, feature), ...] of every window whose turn has come, in submission order.  block=True waits until at least the next
+        window in order is there (if any is pending)."""
+        import queue
+        out = []
+        while True:
+            while True:                                      # drain what has arrived
+                try:
+                    self._take(self._q_out.get_nowait())
+                except queue.Empty:
+                    break
+            while self._released in self._done:
+                out.append((self._labels.pop(self._released), self._done.pop(self._released)))
+                self._released += 1
+            if out or not block or self.pending() == 0:
+                return out
+            self._take(self._get(timeout))
+
+    def drain(self, timeout: Optional[float] = None) -> List[Tuple[object, object]]:
+        out = []
+        while self.pending():
+            out += self.collect(block=True, timeout=timeout)
+        return out
+
+    def close(self) -> None:
+        if self.closed:
+            return
+        self.closed = True
+        for q, p in zip(self._q_in, self._procs):
+            if p.is_alive():
+                try:
+                    q.put(_STOP, True, 1.0)
+                except Exception:
+                    pass
+        for p in self._procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.terminate()                                # this exact child (never by pattern)
+        for q in self._q_in + [self._q_out]:
+            q.close()
+        shutil.rmtree(self._dir, ignore_errors=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def convert_worker_multi_gpu(acoustic_converter, super_resolution, time_length: float, extra_time: float, input_silent_threshold: float,
+                             queue_input, queue_output, acquired_lock, devices: Sequence[int] = (0,), comm: str = 'auto', depth: int = 2,
+                             worker_hook: Optional[Callable] = None, mp_context: str = 'spawn') -> None:
+    """Drop-in process target for the reference's `convert_worker` (/root/reference/realtime_voice_conversion/worker/convert_worker.py:17-59):
+    same arguments and `Item` protocol, the reference's own `ConvertStream` for `add` / `fetch` (imported from the maintainer's installed
+    `realtime_voice_conversion` package at call time), the windows converted on `devices`.  An item of `None` ends the loop."""
+    from realtime_voice_conversion.stream import ConvertStream
+    from .voice_changer import VoiceChanger
+    from .worker import retire_time
+    logger = logging.getLogger('convert')
+    # the central stream only fetches: its VoiceChanger is never asked to convert (no GPU context in this process)
+    stream = ConvertStream(voice_changer=VoiceChanger(super_resolution=super_resolution, acoustic_converter=acoustic_converter,
+                                                      threshold=input_silent_threshold))
+    pad = round(extra_time * stream.in_segment_method.sampling_rate)           # convert_stream.py:40-42
+    pick = (pad, -pad, PICK_KEYS) if pad > 0 else None
+    disp = ChunkDispatcher(acoustic_converter, super_resolution, devices, threshold=input_silent_threshold, comm=comm, depth=depth,
+                           worker_hook=worker_hook, mp_context=mp_context)
+    items = {}
+    try:
+        acquired_lock.release()
+        start_time, current = extra_time, 0.0
+
+        def release(block):
+            for index, out_feature in disp.collect(block=block):
+                item, t0 = items.pop(index)
+                item.item = out_feature
+                queue_output.put(item)
+                logger.debug('%s: %s', item.index, time.time() - t0)
+        while True:
+            if disp.pending() and queue_input.empty():
+                release(block=True)
+                continue
+            item = queue_input.get()
+            if item is None:
+                while disp.pending():
+                    release(block=True)
+                return
+            items[item.index] = (item, time.time())
+            stream.add(start_time=start_time, data=item.item)
+            start_time += time_length
+            in_feature = stream.fetch(start_time=current, time_length=time_length, extra_time=extra_time)
+            current += time_length
+            disp.submit(item.index, in_feature, discard=(pad, pad), pick=pick)
+            stream.remove(end_time=retire_time(current, time_length, extra_time))
+            release(block=False)
+    finally:
+        disp.close()

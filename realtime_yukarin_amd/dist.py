@@ -14,6 +14,7 @@ Two interchangeable transports for that broadcast:
   at all; the 128-byte RCCL id travels from rank 0 to the others through a file next to MASTER_PORT (same node).
 """
 import os
+import tempfile
 import time
 from typing import List, Optional, Sequence
 
@@ -31,12 +32,18 @@ def _dist():
 
 
 def world() -> int:
-    dist = _dist()
+    try:
+        dist = _dist()
+    except ImportError:                      # the torch-free transport (NativeComm) must not need torch for its helpers
+        return 1
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def rank() -> int:
-    dist = _dist()
+    try:
+        dist = _dist()
+    except ImportError:
+        return 0
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
@@ -104,31 +111,58 @@ class TorchComm(object):
 
 # ------------------------------------------------------------------------------------------------ RCCL through the C ABI
 def _rendezvous_path() -> str:
+    """Where rank 0 leaves the 128-byte RCCL id for the other ranks of the same launch: a file in a directory only this user can
+    write (0700), named after the launcher's pid and MASTER_PORT -- every worker of one `torch.distributed.run` launch has the same
+    parent.  RY_COMM_RENDEZVOUS names the file explicitly (the dispatcher passes a path inside a fresh private directory)."""
     p = os.environ.get('RY_COMM_RENDEZVOUS')
     if p:
         return p
-    # every worker of one `torch.distributed.run` launch has the same parent (the elastic agent): the name is unique per launch
-    return '/tmp/ry355_comm_%d_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'))
+    d = os.path.join(tempfile.gettempdir(), 'ry355-%d' % os.getuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise _lib.Ry355Error('%s is not a private directory of this user: refusing to exchange the RCCL id through it' % d)
+    return os.path.join(d, 'comm_%d_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0')))
+
+
+def _launch_time() -> float:
+    """Start of the process that launched the ranks (their common parent): an id file older than this is a leftover of another run."""
+    try:
+        return os.stat('/proc/%d' % os.getppid()).st_mtime
+    except OSError:
+        return 0.0
 
 
 class NativeComm(object):
-    def __init__(self, ctx: engine.Context, rank_: int, world_: int, timeout: float = 120.0):
+    def __init__(self, ctx: engine.Context, rank_: int, world_: int, timeout: float = 120.0, path: Optional[str] = None):
         import ctypes
         self.ctx, self.rank, self.world, self.kind = ctx, int(rank_), int(world_), 'rccl (C ABI, dlopen)'
         lib = ctx.lib
         idb = ctypes.create_string_buffer(128)
-        path = _rendezvous_path()
+        path = path or _rendezvous_path()
         if self.rank == 0:
             lib.check(lib.dll.ry_comm_unique_id(idb))
             if self.world > 1:
-                with open(path + '.tmp', 'wb') as f:
+                for stale in (path, path + '.tmp'):            # whatever a crashed run (or anybody else) left under this name goes first
+                    try:
+                        os.remove(stale)
+                    except OSError:
+                        pass
+                fd = os.open(path + '.tmp', os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+                with os.fdopen(fd, 'wb') as f:
                     f.write(idb.raw)
                 os.replace(path + '.tmp', path)
         else:
-            t0 = time.time()
-            while not os.path.exists(path):
+            t0, born = time.time(), _launch_time() - 2.0
+            while True:
+                try:
+                    st = os.stat(path)
+                    if st.st_mtime >= born and st.st_size == 128:     # written during THIS launch (a leftover is older than the launcher)
+                        break
+                except OSError:
+                    pass
                 if time.time() - t0 > timeout:
-                    raise _lib.Ry355Error('rank %d: no RCCL id at %s after %.0f s' % (self.rank, path, timeout))
+                    raise _lib.Ry355Error('rank %d: no RCCL id of this launch at %s after %.0f s' % (self.rank, path, timeout))
                 time.sleep(0.01)
             with open(path, 'rb') as f:
                 idb.raw = f.read(128)

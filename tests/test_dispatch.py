@@ -1,0 +1,179 @@
+"""The multi-GPU dispatcher of the chained path (realtime_yukarin_amd/dispatch.py): window k -> GPU k mod G, one process per GPU, results
+released in `Item.index` order (/root/reference/run.py:171-183), windows built centrally by the stream's `fetch`
+(/root/reference/realtime_voice_conversion/stream/base_stream.py:32-79).
+
+CPU suite: two emulator workers under injected jitter -- worker 0 is slow, so windows finish OUT of order -- must release in order and
+return the bits the single-worker run returns; a worker that dies is reported, not waited for.  `-m gpu`: G = 1 through the same code
+on the real GPU with the weights arriving by a (one-rank) RCCL broadcast, against the composed oracle."""
+import importlib
+import pickle
+import threading
+import time
+from pathlib import Path
+
+import numpy
+import pytest
+
+import test_shims_e2e as e2e
+from realtime_yukarin_amd import compat, dispatch, engine
+
+compat.install()
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path('/root/reference')
+KEYS = ('f0', 'ap', 'sp', 'voiced', 'mc')
+
+
+def emu_hook(rank):
+    """Runs inside every worker process (tests only): the lazily created context becomes the emulator build, and worker 0 is slow."""
+    from realtime_yukarin_amd import _lib, build
+    ctx = engine.Context(0, _lib.Ry355Lib(build.build_emu()))
+    engine.get_context = lambda device=0, lib=None: ctx
+
+    def per_window(index):
+        if rank == 0:
+            time.sleep(0.4)
+    return per_window
+
+
+def dying_hook(rank):
+    emu_hook(rank)
+    if rank == 1:
+        raise RuntimeError('worker %d cannot see its GPU' % rank)
+
+
+def windows(n_frames, count):
+    from yukarin import AcousticFeature, Wave
+    out = []
+    for i in range(count):
+        wave, feat = e2e.make_window(n_frames, 700 + i)
+
+        class_feat = AcousticFeature(**{k: v.copy() for k, v in feat.items()})
+        class_feat.wave = Wave(wave=wave, sampling_rate=e2e.FS)
+        out.append((wave, feat, class_feat))
+    return out
+
+
+def run(ac, sr, devices, wins, hook, comm='host', pad=7, mp_context='spawn'):
+    pick = (pad, -pad, ('f0', 'ap', 'sp', 'voiced', 'mc')) if pad > 0 else None
+    with dispatch.ChunkDispatcher(ac, sr, devices, threshold=60, comm=comm, worker_hook=hook, mp_context=mp_context, start_timeout=900) as d:
+        got, workers = [], []
+        for i, (_, _, f) in enumerate(wins):
+            workers.append(d.submit(100 + i, f, discard=(pad, pad), pick=pick))
+            got += d.collect()
+        got += d.drain(timeout=900)
+        return got, workers, d.max_out_of_order
+
+
+def same(a, b):
+    return all(numpy.array_equal(getattr(a, k), getattr(b, k)) for k in KEYS)
+
+
+def test_two_workers_out_of_order_completion_in_order_release_same_bits(tmp_path):
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    wins = windows(40, 7)
+    one, w1, _ = run(ac, sr, [0], wins, emu_hook)
+    two, w2, ooo = run(ac, sr, [0, 0], wins, emu_hook)
+    assert w1 == [0] * 7 and w2 == [0, 1, 0, 1, 0, 1, 0]                         # window k -> worker k mod G
+    assert [i for i, _ in one] == [i for i, _ in two] == list(range(100, 107))   # released in submission (= Item.index) order
+    assert ooo >= 1, 'the fast worker must have finished windows ahead of the slow one (otherwise the test shows nothing)'
+    for (_, a), (_, b) in zip(one, two):
+        assert a.sp.shape == (40 - 14, 513) and same(a, b)                       # only the kept frames travel back; bit for bit
+    # ... and they are what the in-process window call returns
+    from realtime_yukarin_amd import _lib, build
+    from realtime_yukarin_amd.voice_changer import VoiceChanger
+    ctx = engine.Context(0, _lib.Ry355Lib(build.build_emu()))
+    real = engine.get_context
+    engine.get_context = lambda device=0, lib=None: ctx
+    try:
+        vc = VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60)
+        for (_, out), (_, _, f) in zip(two, wins):
+            ref = vc.convert_from_acoustic_feature(f, discard=(7, 7)).pick(7, -7, keys=list(KEYS))
+            assert same(out, ref)
+        vc.close(); ac.close(); sr.close()
+    finally:
+        engine.get_context = real
+
+
+def test_a_dead_worker_is_reported_not_waited_for(tmp_path):
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match='cannot see its GPU|exited with code'):
+        dispatch.ChunkDispatcher(ac, sr, [0, 0], comm='host', worker_hook=dying_hook, start_timeout=600)
+    assert time.time() - t0 < 300
+
+
+def test_weightless_copies_for_the_broadcast_receivers(tmp_path):
+    """What the dispatcher ships to GPUs 1 .. G-1 when the weights travel by RCCL: the config without the host weights."""
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    la, ls = ac.without_weights(), sr.without_weights()
+    assert la._params is None and ls._params is None and ac._params is not None and sr._params is not None
+    assert len(pickle.dumps(la)) < len(pickle.dumps(ac)) / 10
+    assert la.desc == ac.desc and la.f0_converter is ac.f0_converter and ls.desc == sr.desc
+    with pytest.raises(RuntimeError, match='carries no weights'):
+        la._get_net()
+    with pytest.raises(RuntimeError, match='carries no weights'):
+        ls._get_net(513)
+
+
+@pytest.mark.skipif(not REF.exists(), reason='/root/reference is not mounted here')
+def test_drop_in_worker_over_two_gpus_matches_the_single_gpu_mirror(tmp_path, emu_ctx, monkeypatch):
+    """`convert_worker_multi_gpu` (the reference's ConvertStream for add / fetch, two emulator workers) against the single-GPU mirror
+    worker on the same items: same windows out, in order."""
+    for p in (str(ROOT / 'tests' / 'stubs'), str(REF)):
+        monkeypatch.syspath_prepend(p)
+    vc_mod = importlib.import_module('realtime_voice_conversion.yukarin_wrapper.voice_changer')
+    util = importlib.import_module('realtime_voice_conversion.worker.utility')
+    from realtime_yukarin_amd import worker
+    from realtime_yukarin_amd.transport import FeatureQueue
+    monkeypatch.setattr(engine, 'get_context', lambda device=0, lib=None: emu_ctx)
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    time_length, extra_time, n_items = 0.2, 0.05, 6
+    inputs = []
+    for i in range(n_items):
+        wave, feat = e2e.make_window(40, 900 + i)
+        inputs.append(vc_mod.AcousticFeatureWrapper(wave=e2e_wave(wave), **feat))
+
+    def drive(target, extra_kwargs):
+        q_in, q_out = FeatureQueue(slots=8, slot_bytes=4 << 20), FeatureQueue(slots=8, slot_bytes=4 << 20)
+        lock = threading.Lock(); lock.acquire()
+        t = threading.Thread(target=target, args=(ac, sr, time_length, extra_time, 60, q_in, q_out, lock), kwargs=extra_kwargs, daemon=True)
+        t.start()
+        for i, f in enumerate(inputs):
+            q_in.put(util.Item(item=f, index=i))
+        q_in.put(None)
+        got = [q_out.get(timeout=900) for _ in range(n_items)]
+        t.join(timeout=120)
+        assert not t.is_alive()
+        q_in.close(); q_out.close()
+        return got
+    want = drive(worker.convert_worker, {})
+    got = drive(dispatch.convert_worker_multi_gpu, dict(devices=[0, 0], comm='host', worker_hook=emu_hook, mp_context='spawn'))
+    assert [g.index for g in got] == [w.index for w in want] == list(range(n_items))
+    for g, w in zip(got, want):
+        assert g.item.sp.shape == w.item.sp.shape == (40, 513)
+        for k in ('f0', 'ap', 'sp', 'voiced'):
+            assert numpy.array_equal(getattr(g.item, k), getattr(w.item, k)), k
+
+
+def e2e_wave(wave):
+    from yukarin import Wave
+    return Wave(wave=wave, sampling_rate=e2e.FS)
+
+
+@pytest.mark.gpu
+def test_dispatcher_with_one_gpu_and_the_rccl_broadcast_gpu(tmp_path, gpu_ctx):
+    """G = 1 on the real GPU through the same code: a spawned worker process, the predictors arriving by a one-rank RCCL broadcast
+    (`ry_comm_bcast_weights`) and adopted by the shims, windows through the shared-memory rings, against the composed oracle."""
+    from oracle import torch_ref
+    P1, P2 = e2e.write_models(tmp_path, 'SYN-64')
+    ac, sr = e2e.build_converters(tmp_path)
+    t1, t2 = torch_ref.TorchUNet(P1), torch_ref.TorchUNet(P2)
+    wins = windows(300, 4)
+    got, workers, _ = run(ac, sr, [0], wins, None, comm='native', pad=0)
+    assert [i for i, _ in got] == [100, 101, 102, 103] and workers == [0, 0, 0, 0]
+    for (_, out), (wave, feat, _) in zip(got, wins):
+        e2e.check(out, e2e.expected(t1, t2, ac.f0_converter, wave, feat, 300, 60), 300, 'dispatcher G=1 (RCCL broadcast)')
