@@ -92,6 +92,31 @@ def pmc_table():
     return {}, None
 
 
+def rocprof_table():
+    """{kernel name: average microseconds per launch} from the newest committed `rocprofv3 --kernel-trace --stats` summary made from THIS
+    kernel source, one window at a time (profiles/*kernel_stats.txt, not the two-lane trace): what `roofline.frac` is computed from, so that
+    the figure in the line can be recomputed from profiles/.  Empty when no summary of the current source exists."""
+    import glob
+    want = source_hash()
+    for path in sorted(glob.glob(str(ROOT / 'profiles' / '*kernel_stats.txt')), reverse=True):
+        lines = open(path).read().splitlines()
+        if not any(('source ' + want) in ln for ln in lines[:3]):
+            continue
+        tab = {}
+        for line in lines:
+            if line.startswith('#') or line.startswith('kernel'):
+                continue
+            cols = line.split()
+            try:
+                name = line[:line.index('(Ry')] if '(Ry' in line else line[:72]
+                avg = float(cols[-2])
+            except (ValueError, IndexError):
+                continue
+            tab[name.replace('void ', '').replace(' ', '')] = avg
+        return tab, Path(path).name
+    return {}, None
+
+
 def main(argv=None):
     args = parse(argv)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC for RCCL / device-buffer sharing: before the HIP runtime comes up
@@ -155,19 +180,37 @@ def main(argv=None):
         if torch is not None and not emu:
             torch.cuda.synchronize()
 
-    # ---- synthetic windows, resident in HBM before the timed region (different data per rank); every frame effective
-    xs_host = synth.stage1_input(N, Wn, seed=synth.SEED_INPUT + 10 * rank)
+    # ---- synthetic windows, resident in HBM before the timed region (different data per rank).  NW DISTINCT windows take turns (nine:
+    # each of the six ring slots of the window call sees three different ones).  Two sets over the same inputs:
+    #   'all'   every frame effective (the workload `value` is quoted on);
+    #   'mixed' one window in three with a silent stretch, as the silence gate of a live stream leaves it (voice_changer.py:27-37): fewer
+    #           effective frames go through stage 1 -- another padded length, i.e. another stage-1 launch plan, and a frame count the
+    #           captured stage-1 graphs of a ring slot were not taken for -- and are scattered back into the silent block.
+    NW = 9
+    xs_host = synth.stage1_input(N, max(NW, Wn), seed=synth.SEED_INPUT + 10 * rank)
     rows_host = numpy.arange(N, dtype=numpy.int32)
-    d_x = [ctx.dev_alloc(N * d1.in_ch) for _ in range(Wn)]
-    for w in range(Wn):
-        ctx.dev_upload(d_x[w], xs_host[w])
-    d_rows = ctx.dev_alloc(N)
-    ctx.dev_upload(d_rows, rows_host)
+    silent_len = {0: max(1, N * 2 // 15), 4: max(1, N // 3), 8: max(1, N * 3 // 5)}        # 300 frames: 260 / 200 / 120 effective -> 384 / 256 / 128 padded
+    wsets = {'all': [], 'mixed': []}
+    for w in range(max(NW, Wn)):
+        for kind in ('all', 'mixed'):
+            eff = numpy.ones(N, bool)
+            if kind == 'mixed' and w in silent_len:
+                a = (N - silent_len[w]) // 2
+                eff[a:a + silent_len[w]] = False
+            rows = numpy.nonzero(eff)[0].astype(numpy.int32)
+            if kind == 'mixed' and not (w in silent_len):
+                wsets[kind].append(wsets['all'][w])                                          # the same device buffers
+                continue
+            dx = ctx.dev_alloc(len(rows) * d1.in_ch); ctx.dev_upload(dx, xs_host[w][eff])
+            dr = ctx.dev_alloc(len(rows)); ctx.dev_upload(dr, rows)
+            wsets[kind].append(dict(d_x=dx, d_rows=dr, n_eff=int(len(rows)), eff=eff, w=w))
+    d_x = [q['d_x'] for q in wsets['all']]
+    d_rows = wsets['all'][0]['d_rows']
     # windows that are in flight together write their own result blocks (six ring slots)
     NB = 6 * Wn
     d_mc = [ctx.dev_alloc(N * d1.out_ch) for _ in range(NB)]
     d_sp = [ctx.dev_alloc(N * synth.FFT_BINS) for _ in range(NB)]
-    turn = {'n': 0, 'w0': 0}
+    turn = {'n': 0, 'w0': 0, 'set': 'all', 'win': 0, 'w0_win': 0}
     sync_all()
 
     if args.profile_only:
@@ -190,12 +233,15 @@ def main(argv=None):
         return None
 
     def step():
+        ws = wsets[turn['set']]
         for w in range(Wn):
             k = turn['n'] % NB
             turn['n'] += 1
+            q = ws[turn['win'] % len(ws)]
             if w == 0:
-                turn['w0'] = k
-            core.enqueue_device(d_x[w], d_rows, N, N, d_mc[k], d_sp[k], SP_FLOOR)
+                turn['w0'], turn['w0_win'] = k, q['w']
+            turn['win'] += 1
+            core.enqueue_device(q['d_x'], q['d_rows'], q['n_eff'], N, d_mc[k], d_sp[k], SP_FLOOR)
 
     def fence():
         sync_all()
@@ -208,7 +254,7 @@ def main(argv=None):
     def timed():
         # launch plans and captured graphs of every ring slot are built before the warm-up (one-off set-up, like loading the weights)
         if not primed['done']:
-            for _ in range(0 if emu else 2 * 6):
+            for _ in range(0 if emu else 3 * 6):
                 step()
             primed['done'] = True
         # W untimed warm-up steps, then exactly K steps between barrier + synchronize fences; the maximum over the ranks
@@ -244,7 +290,21 @@ def main(argv=None):
     elapsed, dev_ms = timed()
     sp_gpu = numpy.empty((N, synth.FFT_BINS), numpy.float32); ctx.dev_download(d_sp[turn['w0']], sp_gpu)      # window 0 of the last timed step
     mc_gpu = numpy.empty((N, d1.out_ch), numpy.float32); ctx.dev_download(d_mc[turn['w0']], mc_gpu)
+    x_checked = xs_host[turn['w0_win']]                                                                        # ... which converted this input
     assert numpy.isfinite(sp_gpu).all() and numpy.isfinite(mc_gpu).all() and (sp_gpu > 0).all()
+    # the same K steps over the 'mixed' set (one window in three cut by the silence gate); every rank runs it (the fences hold barriers)
+    turn['set'] = 'mixed'; primed['done'] = False
+    elapsed_mixed, _ = timed()
+    # a gated window of that region for the parity check: run the shortest one once more, synchronously, into a block of its own
+    qm = wsets['mixed'][8 % len(wsets['mixed'])]
+    sync_all(); core.enqueue_device(qm['d_x'], qm['d_rows'], qm['n_eff'], N, d_mc[0], d_sp[0], SP_FLOOR); sync_all()
+    sp_gated = numpy.empty((N, synth.FFT_BINS), numpy.float32); ctx.dev_download(d_sp[0], sp_gated)
+    mc_gated = numpy.empty((N, d1.out_ch), numpy.float32); ctx.dev_download(d_mc[0], mc_gated)
+    assert not mc_gated[~qm['eff']].any() and numpy.isfinite(sp_gated).all()
+    turn['set'] = 'all'; primed['done'] = False
+    for _ in range(0 if emu else 18):
+        step()
+    sync_all(); primed['done'] = True
 
     frames_total = world * Wn * N * args.steps
     value = frames_total / elapsed
@@ -262,7 +322,14 @@ def main(argv=None):
         'effective_x_realtime_note': '%d of the %d frames of a window are overlap context that ConvertStream discards; buffer_time %.2f s / %.4f ms per window'
                                      % (2 * extra, N, (N - 2 * extra) * 0.005, ms_window),
         'device_ms_per_step_rank0': round(dev_ms / args.steps, 4),
-        'step': 'chained device-resident core (ry_vc_enqueue_device): stage-1 -> combine_silent -> mc2sp + 1e-16 -> stage-2, two windows in flight',
+        'step': 'chained device-resident core (ry_vc_enqueue_device): stage-1 -> combine_silent -> mc2sp + 1e-16 -> stage-2, two windows in flight; '
+                '%d distinct windows take turns, every frame effective' % NW,
+        'mixed_stream': {'value': round(frames_total / elapsed_mixed, 1), 'unit': 'frames/s', 'ms_per_step': round(elapsed_mixed / args.steps * 1e3, 4),
+                         'steps': args.steps, 'effective_frames_of_the_gated_windows': [int(q['n_eff']) for q in wsets['mixed'] if q['n_eff'] < N],
+                         'note': 'the same K steps, the same bracket, over the same %d windows with one in three cut by the silence gate (a silent '
+                                 'stretch in the middle): stage 1 converts only the effective frames -- another padded length and launch plan, frame '
+                                 'counts that change from window to window on every ring slot -- and combine_silent scatters them back; `value` still '
+                                 'counts every frame handed to convert' % NW},
         'comm': None if comm is None else comm.kind,
         'config': {'workload': 'BASELINE config #3: stage-1 + stage-2 SR forward, buffer_time 0.5 s + 2x0.5 s convert_extra_time '
                                '@16 kHz / 5 ms -> %d real frames (%d padded) per window, %d window(s) per GPU per step, %s random-init weights'
@@ -329,7 +396,32 @@ def main(argv=None):
             for _ in range(20):
                 core.wait_wave(core.submit_wave(wv32, 80, 1024, p_eff, p_all, xh))
             gated_ms = (time.perf_counter() - th) / 20 * 1e3
-            out['host_path'] = {'call_ms_per_window': round(host_ms, 4), 'stream_ms_per_window': round(stream_ms, 4),
+            # what a LIVE stream sees (one buffer every buffer_time, no backlog): one synchronous call per window.  The mirror worker announces the
+            # overlap frames ConvertStream.process picks away (worker.convert_worker: discard = (pad, pad)); and the gate makes the number of
+            # effective frames change from window to window on the same ring buffers (stage-1 graphs are taken per frame count)
+            live = {}
+            if extra > 0:
+                core.set_discard(extra, extra)
+                for _ in range(12):
+                    core.convert(xh, eff)
+                th = time.perf_counter()
+                for _ in range(20):
+                    core.convert(xh, eff)
+                live['call_ms_per_window_with_discard_hint'] = round((time.perf_counter() - th) / 20 * 1e3, 4)
+                core.set_discard(0, 0)
+            effs = []
+            for i in range(6):
+                e = numpy.ones(N, bool); e[20 + 7 * i:20 + 7 * i + 11 + 9 * i] = False
+                effs.append(e)
+            for i in range(24):
+                core.convert(xh[effs[i % 6]], effs[i % 6])
+            th = time.perf_counter()
+            for i in range(24):
+                core.convert(xh[effs[i % 6]], effs[i % 6])
+            live['call_ms_per_window_varying_effective_frames'] = round((time.perf_counter() - th) / 24 * 1e3, 4)
+            for _ in range(12):
+                core.convert(xh, eff)
+            out['host_path'] = {'call_ms_per_window': round(host_ms, 4), 'stream_ms_per_window': round(stream_ms, 4), **live,
                                 'call_with_device_gate_ms_per_window': round(gated_ms, 4),
                                 'stream_frames_per_s': round(N / (stream_ms * 1e-3), 1),
                                 'note': 'host arrays in, host arrays out through the pinned ring of ry_vc_submit / ry_vc_wait (PCIe inclusive): one window '
@@ -355,7 +447,8 @@ def main(argv=None):
                 ctx.dev_free(d_b_in); ctx.dev_free(d_b_out)
             # the whole chained window call for 8 windows at once (ry_vc_enqueue_device_batch): stage 1 as one batch, the hop on the device, stage 2 as one batch
             bw = 8
-            xb = synth.stage1_input(N, bw, seed=synth.SEED_INPUT + 10 * rank)        # window 0 is the timed step's window 0
+            xb = synth.stage1_input(N, max(NW, Wn), seed=synth.SEED_INPUT + 10 * rank)[:bw].copy()
+            xb[0] = x_checked                                                        # window 0 is the window the timed step converted last
             d_bx = ctx.dev_alloc(bw * N * d1.in_ch); d_br = ctx.dev_alloc(bw * N)
             d_bmc = ctx.dev_alloc(bw * N * d1.out_ch); d_bsp = ctx.dev_alloc(bw * N * synth.FFT_BINS)
             ctx.dev_upload(d_bx, xb); ctx.dev_upload(d_br, numpy.tile(rows_host, bw))
@@ -442,11 +535,22 @@ def main(argv=None):
         dname, dv = max(((k, v) for k, v in fam.items() if k in st2_names), key=lambda kv: kv[1]['ms'])
         ach = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
         pmc, pmc_file = pmc_table()
+        rpf, rpf_file = rocprof_table()
         targs = dname[dname.find('<') + 1:-1].split(',') if dname.startswith('ry_igemm_ldsdma<') else []
         is_bf16 = len(targs) > 5 and targs[5] == 'true'
         peak_tf = 2500.0 if is_bf16 else F32_MFMA_PEAK_TF
+        # `frac` comes from the rocprofv3 average of the SAME source (profiles/<..>kernel_stats.txt, matched by the hash of csrc/), so that it
+        # can be recomputed from profiles/; the live HIP-event figure of this very run stays beside it as `frac_events`
+        ach_ev = ach
+        rp_us = rpf.get(dname.replace(' ', ''))
+        if rp_us:
+            ach = dv['flops'] / dv['launches'] / (rp_us * 1e-6) / 1e12
         out['roofline'] = {'kernel': dname, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
-                           'frac': round(ach / peak_tf, 4), 'traffic': pmc.get(dname.replace(' ', ''), (None,))[0],
+                           'frac': round(ach / peak_tf, 4),
+                           'frac_source': ('%s: avg %.3f us per launch (rocprofv3 --kernel-trace --stats, one window at a time)' % (rpf_file, rp_us)) if rp_us
+                                          else 'HIP events of this run (no rocprofv3 summary of source %s under profiles/)' % source_hash(),
+                           'achieved_events': round(ach_ev, 2), 'frac_events': round(ach_ev / peak_tf, 4),
+                           'traffic': pmc.get(dname.replace(' ', ''), (None,))[0],
                            'traffic_unit': 'HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)',
                            'traffic_source': pmc_file, 'source_hash': source_hash(),
                            'launches': dv['launches'], 'avg_launch_ms': round(dv['ms'] / dv['launches'], 4),
@@ -485,7 +589,9 @@ def main(argv=None):
 
         # ---- CPU baseline beside it: the oracle's torch/oneDNN restatement of the SAME chained window on this box's host cores
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(args, torch, d1, d2, xs_host[0], mc_gpu, sp_gpu, N, value)
+            out['cpu_baseline'] = cpu_baseline(args, torch, d1, d2, x_checked, mc_gpu, sp_gpu, N, value,
+                                               gated=(xs_host[qm['w']], qm['eff'], mc_gated, sp_gated))
+            out['mixed_stream']['gpu_result_of_a_gated_window_vs_cpu_restatement'] = out['cpu_baseline'].pop('gated_window')
     if rank == 0:
         print(json.dumps(out), flush=True)
     core.close(); net1.close(); net2.close()
@@ -494,7 +600,7 @@ def main(argv=None):
     return out
 
 
-def cpu_baseline(args, torch, d1, d2, x, mc_gpu, sp_gpu, N, gpu_value):
+def cpu_baseline(args, torch, d1, d2, x, mc_gpu, sp_gpu, N, gpu_value, gated=None):
     """Bounded sample of the same workload on the host cores: the torch/oneDNN restatement (oracle/torch_ref.py) of stage-1 -> mc2sp ->
     stage-2 on the window the GPU just converted -- all threads, then one thread -- and the GPU result checked against it."""
     from oracle import mc2sp as omc, torch_ref
@@ -511,6 +617,15 @@ def cpu_baseline(args, torch, d1, d2, x, mc_gpu, sp_gpu, N, gpu_value):
     mc_ref, sp_ref = chain(x)                                  # warm-up + the check
     err_sp = float(numpy.abs(sp_gpu.astype(numpy.float64) / sp_ref - 1).max())
     err_mc = float(numpy.abs(mc_gpu - mc_ref).max() / numpy.abs(mc_ref).max())
+    gated_res = None
+    if gated is not None:                                      # a window of the 'mixed' region: stage 1 on the effective frames, zeros elsewhere (voice_changer.py:33-37)
+        xg, eff, mc_g, sp_g = gated
+        mcw = numpy.zeros((N, mc_ref.shape[1]), numpy.float32)
+        mcw[eff] = torch_ref.stage1_convert_core(t1n, xg[eff])
+        spw = torch_ref.stage2_convert(t2n, (omc.mc2sp(mcw, alpha, 1024) + SP_FLOOR).astype(numpy.float32))
+        gated_res = {'effective_frames': int(eff.sum()), 'sp_max_rel': float(numpy.abs(sp_g.astype(numpy.float64) / spw - 1).max()),
+                     'mc_max_norm': float(numpy.abs(mc_g - mcw).max() / numpy.abs(mcw).max()), 'bar': 1e-4}
+        assert gated_res['sp_max_rel'] < 1e-4 and gated_res['mc_max_norm'] < 1e-4, 'gated window differs from the CPU restatement: %r' % gated_res
     reps, tb = 0, time.perf_counter()
     while True:
         chain(x); reps += 1
@@ -531,7 +646,7 @@ def cpu_baseline(args, torch, d1, d2, x, mc_gpu, sp_gpu, N, gpu_value):
                      'CPU restatement (torch/oneDNN fp32), not Chainer; host has %d logical cpus' % (reps, N, nthr, mid, os.cpu_count()),
            'frames_per_s_by_threads': {str(k): round(v, 1) for k, v in sorted(by_threads.items())},
            'gpu_over_cpu': round(gpu_value / by_threads[best], 1),
-           'gpu_result_vs_this_baseline': {'sp_max_rel': err_sp, 'mc_max_norm': err_mc, 'bar': 1e-4}}
+           'gpu_result_vs_this_baseline': {'sp_max_rel': err_sp, 'mc_max_norm': err_mc, 'bar': 1e-4}, 'gated_window': gated_res}
     assert err_sp < 1e-4 and err_mc < 1e-4, 'GPU result of the timed region differs from the CPU restatement: %g %g' % (err_sp, err_mc)
     # BASELINE config #1, the plumbing baseline: check.py's schedule (/root/reference/check.py:96-125) = 5 windows of 1 s + 2 x 1 s
     # extra = 600 frames each, converted one after the other; here with the same restatement, one pass
