@@ -48,6 +48,9 @@ typedef struct ry_net_desc {
     int width;              /* stage-2: bins fed to the predictor (fft_size/2 = 512); stage-1: 1 */
     float bn_eps;           /* Chainer BatchNormalization eps = 2e-5 */
     float lrelu_slope;      /* F.leaky_relu slope = 0.2 */
+    int glu;                /* stage-1 only, UNVERIFIED [MEM]: `model.glu_generator` of the stage-1 config -- every conv + BatchNormalization block of
+                             * the U-Net produces twice the channels and is gated, a * sigmoid(b), instead of (leaky) ReLU.  The upstream class lives in
+                             * the un-vendored `yukarin` package; the strict K-list / shape check of the loader decides whether a real model fits. */
 } ry_net_desc;
 
 /* One context per (process, GPU).  Create it in the process that converts (after fork), cf. the

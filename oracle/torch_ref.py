@@ -21,8 +21,9 @@ def _t(a, dtype):
 class TorchUNet:
     """Holds the K-list parameters as torch tensors; `forward` mirrors `oracle.unet.unet_forward`."""
 
-    def __init__(self, P, extensive_layers=8, dtype=torch.float32):
+    def __init__(self, P, extensive_layers=8, dtype=torch.float32, glu=False):
         self.e = int(extensive_layers)
+        self.glu = bool(glu)                  # stage-1 glu_generator variant (UNVERIFIED [MEM], see oracle.unet.unet_forward)
         self.dtype = dtype
         self.P = {k: _t(v, dtype) for k, v in P.items() if not k.endswith('/N')}
         self.nd = self.P['encoder/c0/W'].dim() - 2
@@ -45,6 +46,8 @@ class TorchUNet:
         bn = prefix + '/batchnorm/'
         h = F.batch_norm(h, P[bn + 'avg_mean'], P[bn + 'avg_var'], P[bn + 'gamma'], P[bn + 'beta'],
                          training=False, eps=BN_EPS)
+        if self.glu:
+            return F.glu(h, dim=1)            # h[:, :C] * sigmoid(h[:, C:])
         return F.leaky_relu(h, LRELU_SLOPE) if act == 'lrelu' else F.relu(h)
 
     @torch.no_grad()

@@ -38,22 +38,27 @@ def _cbr(x, P, prefix, sample, act, ops=ops):
     return ops.apply_act(h, act)
 
 
-def unet_forward(x, P, extensive_layers=8, return_all=False, ops=ops):
+def unet_forward(x, P, extensive_layers=8, return_all=False, ops=ops, glu=False):
     """`Predictor.__call__` / `SRPredictor.__call__`: x (B, in_ch, *spatial) -> (B, out_ch, *spatial).
 
     The spatial rank is taken from the weights (1 -> stage-1, 2 -> stage-2).  `ops` selects the operator restatement:
-    `ops_numpy` (default) or `c_ref` (the plain-C loop nests of ops_ref.c)."""
+    `ops_numpy` (default) or `c_ref` (the plain-C loop nests of ops_ref.c).
+
+    glu=True: the stage-1 `model.glu_generator` variant as THIS repository reads it -- UNVERIFIED [MEM], the upstream class is in the
+    un-vendored `yukarin` package: every conv + BatchNormalization block computes twice the channels and is gated, h[:C] * sigmoid(h[C:])
+    (`chainer.functions.glu` along the channel axis), in place of leaky_relu (encoder) / relu (decoder); c0 and the last layer as before."""
     e = int(extensive_layers)
     end_pad = 1 if e > 0 else 0
+    act_e, act_d = ('glu', 'glu') if glu else ('lrelu', 'relu')
     hs = [ops.leaky_relu(ops.conv_nd(x, P['encoder/c0/W'], P['encoder/c0/b'], stride=1, pad=end_pad))]
     for i in range(1, 8):
-        hs.append(_cbr(hs[i - 1], P, 'encoder/c%d' % i, 'down' if i < e else 'same', 'lrelu', ops))
-    h = _cbr(hs[7], P, 'decoder/c0', 'up' if 7 < e else 'same', 'relu', ops)
+        hs.append(_cbr(hs[i - 1], P, 'encoder/c%d' % i, 'down' if i < e else 'same', act_e, ops))
+    h = _cbr(hs[7], P, 'decoder/c0', 'up' if 7 < e else 'same', act_d, ops)
     acts = {'enc': hs, 'dec': [h]}
     for j in range(1, 8):
         h = np.concatenate([h, hs[7 - j]], axis=1)
         if j < 7:
-            h = _cbr(h, P, 'decoder/c%d' % j, 'up' if (7 - j) < e else 'same', 'relu', ops)
+            h = _cbr(h, P, 'decoder/c%d' % j, 'up' if (7 - j) < e else 'same', act_d, ops)
             acts['dec'].append(h)
         else:
             h = ops.conv_nd(h, P['decoder/c7/W'], P['decoder/c7/b'], stride=1, pad=end_pad)
@@ -67,7 +72,7 @@ def pad_frames(n):
     return 128 - n % 128
 
 
-def stage1_convert_core(x_nc, P, extensive_layers=8, ops=ops):
+def stage1_convert_core(x_nc, P, extensive_layers=8, ops=ops, glu=False):
     """Array part of `AcousticConverter.convert` ([MEM]):
     x_nc (N, C_in) = encode_feature(...) before the transpose -> (N, C_out).
 
@@ -75,7 +80,7 @@ def stage1_convert_core(x_nc, P, extensive_layers=8, ops=ops):
     n = x_nc.shape[0]
     pad = pad_frames(n)
     x = np.pad(x_nc.T, [(0, 0), (0, pad)], mode='minimum')
-    y = unet_forward(x[np.newaxis], P, extensive_layers, ops=ops)[0]
+    y = unet_forward(x[np.newaxis], P, extensive_layers, ops=ops, glu=glu)[0]
     return np.ascontiguousarray(y[:, :-pad].T)
 
 

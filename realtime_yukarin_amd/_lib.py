@@ -47,7 +47,7 @@ ABI_SYMBOLS = (
 class RyNetDesc(ctypes.Structure):
     _fields_ = [('ndim', ctypes.c_int), ('in_ch', ctypes.c_int), ('out_ch', ctypes.c_int),
                 ('base', ctypes.c_int), ('extensive_layers', ctypes.c_int), ('width', ctypes.c_int),
-                ('bn_eps', ctypes.c_float), ('lrelu_slope', ctypes.c_float)]
+                ('bn_eps', ctypes.c_float), ('lrelu_slope', ctypes.c_float), ('glu', ctypes.c_int)]
 
 
 class RyKernelStat(ctypes.Structure):

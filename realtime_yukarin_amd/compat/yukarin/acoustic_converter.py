@@ -36,7 +36,7 @@ class AcousticConverter(object):
         self._param = config.dataset.acoustic_param
         self.out_sampling_rate = self._param.sampling_rate if out_sampling_rate is None else out_sampling_rate
         m = config.model
-        self.desc = NetDesc(1, m.in_channels, m.out_channels, m.generator_base_channels, m.generator_extensive_layers)
+        self.desc = NetDesc(1, m.in_channels, m.out_channels, m.generator_base_channels, m.generator_extensive_layers, glu=bool(m.glu_generator))
         self._params = load_npz(self.desc, model_path)            # strict K-list / shape validation
         self._net = None
         self._net_pid = None
@@ -66,8 +66,7 @@ class AcousticConverter(object):
 
     def adopt_net(self, net: engine.Net) -> None:
         """Use a device-resident predictor that was built elsewhere in THIS process (from a broadcast weight blob)."""
-        if (net.desc.ndim, net.desc.in_ch, net.desc.out_ch, net.desc.base, net.desc.extensive_layers) != (
-                self.desc.ndim, self.desc.in_ch, self.desc.out_ch, self.desc.base, self.desc.extensive_layers):
+        if net.desc != self.desc:
             raise ValueError('adopt_net: predictor %r does not match the config %r' % (net.desc, self.desc))
         self.close()
         self._net, self._net_pid = net, os.getpid()

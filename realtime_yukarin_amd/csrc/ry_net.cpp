@@ -178,6 +178,9 @@ static std::vector<Layer> build_topology(const ry_net_desc& d) {
     std::vector<Layer> L(16);
     const int B = d.base, e = d.extensive_layers;
     const int end_k = e > 0 ? 3 : 1;
+    // glu_generator (stage 1, UNVERIFIED [MEM]): a conv + BN block computes 2 x co channels (value | gate), its consumers see co = value * sigmoid(gate)
+    const int g = (d.glu && d.ndim == 1) ? 2 : 1;
+    const int blk_act_e = g == 2 ? RY_ACT_GLU : RY_ACT_LRELU, blk_act_d = g == 2 ? RY_ACT_GLU : RY_ACT_RELU;
     auto nm = [](Layer& l, const char* p, int i) { snprintf(l.name, sizeof l.name, "%s/c%d", p, i); };
     {   // encoder c0: conv + bias, leaky_relu
         Layer& l = L[0]; nm(l, "encoder", 0);
@@ -187,13 +190,13 @@ static std::vector<Layer> build_topology(const ry_net_desc& d) {
         Layer& l = L[i]; nm(l, "encoder", i);
         const bool down = i < e;
         l.k = down ? 4 : 1; l.stride = down ? 2 : 1; l.pad = down ? 1 : 0;
-        l.cin_a = ENC_CH[i - 1] * B; l.cout = ENC_CH[i] * B; l.src_a = i - 1; l.bn = true; l.act = RY_ACT_LRELU;
+        l.cin_a = ENC_CH[i - 1] * B; l.cout = ENC_CH[i] * B * g; l.src_a = i - 1; l.bn = true; l.act = blk_act_e;
     }
     for (int j = 0; j < 7; ++j) {
         Layer& l = L[8 + j]; nm(l, "decoder", j);
         const bool up = (7 - j) < e;
         l.deconv = up; l.k = up ? 4 : 1; l.stride = up ? 2 : 1; l.pad = up ? 1 : 0;
-        l.cout = DEC_OUT[j] * B; l.bn = true; l.act = RY_ACT_RELU;
+        l.cout = DEC_OUT[j] * B * g; l.bn = true; l.act = blk_act_d;
         if (j == 0) { l.cin_a = DEC_IN[0] * B; l.src_a = 7; }
         else { l.cin_a = DEC_OUT[j - 1] * B; l.cin_b = ENC_CH[7 - j] * B; l.src_a = 8 + j - 1; l.src_b = 7 - j; }
     }
@@ -221,6 +224,8 @@ static int check_desc(const ry_net_desc* d) {
     if (d->ndim == 2 && d->width < 1) return fail(RY_EINVAL, "stage-2 needs width >= 1");
     if (d->ndim == 2 && (d->in_ch != 1 || d->out_ch != 1))
         return fail(RY_EINVAL, "stage-2 (SRPredictor) takes and returns one channel (got %d -> %d)", d->in_ch, d->out_ch);
+    if (d->glu != 0 && d->glu != 1) return fail(RY_EINVAL, "glu must be 0 or 1 (got %d)", d->glu);
+    if (d->glu && d->ndim != 1) return fail(RY_EINVAL, "glu_generator is a stage-1 option");
     return RY_OK;
 }
 
@@ -1205,7 +1210,7 @@ static RySrc1d src1d_of(const ry_net* net, const Plan& P, int idx) {
     const Layer& l = net->layers[idx];
     const LayerPlan& lp = P.lp[idx];
     s.raw = lp.raw; s.scale = l.scale; s.shift = l.shift; s.slab_stride = lp.slab_stride;
-    s.C = l.cout; s.Craw = l.cout; s.splits = lp.splits; s.act = l.act;
+    s.C = l.act == RY_ACT_GLU ? l.cout / 2 : l.cout; s.Craw = l.cout; s.splits = lp.splits; s.act = l.act;
     return s;
 }
 

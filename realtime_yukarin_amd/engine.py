@@ -344,7 +344,7 @@ class Net(object):
         self.desc = desc
         self.width = int(width) if desc.ndim == 2 else 1
         self.cdesc = _lib.RyNetDesc(desc.ndim, desc.in_ch, desc.out_ch, desc.base, desc.extensive_layers, self.width,
-                                    bn_eps, lrelu_slope)
+                                    bn_eps, lrelu_slope, int(bool(desc.glu)))
         lib = ctx.lib
         want = int(lib.dll.ry_net_param_count(ctypes.byref(self.cdesc)))
         if want != param_count(desc):

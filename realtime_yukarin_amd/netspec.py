@@ -29,10 +29,13 @@ class NetDesc:
     out_ch: int
     base: int = 64
     extensive_layers: int = 8
+    glu: bool = False          # stage-1 `model.glu_generator` (UNVERIFIED [MEM]): gated blocks, twice the conv / BN channels per block
 
     def __post_init__(self):
         if self.ndim not in (1, 2):
             raise ValueError('ndim must be 1 or 2')
+        if self.glu and self.ndim != 1:
+            raise ValueError('glu_generator is a stage-1 option')
         if min(self.in_ch, self.out_ch, self.base) < 1 or not (0 <= self.extensive_layers <= 8):
             raise ValueError('bad NetDesc %r' % (self,))
 
@@ -52,16 +55,17 @@ def dec_sample(desc: NetDesc, j: int) -> str:
 def param_list(desc: NetDesc) -> List[Tuple[str, Tuple[int, ...]]]:
     """Ordered (key, shape) for every float array of the predictor (BN counter `N` excluded)."""
     B = desc.base
+    g = 2 if desc.glu else 1          # a gated block computes 2 x co channels (value | gate) and hands co on
     end_k = 3 if desc.extensive_layers > 0 else 1
     out = [('encoder/c0/W', (B, desc.in_ch) + _k(desc, end_k)), ('encoder/c0/b', (B,))]
     for i in range(1, 8):
-        ci, co = ENC_CH[i - 1] * B, ENC_CH[i] * B
+        ci, co = ENC_CH[i - 1] * B, ENC_CH[i] * B * g
         k = 4 if enc_sample(desc, i) == 'down' else 1
         p = 'encoder/c%d' % i
         out += [(p + '/c/W', (co, ci) + _k(desc, k)), (p + '/c/b', (co,))]
         out += [(p + '/batchnorm/' + n, (co,)) for n in BN_KEYS]
     for j in range(0, 7):
-        ci, co = DEC_IN[j] * B, DEC_OUT[j] * B
+        ci, co = DEC_IN[j] * B, DEC_OUT[j] * B * g
         p = 'decoder/c%d' % j
         if dec_sample(desc, j) == 'up':
             out += [(p + '/c/W', (ci, co) + _k(desc, 4))]          # Deconvolution: (Cin, Cout, k...)
@@ -88,13 +92,14 @@ def flops(desc: NetDesc, T: int, width: int = 1) -> int:
     n = desc.ndim
     sp = [T] if n == 1 else [T, width]
     B = desc.base
+    g = 2 if desc.glu else 1
     end_k = 3 if desc.extensive_layers > 0 else 1
     area = lambda s: int(numpy.prod(s))
     total = 2 * desc.in_ch * B * end_k ** n * area(sp)
     cur = list(sp)
     sizes = [list(cur)]
     for i in range(1, 8):
-        ci, co = ENC_CH[i - 1] * B, ENC_CH[i] * B
+        ci, co = ENC_CH[i - 1] * B, ENC_CH[i] * B * g
         if enc_sample(desc, i) == 'down':
             cur = [c // 2 for c in cur]
             total += 2 * ci * co * 4 ** n * area(cur)
@@ -102,7 +107,7 @@ def flops(desc: NetDesc, T: int, width: int = 1) -> int:
             total += 2 * ci * co * area(cur)
         sizes.append(list(cur))
     for j in range(0, 7):
-        ci, co = DEC_IN[j] * B, DEC_OUT[j] * B
+        ci, co = DEC_IN[j] * B, DEC_OUT[j] * B * g
         if dec_sample(desc, j) == 'up':
             total += 2 * ci * co * 4 ** n * area(cur)
             cur = [c * 2 for c in cur]

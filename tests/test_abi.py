@@ -33,13 +33,13 @@ def test_library_exports_every_symbol(lib):
 @pytest.mark.parametrize('desc', [NetDesc(1, 9, 9, 64, 8), NetDesc(1, 523, 9, 16, 8), NetDesc(2, 1, 1, 64, 8),
                                   NetDesc(2, 1, 1, 8, 8), NetDesc(1, 9, 9, 8, 3), NetDesc(1, 9, 9, 8, 0)])
 def test_param_count_matches_netspec(lib, desc):
-    c = _lib.RyNetDesc(desc.ndim, desc.in_ch, desc.out_ch, desc.base, desc.extensive_layers, 512 if desc.ndim == 2 else 1, 2e-5, 0.2)
+    c = _lib.RyNetDesc(desc.ndim, desc.in_ch, desc.out_ch, desc.base, desc.extensive_layers, 512 if desc.ndim == 2 else 1, 2e-5, 0.2, int(desc.glu))
     assert int(lib.dll.ry_net_param_count(ctypes.byref(c))) == param_count(desc)
     assert param_count(desc) == sum(int(numpy.prod(s)) for _, s in param_list(desc))
 
 
 def test_bad_descriptor_is_an_error_not_a_crash(lib):
-    c = _lib.RyNetDesc(3, 9, 9, 64, 8, 1, 2e-5, 0.2)
+    c = _lib.RyNetDesc(3, 9, 9, 64, 8, 1, 2e-5, 0.2, 0)
     assert int(lib.dll.ry_net_param_count(ctypes.byref(c))) == 0
     assert b'ndim' in lib.dll.ry_last_error()
 
