@@ -224,9 +224,6 @@ int ry_net_profile_window(ry_net* net, int n_frames, int reps, ry_kernel_stat* s
  * ~1 when the two streams run side by side, ~2 when one waits for the other (scripts/gpu_r2_queues.py). */
 int ry_debug_stream_overlap(ry_ctx* ctx, int n, int us, float* ratio);
 
-/* diagnostics (RY_TIMING=1 only): per-phase shader-clock totals of ry_igemm_f32, summed over waves; reads and resets */
-int ry_debug_igemm_phases(ry_ctx* ctx, unsigned long long* out8);
-
 /* diagnostics: the launch configuration the stage-2 planner picks for an implicit-GEMM layer with M output rows (pixels of
  * one sub-pixel phase), Cout output channels, `nphases` phases (4 for the k4s2 deconvolution, else 1) and K = 32 * nk:
  * tile code (see ry_conv2d), external split-K count, K groups per workgroup, estimated microseconds.  No device work. */

@@ -19,8 +19,8 @@ DEFAULT_LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GLU = 0, 1, 2, 3
 ACTS = {None: ACT_NONE, 'none': ACT_NONE, 'lrelu': ACT_LRELU, 'relu': ACT_RELU, 'glu': ACT_GLU}
 PATH_AUTO, PATH_IGEMM, PATH_DIRECT = 0, 1, 2
-TILES = {None: 0, 'auto': 0, '128x128': 1, '256x64': 2, '64x128': 3, '32x128': 4, '128x64': 5, '96x128': 6, '256x128': 7}
-TILES.update({k + 'k2': v + 16 for k, v in list(TILES.items()) if isinstance(k, str) and k not in ('auto', '256x64', '256x128')})   # two K groups per workgroup
+TILES = {None: 0, 'auto': 0, '128x128': 1, '64x128': 3, '32x128': 4, '128x64': 5, '96x128': 6}
+TILES.update({k + 'k2': v + 16 for k, v in list(TILES.items()) if isinstance(k, str) and k != 'auto'})   # two K groups per workgroup
 TILES.update({k + 'k1': v + 32 for k, v in list(TILES.items()) if isinstance(k, str) and k[-2:] != 'k2' and k != 'auto'})           # force one
 
 # every symbol include/ry355.h declares (checked by tests/test_abi.py)
@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     'ry_init', 'ry_shutdown', 'ry_sync', 'ry_stream', 'ry_device_count', 'ry_last_error',
     'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_clone', 'ry_net_set_dtype', 'ry_net_forward',
     'ry_ac_convert', 'ry_sr_convert', 'ry_sr_convert_rows', 'ry_conv1d', 'ry_conv2d', 'ry_conv2d_dilated',
-    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_net_profile_window', 'ry_debug_igemm_phases', 'ry_debug_plan_igemm', 'ry_debug_stream_overlap', 'ry_debug_plan_igemm_bf16',
+    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_net_profile_window', 'ry_debug_plan_igemm', 'ry_debug_stream_overlap', 'ry_debug_plan_igemm_bf16',
     'ry_vc_create', 'ry_vc_destroy', 'ry_vc_convert', 'ry_mc2sp',
     'ry_vc_submit', 'ry_vc_set_lanes', 'ry_vc_set_discard', 'ry_vc_wait', 'ry_vc_enqueue_device', 'ry_vc_enqueue_device_batch', 'ry_vc_stage1', 'ry_vc_stage2_from_mc', 'ry_vc_mid_sp', 'ry_vc_reserve_frames',
     'ry_vc_submit_wave', 'ry_vc_wait_wave', 'ry_vc_gate',

@@ -14,7 +14,6 @@
 //                       epilogue with 16-byte stores, optional split-K slabs; tiles 128x128 / 96x128 / 128x64 / 64x128 / 32x128
 //                       (the bf16 form also runs the split-bf16 mode: sources [pixel][hi | lo], K axis [hi | lo | hi] against
 //                       filters [w_hi | w_hi | w_lo] = three bf16 products per fp32 product, fp32 accumulate -- DESIGN.md 4.7)
-//   ry_igemm_f32        the register-staged predecessor: kept for 256-row tiles and as the RY_LDSDMA=0 A/B
 //   ry_splitk_reduce    sum of split-K slabs + folded BN + activation
 //   ry_sr_first / ry_sr_last   the 1 -> N and C -> 1 3x3 end layers of stage 2 (HBM / L2-bound)
 //   ry_conv_direct      generic VALU conv (odd channel counts)
@@ -114,256 +113,8 @@ struct RyIgemmParams {
     int kq, krem;               // K chunks per split: split s takes kq + (s < krem) chunks starting at s * kq + min(s, krem)
     int tw;                     // > 0: an M-tile is a 2-D block of (BM/tw) x tw rows of the Mh x Mw grid (compact input footprint:
                                 //      overlapping taps hit L2); 0: BM consecutive rows in raster order
-    unsigned long long* dbg;    // VAR bit 1 (diagnostic build of the kernel): per-phase shader-clock totals, else unused
     int dbg_flags;              // diagnostics of ry_igemm_ldsdma (wrong results): 4 skip the output stores, 8 skip the K loop, 128 skip the loads in the K loop
 };
-
-// VAR bit 1 (RY_TIMING=1, diagnostics only): every wave accumulates s_memtime deltas per loop phase into p.dbg.
-// ILV = 1: the global loads of chunk k+1 are issued in BK/8 slices between the MFMA steps of chunk k instead of
-// in one burst before them (a burst of 8-12 16-byte loads per lane from every wave of the CU back-pressures the
-// vector-memory queue and the wave cannot issue its MFMAs while it is stuck issuing loads).
-template <int BM, int BN, int WM, int WN, int BK, int VAR>
-RY_KERNEL(256) void ry_igemm_f32(RyIgemmParams p) {
-    constexpr int ILV = VAR & 1;
-    constexpr bool TIMING = (VAR & 2) != 0;
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
-#if defined(RY_HOST_EMU)
-#define RY_STAMP(i)
-#else
-#define RY_STAMP(i) if (TIMING) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); tph[i] += t_now - t_prev; t_prev = t_now; }
-    if (TIMING) t_prev = __builtin_amdgcn_s_memtime();
-#endif
-    static_assert(BK == 32, "the filter layout is blocked in 32-deep K chunks");
-    constexpr int BKP = BK + 4;                    // +4-float row pad: conflict-free ds_read_b128
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int TPR = BK / 4;                    // threads per row of a K chunk (16 bytes each)
-    constexpr int RSTEP = 256 / TPR;               // rows covered by one pass of the workgroup
-    constexpr int AR = BM / RSTEP, BR = BN / RSTEP; // 16-byte loads per thread per K chunk
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
-    __shared__ __attribute__((aligned(16))) float As[BM * BKP];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * BKP];
-    __shared__ int rY[BM], rX[BM], rP[BM], rO[BM];
-
-    const RyConvGeom& g = p.g;
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 31, lh = lane >> 5;
-    // XCD-aware 1-D grid: block b runs on XCD b % 8 (observed dispatch rule, speed only); give each XCD a contiguous
-    // range of logical ids so the phases / N-tiles / neighbouring M-tiles that re-read the same input pixels share one L2
-    const int total_tiles = p.splits * p.mtiles * p.ntiles * p.g.nphases;
-    const int per_xcd = (total_tiles + 7) >> 3;
-    int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (lid >= total_tiles) return;
-    const int phase = lid % p.g.nphases; lid /= p.g.nphases;
-    const int nt = lid % p.ntiles; lid /= p.ntiles;
-    const int mt = lid % p.mtiles;
-    const int split = lid / p.mtiles;
-    const int m0 = mt * BM;
-    const int n0 = nt * BN;
-    const int Ctot = g.C1 + g.C2;
-    const int Mimg = g.Mh * g.Mw;
-    const int M = g.B * Mimg;
-    // sub-pixel deconv: phase (py,px) reads input offset (py - ty, px - tx) for tap (ty,tx); conv reads (ky,kx).
-    // Offsets are derived from (ky,kx) counters -- no table loads inside the K loop.
-    const bool subpix = g.ostride == 2;
-    const int pdy = subpix ? (phase >> 1) : 0, pdx = subpix ? (phase & 1) : 0;
-
-    // per-row geometry, once per workgroup
-    for (int r = tid; r < BM; r += 256) {
-        const int m = m0 + r;
-        int yb = -(1 << 20), xb = 0, pb = 0, ob = -1;
-        bool live = m < M;
-        int b = 0, ry = 0, rx = 0;
-        if (p.tw > 0) {                            // 2-D tile: mt enumerates (image, tile row, tile column)
-            const int th = BM / p.tw, tcols = g.Mw / p.tw, trows = g.Mh / th;
-            const int tx = mt % tcols, ty = (mt / tcols) % trows;
-            b = mt / (tcols * trows);
-            ry = ty * th + r / p.tw; rx = tx * p.tw + r % p.tw;
-            live = b < g.B;
-        } else if (live) {
-            b = m / Mimg; const int rem = m - b * Mimg;
-            ry = rem / g.Mw; rx = rem - ry * g.Mw;
-        }
-        if (live) {
-            yb = ry * g.stride - g.pad;
-            xb = rx * g.stride - g.pad;
-            pb = b * g.Hs * g.Wi;
-            ob = (b * g.Hos + ry * g.ostride + pdy) * g.Wo + rx * g.ostride + pdx;
-        }
-        rY[r] = yb; rX[r] = xb; rP[r] = pb; rO[r] = ob;
-    }
-    __syncthreads();
-
-    const int c4 = (tid % TPR) * 4;                // float offset of this thread's 16 bytes in a K chunk
-    const int rbase = tid / TPR;                   // 0..RSTEP-1
-    // Per-row state: base coordinates (for the padding test) and the element offset of the row's base pixel.
-    // Offsets are 32-bit (the executor bounds every activation below 2^31 elements); a tap only adds a
-    // workgroup-uniform delta, so the K loop does one vector add per row instead of 64-bit multiplies.
-    int ayb[AR], axb[AR], aoff1[AR], aoff2[AR];
-#pragma unroll
-    for (int j = 0; j < AR; ++j) {
-        ayb[j] = rY[rbase + RSTEP * j]; axb[j] = rX[rbase + RSTEP * j];
-        const int pixb = rP[rbase + RSTEP * j] + ayb[j] * g.Wi + axb[j];     // may be "negative" on padded rows: never dereferenced
-        aoff1[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C1 + c4 : 0;
-        aoff2[j] = (ayb[j] > -(1 << 19)) ? pixb * g.C2 + c4 : 0;
-    }
-    unsigned boff[BR];
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-        const int n = n0 + rbase + RSTEP * j;
-        boff[j] = (unsigned)((phase * (g.N >> 6) + (n >> 6)) * (g.ntaps * (Ctot >> 5)) * 2048 +
-                             ((n >> 5) & 1) * 1024 + (c4 >> 3) * 256 + (((c4 >> 2) & 1) * 32 + (n & 31)) * 4);   // fragment-ordered block
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int cpt = Ctot / BK;                     // K chunks per tap
-    const int nk = g.ntaps * cpt;
-    const int kc_begin = (int)(((long long)nk * split) / p.splits);
-    const int kc_end = (int)(((long long)nk * (split + 1)) / p.splits);
-    int tap = kc_begin / cpt;
-    int cib = kc_begin - tap * cpt;
-    int ky = tap / g.kw, kx = tap - (tap / g.kw) * g.kw;
-
-    // Register staging, one chunk deep: the loads issued while chunk k computes are those of chunk k+1.  (A two-chunk-deep
-    // variant, fragment prefetch, a one-barrier LDS-double-buffered loop and per-workgroup priorities were all measured
-    // as nulls or losses on MI355X -- DESIGN.md section 4.1.)
-    constexpr int DEPTH = 1;
-    f32x4 areg[DEPTH][AR], breg[DEPTH][BR];
-    unsigned amask[DEPTH];
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) amask[d] = 0;
-    // chunk state of the loads being issued (workgroup-uniform)
-    const float* src = g.src1;
-    int delta = 0, dy = 0, dx = 0;
-    bool first = true;
-    unsigned bdelta = 0;
-    auto chunk_setup = [&](int set) {              // scalars of the next chunk of the walk; then advances the walk
-        const int ci0 = cib * BK;
-        first = ci0 < g.C1;
-        src = first ? g.src1 : g.src2;
-        const int Cs = first ? g.C1 : g.C2;
-        const int cil = first ? ci0 : ci0 - g.C1;
-        dy = subpix ? pdy - ky : ky * g.dil; dx = subpix ? pdx - kx : kx * g.dil;
-        delta = (dy * g.Wi + dx) * Cs + cil;                    // workgroup-uniform (scalar unit)
-        bdelta = (unsigned)((tap * cpt + cib) * 2048);
-        amask[set] = 0;
-        if (++cib == cpt) { cib = 0; ++tap; if (++kx == g.kw) { kx = 0; ++ky; } }
-    };
-    auto load_a = [&](int set, int j) {
-        const int iy = ayb[j] + dy, ix = axb[j] + dx;
-        const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-        // zero padding / ragged rows: load a valid address and discard (no divergent control flow around the load)
-        const int off = ok ? (first ? aoff1[j] : aoff2[j]) + delta : c4;
-        areg[set][j] = ry_ld4(src + (unsigned)off); // zeroed when it is written to LDS, so the wait sits after the MFMAs
-        amask[set] |= ok ? (1u << j) : 0u;
-    };
-    auto load_b = [&](int set, int j) { breg[set][j] = ry_ld4(p.wt + (boff[j] + bdelta)); };
-
-    const int nchunks = kc_end - kc_begin;
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {              // prologue: chunks 0 .. DEPTH-1 into the register sets
-        if (d < nchunks) {
-            chunk_setup(d);
-#pragma unroll
-            for (int j = 0; j < AR; ++j) load_a(d, j);
-#pragma unroll
-            for (int j = 0; j < BR; ++j) load_b(d, j);
-        }
-    }
-    constexpr int NS = BK / 8;                     // MFMA steps per chunk (8 K values each)
-    RY_STAMP(5)
-    // one iteration: registers of `set` (chunk k) -> LDS, then `set` is re-used for the loads of chunk k + DEPTH
-    auto iteration = [&](int k, int set) {
-        __syncthreads();                           // previous chunk's fragment reads are done
-        RY_STAMP(0)
-#pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            f32x4 v = areg[set][j];
-            if (!(amask[set] & (1u << j))) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
-            ry_st4(&As[(rbase + RSTEP * j) * BKP + c4], v);
-        }
-#pragma unroll
-        for (int j = 0; j < BR; ++j) ry_st4(&Bs[(rbase + RSTEP * j) * BKP + c4], breg[set][j]);
-        RY_STAMP(1)
-        __syncthreads();
-        RY_STAMP(2)
-        const bool more = k + DEPTH < nchunks;
-        if (more) {
-            chunk_setup(set);
-            if (!ILV) {                            // global loads in flight under the MFMAs below
-#pragma unroll
-                for (int j = 0; j < AR; ++j) load_a(set, j);
-#pragma unroll
-                for (int j = 0; j < BR; ++j) load_b(set, j);
-            }
-        }
-        RY_STAMP(3)
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = ry_ld4(&As[((wm * TM + i) * 32 + lr) * BKP + s * 8 + lh * 4]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = ry_ld4(&Bs[((wn * TN + j) * 32 + lr) * BKP + s * 8 + lh * 4]);
-            if (ILV && more) {                     // slice s of the loads being issued
-#pragma unroll
-                for (int j = 0; j < AR; ++j) if (j % NS == s) load_a(set, j);
-#pragma unroll
-                for (int j = 0; j < BR; ++j) if (j % NS == s) load_b(set, j);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = ry_mfma_32x32x2(af[i][t], bf[j][t], acc[i][j]);
-#ifndef RY_HOST_EMU
-            if (ILV) __builtin_amdgcn_sched_barrier(0);       // keep the load slices where they are
-#endif
-        }
-        RY_STAMP(4)
-    };
-    for (int k = 0; k < nchunks; ++k) iteration(k, 0);
-
-    // epilogue: D[row=(r&3)+8*(r>>2)+4*lh][col=lr]; 32 lanes store 128 contiguous bytes of one pixel
-    float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + lr;
-        float sc = 1.f, sh = 0.f;
-        if (p.splits == 1) { sc = p.scale[n]; sh = p.shift[n]; }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int ob = rO[ml];
-                if (ob >= 0) {
-                    float v = acc[i][j][r];
-                    if (p.splits == 1) v = ry_act(fmaf(v, sc, sh), p.act, p.slope);
-                    outp[(size_t)ob * g.N + n] = v;
-                }
-            }
-        }
-    }
-    RY_STAMP(6)
-#if !defined(RY_HOST_EMU)
-    if (TIMING && p.dbg && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) atomicAdd(p.dbg + i, tph[i]);
-        atomicAdd(p.dbg + 7, 1ull);
-    }
-#endif
-#undef RY_STAMP
-}
 
 // ---------------------------------------------------------------------------------------------
 // ry_igemm_ldsdma<BM, BN, WM, WN, KG, BF16, PATCH> -- the stage-2 implicit GEMM (DESIGN.md 4.1 has the measurements behind

@@ -359,7 +359,7 @@ static bool igemm_eligible(const Layer& l) {
 // ------------------------------------------------------------------------------------------------
 enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4, PATH_IGEMM_BF16 = 5,
        PATH_IGEMM_X3 = 6 };   // op-level selector only (ry_conv2d): runs as PATH_IGEMM_BF16 with LayerPlan::x3
-enum { TILE_128x128 = 1, TILE_256x64 = 2, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5, TILE_96x128 = 6, TILE_256x128 = 7 };
+enum { TILE_128x128 = 1, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5, TILE_96x128 = 6 };   // (2 and 7 were the 256-row tiles of the register-staged kernel, removed in round 3)
 
 struct LayerPlan {
     // geometry
@@ -384,7 +384,6 @@ struct LayerPlan {
     int crop_lo = 0;                          // ... starting at this input row (> 0 when the caller discards the leading frames of the window too)
     int last_rows = 0, last_cols = 0, last_exp = 0;   // PATH_LAST: fused exp / edge-pad / crop
     int last_row0 = 0, last_out_rows = 0;     // PATH_LAST: first output row computed, rows per image of the caller's block (0: last_rows)
-    bool last_x3 = false;                     // PATH_LAST in split-bf16 mode: reads the producers' [hi | lo] copies instead of fp32 ones
     double flops = 0, bytes = 0;
 };
 
@@ -407,10 +406,10 @@ struct Plan {
     // one captured graph per (input, output) address pair the plan has been run with: host callers (plan staging), device callers
     // and the ring slots of ry_vc each keep their own, so switching between them neither re-captures nor destroys an exec that
     // may still be in flight
-    struct GraphSlot { const float* in; float* out; hipGraphExec_t gexec; hipGraphExec_t gexec2; bool tried; long long graph_n, last_n; unsigned long long used; };
+    struct GraphSlot { const float* in; float* out; hipGraphExec_t gexec; bool tried; long long graph_n, last_n; unsigned long long used; };
     std::vector<GraphSlot> gslots;
     unsigned long long gclock = 0;
-    ~Plan() { for (GraphSlot& g : gslots) { if (g.gexec) hipGraphExecDestroy(g.gexec); if (g.gexec2) hipGraphExecDestroy(g.gexec2); } }
+    ~Plan() { for (GraphSlot& g : gslots) if (g.gexec) hipGraphExecDestroy(g.gexec); }
 #endif
 };
 
@@ -427,9 +426,6 @@ struct ry_net {
     ry_stream_t stream = nullptr;            // each predictor enqueues on its own stream: stage-1 of one window overlaps stage-2 of another
     rt::Event done;                          // (spare: ry_sync / ry_timer_stop join the predictor streams on the host)
     bool has_done = false;
-    int split_at = 0;                        // > 0 (stage 2): the forward runs as two graphs, layers [0, split_at) and the rest, with `mid` recorded between them
-    rt::Event mid;                           // ... so that the NEXT window's stage 1 can be timed to run under the weight-streaming layers at the bottom of the U-Net
-    bool mid_recorded = false;
     ry_net_desc desc;
     std::vector<Layer> layers;
     std::shared_ptr<Arena> weights = std::make_shared<Arena>();   // filters, scale / shift: shared by the clones of a predictor (ry_net_clone)
@@ -535,41 +531,28 @@ static void fill_geom(RyConvGeom& g, const Layer& l, const LayerPlan& lp, int B,
 static void tile_dims(int tile, int* bm, int* bn) {
     switch (tile) {
         case TILE_128x128: *bm = 128; *bn = 128; break;
-        case TILE_256x64: *bm = 256; *bn = 64; break;
         case TILE_64x128: *bm = 64; *bn = 128; break;
         case TILE_128x64: *bm = 128; *bn = 64; break;
         case TILE_96x128: *bm = 96; *bn = 128; break;
-        case TILE_256x128: *bm = 256; *bn = 128; break;
         default: *bm = 32; *bn = 128; break;
     }
 }
 
 
-static int g_vc_stagger = 1;  // RY_VC_STAGGER=0: stage 1 of the next window starts at once instead of under the bottom layers of the previous window's stage 2
-static int g_s2_crop = 2;     // RY_S2_CROP=0: every decoder layer of the convert wrapper computes all padded rows (A/B of the dead-row crop); 1: only grids of more than one workgroup per CU
-static int g_last_band = 1;   // RY_LAST_BAND=0: raster-order workgroups in ry_sr_last (A/B of the per-XCD row bands)
-static int g_ilv = 1;      // RY_ILV=0: issue the next chunk's global loads in one burst (measured 5% slower)
-static int g_bigtile = 0;  // RY_BIGTILE=1: 256x128 tile (4 waves of 128x64) for the large layers
-static int g_tile2d = 1;   // RY_TILE2D=0: M-tiles are raster-order row runs instead of 2-D pixel blocks
-static int g_igemm_dbg = 0; // RY_IGEMM_DBG: ablation bits of ry_igemm_ldsdma (diagnostics; wrong results)
-static int g_xcd_groups = 1;   // RY_XCD_GROUPS=0: contiguous runs of tiles per XCD instead of the M-tile x filter-slice grouping
-static int g_patch = 3;     // RY_PATCH: bit 0 = input-patch reuse in the deconvolution layers, bit 1 = in the k4 s2 convolution layers (0: every tap gathers its own A tile)
-static int g_kgroups = 1;   // RY_KGROUPS=0: never split K inside a workgroup (external split-K + reduce kernel only)
-static int g_ldsdma = 1;    // RY_LDSDMA=0: register-staged ry_igemm_f32 instead of the LDS-DMA kernel (A/B; ~5 % slower end to end)
-static int g_timing = 0;   // RY_TIMING=1: diagnostic kernel variant with s_memtime phase stamps
-static unsigned long long* g_dbg = nullptr;
-static int g_force[16][3];   // RY_PLAN="layer:tile:splits:kgroups,...": tuning aid, fixes the stage-2 plan of single layers (0 = planner's choice)
-static int g_x3_min_m = 128;   // RY_X3_MINM: split-bf16 mode runs a layer on the bf16 pipe from this many GEMM rows (per phase) up (measured at 300 frames: 1 / 32 / 64 / 128 / 512 / 2048 -> 0.861 / 0.865 / 0.867 / 0.864 vs 0.840 / 0.928 ms per step on two boxes; 128 beat 512 by 1 % in the same-box A/B)
-static int g_autotune = 0;     // RY_AUTOTUNE=1: time candidate launch plans of every stage-2 implicit-GEMM layer on the device when a plan is built (autotune_plan)
-static int g_autotune_reps = 3, g_autotune_max = 0;   // RY_AUTOTUNE_REPS timed rounds per candidate; RY_AUTOTUNE_MAX caps the candidates per layer (0 = all; tests)
-static int g_autotune_pick = -1;                      // RY_AUTOTUNE_PICK=k (tests only): take candidate k of every layer instead of the fastest
-static int g_x3_last = 0;      // RY_X3_LAST=1: split-bf16 mode: the last layer reads the producers' [hi | lo] copies, no fp32 copies kept for it (measured: step 0.829 -> 0.826 ms, error 2.6e-6 -> 3.7e-6: off by default)
-static int g_tile64 = TILE_128x64;   // tile for 64-channel outputs: 128x64 measured 94 TF vs 79 TF for 256x64 (RY_TILE64=256 selects the latter)
+// Process-wide switches (INTEGRATION.md section 6 lists every one).  Round 3 removed the A/B switches of closed experiments (register-staged
+// kernel, 256-row tiles, burst loads, raster tiles, two-graph cut + stagger, stage-1 tuning aids, ...): their measurements are in DESIGN.md.
+static int g_s2_crop = 2;     // RY_S2_CROP=0: every decoder layer of the convert wrapper computes all padded rows (A/B of the dead-row crop, used by the bit-identity tests); 1: only grids of more than one workgroup per CU
+static int g_igemm_dbg = 0;   // RY_IGEMM_DBG: ablation bits of ry_igemm_ldsdma (diagnostics; WRONG results): 4 no stores, 8 no K loop, 128 no loads in the K loop
+static int g_force[16][3];    // RY_PLAN="layer:tile:splits:kgroups,...": tuning aid, fixes the stage-2 plan of single layers (0 = planner's choice)
+static int g_x3_min_m = 128;  // RY_X3_MINM: split-bf16 mode runs a layer on the bf16 pipe from this many GEMM rows (per phase) up (measured at 300 frames: 1 / 32 / 64 / 128 / 512 / 2048 -> 0.861 / 0.865 / 0.867 / 0.864 vs 0.840 / 0.928 ms per step on two boxes; 128 beat 512 by 1 % in the same-box A/B)
+static int g_autotune = 0;    // RY_AUTOTUNE="1[:reps[:max[:pick]]]": time candidate launch plans of every stage-2 implicit-GEMM layer on the device when a plan is built (autotune_plan)
+static int g_autotune_reps = 3, g_autotune_max = 0;   // ... timed rounds per candidate; cap on the candidates per layer (0 = all; tests)
+static int g_autotune_pick = -1;                      // ... (tests only) take candidate `pick` of every layer instead of the fastest
+static const int g_patch = 3;      // bit 0 = input-patch reuse in the deconvolution layers, bit 1 = in the k4 s2 convolution layers (A/B measured, both on)
 
 // Kernel names as rocprofv3 prints them (template arguments, no spaces): bench.py matches them against profiles/*.
 static const char* tile_name(int tile, int kg, bool bf16, int patch) {
-    const bool dma = (g_ldsdma && !g_timing) || bf16;
-    if (dma && tile != TILE_256x64 && tile != TILE_256x128) {
+    {
         static std::map<int, std::string> names;        // stable storage for the returned pointers
         const int key = ((tile * 4 + kg) * 2 + (bf16 ? 1 : 0)) * 4 + patch;
         auto it = names.find(key);
@@ -582,15 +565,6 @@ static const char* tile_name(int tile, int kg, bool bf16, int patch) {
         }
         return it->second.c_str();
     }
-    switch (tile) {
-        case TILE_128x128: return "ry_igemm_f32<128,128>";
-        case TILE_256x64: return "ry_igemm_f32<256,64>";
-        case TILE_64x128: return "ry_igemm_f32<64,128>";
-        case TILE_128x64: return "ry_igemm_f32<128,64>";
-        case TILE_96x128: return "ry_igemm_f32<96,128>";
-        case TILE_256x128: return "ry_igemm_f32<256,128>";
-        default: return "ry_igemm_f32<32,128>";
-    }
 }
 
 // ---- choice of tile, split-K and K groups for one stage-2 layer ----
@@ -601,19 +575,15 @@ static thread_local int g_plan_ck = 32;             // input channels per K chun
 // split-bf16 kernels (measured, profiles/r01_n_x3_plansweep_n300.txt): the main-loop rate the planner prices them at (three times
 // the K of the bf16 mode per tile: the fixed costs weigh less, 128x128 tiles reach 730-800 TF of bf16 products = 0.7 x 1150),
 // and the price of two K groups in one 512-thread workgroup against two 256-thread workgroups on the same CU (the GEMM alone
-// ran 10-17 % slower: 69 vs 59 us on decoder c3, 73 vs 66 us on encoder c1).  RY_PLAN_X3_PEAK (TFLOP/s) / RY_PLAN_X3_KG2 override.
-static double g_x3_peak = 2.0e9, g_x3_kg2 = 1.15;
+// ran 10-17 % slower: 69 vs 59 us on decoder c3, 73 vs 66 us on encoder c1).
+static const double g_x3_peak = 2.0e9, g_x3_kg2 = 1.15;
 static thread_local double g_plan_kg2 = 1.0;        // factor on the main loop of a two-K-group workgroup
 
 static int tile_occ(int tile, int kg) {
     int bm, bn; tile_dims(tile, &bm, &bn);
-    if ((g_ldsdma || g_plan_ck == 64) && bm <= 128) {
-        const int occ = (160 * 1024) / (kg * (bm + bn) * 32 * 4 * 2 + bm * 16);
-        const int cap = 4 / kg;                                          // <= 128 VGPRs: four waves per SIMD
-        return occ > cap ? cap : occ;
-    }
-    const int occ = (160 * 1024) / ((bm + bn) * 36 * 4 + bm * 16);
-    return occ > 3 ? 3 : (occ < 1 ? 1 : occ);
+    const int occ = (160 * 1024) / (kg * (bm + bn) * 32 * 4 * 2 + bm * 16);
+    const int cap = 4 / kg;                                              // <= 128 VGPRs: four waves per SIMD
+    return occ > cap ? cap : occ;
 }
 
 // Fraction of the MFMA peak a CU sustains with r co-resident four-wave groups running the main loop (measured on gfx950:
@@ -661,13 +631,12 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
     // MFMA-bound layers: every CU should hold a full set of co-resident wave groups for the whole launch.  Candidate
     // M-tiles 128 / 96 / 64 (N-tile 128), with one or two K groups per workgroup and the best external split-K, are
     // compared by estimated time.
-    const bool kg_ok = (g_ldsdma || bf16) && g_kgroups && M > 64 && nk >= 16;
+    const bool kg_ok = M > 64 && nk >= 16;
     const int N = l.cout;
     if (*tile == 0) {
-        if (N % 128 != 0) *tile = bf16 ? TILE_128x64 : g_tile64;
+        if (N % 128 != 0) *tile = TILE_128x64;                         // (128x64 measured 94 TF vs 79 TF for the old 256x64 tile)
         else if (M <= 32) *tile = TILE_32x128;
         else if (M <= 64) *tile = TILE_64x128;
-        else if (g_bigtile && !bf16 && M >= 2048) *tile = TILE_256x128;
         else {
             const int cand[3] = {TILE_128x128, TILE_96x128, TILE_64x128};
             const double bias[3] = {1.0, 1.02, 1.08};                     // smaller tiles re-read more B per flop
@@ -699,7 +668,6 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
             if (t2 < t1 - 1e-9) *kg = 2;
         }
     }
-    if (bm > 128 || !(g_ldsdma || bf16)) *kg = 1;
     if (*splits == 0) *splits = best_split(blocks, bm, bn, nk, M <= 64, tile_occ(*tile, *kg), *kg, M, N, nullptr);
     if (*splits * *kg > nk) { *kg = 1; if (*splits > nk) *splits = nk; }
 }
@@ -723,11 +691,8 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         int bm, bn; tile_dims(lp.tile, &bm, &bn);
         p.mtiles = (M + bm - 1) / bm; p.ntiles = l.cout / bn;
         p.tw = 0;
-        if (g_tile2d) {                               // 2-D M-tiles when the row grid divides evenly
-            for (int tw = 16; tw >= 4; tw >>= 1) {
-                if (bm % tw == 0 && g.Mw % tw == 0 && g.Mh % (bm / tw) == 0) { p.tw = tw; break; }
-            }
-        }
+        for (int tw = 16; tw >= 4; tw >>= 1)           // 2-D M-tiles when the row grid divides evenly, else BM consecutive rows in raster order
+            if (bm % tw == 0 && g.Mw % tw == 0 && g.Mh % (bm / tw) == 0) { p.tw = tw; break; }
         int patch = 0;
         {   // prologue helpers of the LDS-DMA kernel (ry_fdiv reciprocals; operands stay below 2^24, checked here)
             const int ck = bf16 ? 64 : 32, cpt = (C1 + C2) / ck, nkc = g.ntaps * cpt;
@@ -739,7 +704,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             const int nsl = lp.splits * p.ntiles * g.nphases;
             p.inv_nsl = 1.f / nsl;
             p.xcd_gs = 0; p.xcd_gs_shift = 0; p.xcd_nsg = 1; p.xcd_mtg = 1; p.inv_xcd_nsg = 1.f;
-            if (g_xcd_groups) {
+            {
                 const double wbytes = (double)g.nphases * l.cout * g.ntaps * (C1 + C2), abytes = (double)B * lp.Hi * lp.Wi * (C1 + C2);
                 double best = 1e300;
                 for (int sh = 0; sh <= 3; ++sh) {
@@ -759,7 +724,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             }
             // sub-pixel deconvolution on 16-pixel-wide 2-D tiles: the patch variant of the kernel (K units = whole channel chunks)
             // 1: sub-pixel deconvolution, one patch per channel chunk; 2: k4 s2 p1 convolution, one patch per (chunk, input parity)
-            if (g_patch && (g_ldsdma || bf16) && !g_timing && p.tw == 16 && bm <= 128 && (M >= 512 || lp.any_m_patch)) {   // small layers: the longer set-up costs more than the reuse saves (measured at M = 192)
+            if (p.tw == 16 && (M >= 512 || lp.any_m_patch)) {   // small layers: the longer set-up costs more than the reuse saves (measured at M = 192)
                 if (g.ostride == 2 && (g_patch & 1) && lp.splits * lp.kg <= cpt) patch = 1;
                 else if (!l.deconv && l.k == 4 && l.stride == 2 && l.pad == 1 && l.dil == 1 && (g_patch & 2) && lp.splits * lp.kg <= 4 * cpt) patch = 2;
             }
@@ -769,21 +734,15 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
         dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
         RY_TRY(Lc.begin(tile_name(lp.tile, lp.kg, bf16, patch), l.name, lp.flops, lp.bytes, grid));
-        p.dbg = g_dbg; p.dbg_flags = g_igemm_dbg;
-#define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BK_)                                                            \
+        p.dbg_flags = g_igemm_dbg;
+#define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_)                                                                    \
     do {                                                                                                    \
-        if (g_ldsdma && !g_timing && BM_ <= 128) {                                                            \
-            constexpr int BMc = BM_ <= 128 ? BM_ : 128;                                                        \
-            if (patch == 1 && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 2, false, 1>), grid, 512, Lc.stream, p); \
-            else if (patch == 1) RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 1, false, 1>), grid, 256, Lc.stream, p);          \
-            else if (patch == 2 && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 2, false, 2>), grid, 512, Lc.stream, p); \
-            else if (patch == 2) RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 1, false, 2>), grid, 256, Lc.stream, p);          \
-            else if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 2, false, 0>), grid, 512, Lc.stream, p);          \
-            else RY_LAUNCH((ry_igemm_ldsdma<BMc, BN_, WM_, WN_, 1, false, 0>), grid, 256, Lc.stream, p);                          \
-        }                                                                                                   \
-        else if (g_timing) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 3>), grid, 256, Lc.stream, p);      \
-        else if (g_ilv) RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 1>), grid, 256, Lc.stream, p);    \
-        else RY_LAUNCH((ry_igemm_f32<BM_, BN_, WM_, WN_, BK_, 0>), grid, 256, Lc.stream, p);               \
+        if (patch == 1 && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, false, 1>), grid, 512, Lc.stream, p); \
+        else if (patch == 1) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, false, 1>), grid, 256, Lc.stream, p);          \
+        else if (patch == 2 && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, false, 2>), grid, 512, Lc.stream, p); \
+        else if (patch == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, false, 2>), grid, 256, Lc.stream, p);          \
+        else if (lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, false, 0>), grid, 512, Lc.stream, p);          \
+        else RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, false, 0>), grid, 256, Lc.stream, p);                          \
     } while (0)
 #define RY_IGEMM16_LAUNCH(BM_, BN_, WM_, WN_)                                                                  \
     do {                                                                                                    \
@@ -805,15 +764,11 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
 #undef RY_IGEMM16_LAUNCH
         } else
         switch (lp.tile) {
-            case TILE_128x128:
-                RY_IGEMM_LAUNCH(128, 128, 2, 2, 32);
-                break;
-            case TILE_256x64: RY_IGEMM_LAUNCH(256, 64, 4, 1, 32); break;
-            case TILE_64x128: RY_IGEMM_LAUNCH(64, 128, 1, 4, 32); break;
-            case TILE_128x64: RY_IGEMM_LAUNCH(128, 64, 4, 1, 32); break;
-            case TILE_96x128: RY_IGEMM_LAUNCH(96, 128, 1, 4, 32); break;
-            case TILE_256x128: RY_IGEMM_LAUNCH(256, 128, 2, 2, 32); break;
-            default: RY_IGEMM_LAUNCH(32, 128, 1, 4, 32); break;
+            case TILE_128x128: RY_IGEMM_LAUNCH(128, 128, 2, 2); break;
+            case TILE_64x128: RY_IGEMM_LAUNCH(64, 128, 1, 4); break;
+            case TILE_128x64: RY_IGEMM_LAUNCH(128, 64, 4, 1); break;
+            case TILE_96x128: RY_IGEMM_LAUNCH(96, 128, 1, 4); break;
+            default: RY_IGEMM_LAUNCH(32, 128, 1, 4); break;
         }
 #undef RY_IGEMM_LAUNCH
         RY_TRY(Lc.end());
@@ -861,13 +816,12 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         dim3 grid((unsigned)((total + 7) / 8));
         if (C1 + C2 == 128 && lp.Wi % 16 == 0) {
             const long long strips = (long long)B * p.rows_valid * (lp.Wi / 16);
-            p.xcd_band = g_last_band;
+            p.xcd_band = 1;                                   // every XCD owns a contiguous band of output rows (45.0 -> 31.5 us against raster order)
             const long long nb = (strips + 7) / 8;
-            dim3 sg((unsigned)(g_last_band ? ((nb + 7) / 8) * 8 : nb));
-            RY_TRY(Lc.begin(lp.last_x3 ? "ry_sr_last<true>" : "ry_sr_last<false>", l.name, lp.flops, lp.bytes, sg));
-            p.x3 = lp.last_x3 ? 1 : 0;
-            if (lp.last_x3) RY_LAUNCH(ry_sr_last<true>, sg, 256, Lc.stream, p);
-            else RY_LAUNCH(ry_sr_last<false>, sg, 256, Lc.stream, p);
+            dim3 sg((unsigned)(((nb + 7) / 8) * 8));
+            RY_TRY(Lc.begin("ry_sr_last<false>", l.name, lp.flops, lp.bytes, sg));
+            p.x3 = 0;
+            RY_LAUNCH(ry_sr_last<false>, sg, 256, Lc.stream, p);
         } else {
             RY_TRY(Lc.begin("ry_sr_last_gather", l.name, lp.flops, lp.bytes, grid));
             RY_LAUNCH(ry_sr_last_gather, grid, 256, Lc.stream, p);
@@ -885,7 +839,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     return RY_OK;
 }
 
-static int g_s1_wgs = 256, g_s1_maxs = 32;   // stage-1 split heuristic (RY_S1_WGS / RY_S1_MAXS: tuning aids; 128 / 16 measured 0.275 ms, 256 / 32 0.231 ms, 512 / 64 0.238 ms per forward)
+static const int g_s1_wgs = 256, g_s1_maxs = 32;   // split heuristic of the weight-streaming stage-1 kernels (128 / 16 measured 0.275 ms, 256 / 32 0.231 ms, 512 / 64 0.238 ms per forward)
 
 static int c1d_mode(const Layer& l) {
     if (l.deconv) return RY_C1D_DECONV;
@@ -940,11 +894,7 @@ static int choose_splits_1d(const Layer& l, int B, int rows, int mode) {
 
 
 // ---- stage-1, output-stationary form (ry_c1d_os) ----
-static int g_s1_timing = 0;        // RY_S1_TIMING=1 (diagnostics): every ry_c1d_os launch is followed by a sync and a print of its phase stamps
-static int g_s1_padfuse = 1;       // RY_S1_PADFUSE=0: separate ry_pad_min_rows node in front of stage 1 (A/B)
-static int g_s1_os = 1;            // RY_S1_OS=0: the round-1 weight-streaming kernels with split-K slabs (A/B)
-static int g_s1_units = 256;       // RY_S1_UNITS: smallest workgroup count a layer should reach before it takes a larger slice per workgroup
-static int g_s1_force[16][2];      // RY_S1_CFG="layer:cb:tp,...": tuning aid, fixes the (output channels, rows) slice of single layers
+static const int g_s1_units = 256;   // smallest workgroup count a layer should reach before it takes a larger slice per workgroup (128 / 256 / 512 / 1024 measured 0.119 / 0.116 / 0.112 / 0.116 ms)
 
 static bool c1d_os_capable(const Layer& l) {
     const int mode = c1d_mode(l);
@@ -978,16 +928,7 @@ static int launch_c1d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     p.sa = sa; p.sb = sb; p.Ca = Ca; p.Cb = Cb; p.w = l.w1os; p.scale = l.scale; p.shift = l.shift; p.out = out;
     p.B = B; p.Lin = lp.Wi; p.Lout = lp.Wo; p.N = l.cout; p.keep = keep; p.pad = l.pad; p.act = l.act; p.slope = slope;
     p.kt_shift = lp.os_kt == 4 ? 2 : lp.os_kt == 2 ? 1 : 0; p.n_real = n_real;
-    unsigned long long* dbg = nullptr;
-#ifndef RY_HOST_EMU
-    if (g_s1_timing) {
-        static unsigned long long* g_s1_dbg = nullptr;
-        if (!g_s1_dbg) RT_TRY(hipMalloc((void**)&g_s1_dbg, 65536 * 8 * sizeof(unsigned long long)));
-        RT_TRY(hipMemsetAsync(g_s1_dbg, 0, 65536 * 8 * sizeof(unsigned long long), Lc.stream));
-        dbg = g_s1_dbg;
-    }
-#endif
-    p.dbg = dbg;
+    p.dbg = nullptr;                                   // (per-workgroup phase stamps: -DRY_S1_STAMPS diagnostic builds only)
     const int mode = c1d_mode(l);
     const int rows = mode == RY_C1D_DECONV ? lp.Wi : lp.Wo;
     const int PG = 4 / lp.os_kt;
@@ -1022,26 +963,6 @@ static int launch_c1d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
 #undef RY_OS_CASE
 #undef RY_OS_CASE_NU
 #undef RY_OS_CASE_PM
-#ifndef RY_HOST_EMU
-    if (dbg) {          // diagnostics: mean shader-clock deltas between the phase stamps over the workgroups, and the spread of start / end
-        RT_TRY(rt::stream_sync(Lc.stream));
-        const size_t nwg = (size_t)grid.x * grid.y * grid.z;
-        std::vector<unsigned long long> h(nwg * 8);
-        RT_TRY(hipMemcpy(h.data(), dbg, nwg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        double d[5] = {0, 0, 0, 0, 0};
-        unsigned long long t_first = ~0ull, t_last_start = 0, t_last_end = 0;
-        for (size_t w = 0; w < nwg; ++w) {
-            const unsigned long long* q = &h[w * 8];
-            const unsigned long long t1 = q[1] ? q[1] : q[0];
-            d[0] += (double)(t1 - q[0]); d[1] += (double)(q[2] - t1); d[2] += (double)(q[3] - q[2]); d[3] += (double)(q[4] - q[3]); d[4] += (double)(q[5] - q[4]);
-            if (q[0] < t_first) t_first = q[0];
-            if (q[0] > t_last_start) t_last_start = q[0];
-            if (q[5] > t_last_end) t_last_end = q[5];
-        }
-        fprintf(stderr, "S1TIMING %-12s %-24s wgs %5zu | issue %6.0f  loads+fma %6.0f  reduce %6.0f  lds+barrier %6.0f  store %6.0f | first start -> last start %6llu, -> last end %6llu cycles\n",
-                l.name, nm, nwg, d[0] / nwg, d[1] / nwg, d[2] / nwg, d[3] / nwg, d[4] / nwg, t_last_start - t_first, t_last_end - t_first);
-    }
-#endif
     return Lc.end();
 }
 
@@ -1081,10 +1002,10 @@ static int build_plan(ry_net* net, Plan& P) {
     }
     // buffers
     if (nd == 1) {
-        P.s1_os = g_s1_os != 0;
+        P.s1_os = true;                                   // the output-stationary kernels whenever every layer can take them (generic stride / dilation / GLU layers: the weight-streaming kernels)
         for (int i = 0; i < 16; ++i) if (!c1d_os_capable(net->layers[i]) || !net->layers[i].w1os) P.s1_os = false;
         // the pad of the convert wrapper inside the first layer: a stride-1 first layer whose input channels fit one lane set
-        P.s1_padfuse = P.s1_os && g_s1_padfuse && P.mode == 1 && c1d_mode(net->layers[0]) == RY_C1D_S1 && net->layers[0].cin() <= 64;
+        P.s1_padfuse = P.s1_os && P.mode == 1 && c1d_mode(net->layers[0]) == RY_C1D_S1 && net->layers[0].cin() <= 64;
     }
     for (int i = 0; i < 16; ++i) {
         const Layer& l = net->layers[i];
@@ -1094,7 +1015,6 @@ static int build_plan(ry_net* net, Plan& P) {
             const int mode = c1d_mode(l);
             lp.os_kt = c1d_os_ktw(l.cin());
             choose_os(l, B, mode == RY_C1D_DECONV ? lp.Wi : lp.Wo, &lp.os_cb, &lp.os_tp);
-            if (g_s1_force[i][0] > 0) { lp.os_cb = g_s1_force[i][0]; lp.os_tp = g_s1_force[i][1]; }
             if (l.cin_b > 0 && l.cin_a % 64 != 0) { lp.os_cb = 2; lp.os_tp = 4; }      // sources split inside a wave: the per-lane form exists for this slice only
             if (i < 15) RY_TRY(P.arena.alloc(&lp.out, out_elems));          // the last layer stores straight into the caller's block
         } else if (nd == 1) {
@@ -1124,9 +1044,7 @@ static int build_plan(ry_net* net, Plan& P) {
                 for (int src : {l.src_a, l.src_b}) {
                     if (src < 0) continue;
                     const LayerPlan& sp = P.lp[src];
-                    const bool dma_kernel = sp.path == PATH_IGEMM_BF16 ||
-                                            (sp.path == PATH_IGEMM && g_ldsdma && !g_timing && sp.tile != TILE_256x64 && sp.tile != TILE_256x128);
-                    if (sp.path != PATH_FIRST && !dma_kernel) want16 = false;       // that producer cannot write a bf16 copy
+                    if (sp.path != PATH_FIRST && sp.path != PATH_IGEMM && sp.path != PATH_IGEMM_BF16) want16 = false;   // that producer cannot write a bf16 copy
                 }
                 if (l.src_a < 0) want16 = false;
                 if (want16) {
@@ -1155,23 +1073,9 @@ static int build_plan(ry_net* net, Plan& P) {
         const bool x3 = net->dtype == 2;
         std::vector<char> need32(16, 0), need16(16, 0);
         need32[15] = 1;
-        {   // split-bf16 mode: the last layer (rolling form) reads the [hi | lo] copies when both producers can write them, so
-            // that neither keeps an fp32 copy for this layer alone (encoder c0: 50 MB less to write per 384-frame window)
-            LayerPlan& ll = P.lp[15];
-            const Layer& l15 = net->layers[15];
-            bool ok = x3 && g_x3_last && ll.path == PATH_LAST && l15.cin() == 128 && ll.Wi % 16 == 0 && l15.src_a >= 0 && l15.src_b >= 0;
-            for (int src : {l15.src_a, l15.src_b}) {
-                if (!ok || src < 0) continue;
-                const LayerPlan& sp = P.lp[src];
-                const bool dma_kernel = sp.path == PATH_IGEMM_BF16 ||
-                                        (sp.path == PATH_IGEMM && g_ldsdma && !g_timing && sp.tile != TILE_256x64 && sp.tile != TILE_256x128);
-                if (sp.path != PATH_FIRST && !dma_kernel) ok = false;
-            }
-            ll.last_x3 = ok;
-        }
         for (int i = 0; i < 16; ++i)
             for (int src : {net->layers[i].src_a, net->layers[i].src_b})
-                if (src >= 0) ((P.lp[i].path == PATH_IGEMM_BF16 || P.lp[i].last_x3) ? need16 : need32)[src] = 1;
+                if (src >= 0) (P.lp[i].path == PATH_IGEMM_BF16 ? need16 : need32)[src] = 1;
         for (int i = 0; i < 16; ++i) {
             LayerPlan& lp = P.lp[i];
             lp.w32 = need32[i] || lp.path == PATH_DIRECT || lp.path == PATH_LAST; lp.w16 = need16[i];
@@ -1215,16 +1119,15 @@ static RySrc1d src1d_of(const ry_net* net, const Plan& P, int idx) {
 }
 
 // enqueue the whole forward of a plan (wrapper kernels included when mode == 1)
-// part 0: the whole forward; 1: the wrapper pad and layers [0, net->split_at); 2: layers [net->split_at, 16) and the tail wrappers
-static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
+static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
     const ry_net_desc& d = net->desc;
-    const int lo = part == 2 ? net->split_at : 0, hi = part == 1 ? net->split_at : 16;
+    const int lo = 0, hi = 16;
     const int nd = d.ndim, B = P.B;
     const float slope = d.lrelu_slope;
     // the fused pad takes the column minimum inside the workgroups that reach the padding: one chain of n_frames / 8 load rounds, worth
     // it while the window is short (measured: 300 frames -3 us, 1000 frames +14 us against the separate ry_pad_min_rows node)
     const bool padfuse_now = nd == 1 && P.s1_padfuse && P.n_frames <= 512;
-    if (P.mode == 1 && !padfuse_now && part != 2) {
+    if (P.mode == 1 && !padfuse_now) {
         const int cols_in = nd == 1 ? d.in_ch : d.width + 1;
         const int cols_out = nd == 1 ? d.in_ch : d.width;
         // numpy.pad(mode='minimum') over time (+ log and the dropped last bin for stage 2): column minima and the padded
@@ -1295,7 +1198,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
         } else if (nd == 1) {
             RY_TRY(launch_conv1d(Lc, l, lp, B, src1d_of(net, P, l.src_a), src1d_of(net, P, l.src_b), slope));
         } else {
-            const bool in16 = lp.path == PATH_IGEMM_BF16 || lp.last_x3;       // bf16 consumers read the producers' bf16 copies
+            const bool in16 = lp.path == PATH_IGEMM_BF16;                     // bf16 consumers read the producers' bf16 copies
             const float* s1 = l.src_a < 0 ? (P.mode == 1 ? P.x_in : P.cur_in)
                                           : in16 ? reinterpret_cast<const float*>(P.lp[l.src_a].out16) : P.lp[l.src_a].out;
             const float* s2 = l.src_b < 0 ? nullptr : in16 ? reinterpret_cast<const float*>(P.lp[l.src_b].out16) : P.lp[l.src_b].out;
@@ -1306,7 +1209,6 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc, int part = 0) {
             RY_TRY(launch_conv2d(Lc, l, lq, B, s1, l.cin_a, s2, l.cin_b, slope));
         }
     }
-    if (part == 1) return RY_OK;
     if (nd == 1 && P.s1_os) {
         // nothing left to do: decoder c7 wrote the cropped, dense result
     } else if (nd == 1) {
@@ -1349,7 +1251,6 @@ static int autotune_plan(ry_net* net, Plan& P) {
     for (int i = 0; i < 16 && rc == RY_OK; ++i) {
         LayerPlan& lp = P.lp[i];
         if (lp.path != PATH_IGEMM && lp.path != PATH_IGEMM_BF16) continue;
-        if (lp.path == PATH_IGEMM && (!g_ldsdma || g_timing)) continue;        // the register-staged A/B kernel is not tuned
         if (g_force[i][0] || g_force[i][1] || g_force[i][2]) continue;         // RY_PLAN fixes this layer
         const Layer& l = net->layers[i];
         if (l.src_a < 0) continue;
@@ -1370,7 +1271,7 @@ static int autotune_plan(ry_net* net, Plan& P) {
         else tiles = {TILE_128x128, TILE_96x128, TILE_64x128};
         static const int split_list[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32, 48, 64, 96, 128};
         for (int tile : tiles)
-            for (int kg = 1; kg <= ((g_kgroups && M > 64 && nk >= 16) ? 2 : 1); ++kg)
+            for (int kg = 1; kg <= ((M > 64 && nk >= 16) ? 2 : 1); ++kg)
                 for (int sp : split_list) {
                     if (sp * kg > nk || sp > (M <= 64 ? 128 : 32)) continue;
                     int bm, bn; tile_dims(tile, &bm, &bn);
@@ -1456,10 +1357,9 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
             for (size_t i = 1; i < P.gslots.size(); ++i) if (P.gslots[i].used < P.gslots[lru].used) lru = i;
             RT_TRY(rt::stream_sync(net->stream));
             if (P.gslots[lru].gexec) hipGraphExecDestroy(P.gslots[lru].gexec);
-            if (P.gslots[lru].gexec2) hipGraphExecDestroy(P.gslots[lru].gexec2);
             P.gslots.erase(P.gslots.begin() + (long)lru);
         }
-        P.gslots.push_back(Plan::GraphSlot{want_in, want_out, nullptr, nullptr, false, -1, -1, 0});
+        P.gslots.push_back(Plan::GraphSlot{want_in, want_out, nullptr, false, -1, -1, 0});
         G = &P.gslots.back();
     }
     G->used = ++P.gclock;
@@ -1470,15 +1370,13 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
     if (G->gexec && G->graph_n != shape && G->last_n == shape) {
         RT_TRY(rt::stream_sync(net->stream));             // the exec being replaced may still be running
         hipGraphExecDestroy(G->gexec); G->gexec = nullptr; G->tried = false;
-        if (G->gexec2) { hipGraphExecDestroy(G->gexec2); G->gexec2 = nullptr; }
     }
     const bool capture_now = net->use_graph && !G->tried && (P.mode == 0 || G->last_n == shape || G->last_n < 0);
     G->last_n = shape;
-    const bool split = net->split_at > 0 && net->split_at < 16;
-    auto capture = [&](int part, hipGraphExec_t* ex) -> int {
+    auto capture = [&](hipGraphExec_t* ex) -> int {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(net->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            int r = enqueue_forward(net, P, Lc, part);
+            int r = enqueue_forward(net, P, Lc);
             hipError_t e = hipStreamEndCapture(net->stream, &graph);
             if (r == RY_OK && e == hipSuccess && graph) {
                 if (hipGraphInstantiate(ex, graph, nullptr, nullptr, 0) != hipSuccess) *ex = nullptr;
@@ -1492,28 +1390,14 @@ static int run_plan(ry_net* net, Plan& P, const float* x, float* y, int on_devic
     if (capture_now) {
         G->tried = true;
         G->graph_n = shape;
-        RY_TRY(capture(split ? 1 : 0, &G->gexec));
-        if (split && G->gexec) {
-            RY_TRY(capture(2, &G->gexec2));
-            if (!G->gexec2) { hipGraphExecDestroy(G->gexec); G->gexec = nullptr; }
-        }
+        RY_TRY(capture(&G->gexec));
     }
     if (G->gexec && G->graph_n == shape) {
         RT_TRY(hipGraphLaunch(G->gexec, net->stream));
-        if (split) {
-            RT_TRY(rt::event_record(net->mid, net->stream)); net->mid_recorded = true;
-            RT_TRY(hipGraphLaunch(G->gexec2, net->stream));
-        }
     } else
 #endif
     {
-        if (net->split_at > 0 && net->split_at < 16) {
-            RY_TRY(enqueue_forward(net, P, Lc, 1));
-            RT_TRY(rt::event_record(net->mid, net->stream)); net->mid_recorded = true;
-            RY_TRY(enqueue_forward(net, P, Lc, 2));
-        } else {
-            RY_TRY(enqueue_forward(net, P, Lc));
-        }
+        RY_TRY(enqueue_forward(net, P, Lc));
     }
     if (!on_device) {
         RT_TRY(rt::d2h(y, P.user_out, out_bytes, net->stream));
@@ -1543,7 +1427,7 @@ static int read_plan_env() {
     if (const char* e = getenv("RY_PLAN")) {
         for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
             int i = -1, t = 0, sp = 0, kg = 0;
-            if (sscanf(q, "%d:%d:%d:%d", &i, &t, &sp, &kg) >= 2 && i >= 0 && i < 16 && t >= 0 && t <= TILE_256x128 && sp >= 0 && kg >= 0 && kg <= 2) {
+            if (sscanf(q, "%d:%d:%d:%d", &i, &t, &sp, &kg) >= 2 && i >= 0 && i < 16 && t >= 0 && t <= TILE_96x128 && t != 2 && sp >= 0 && kg >= 0 && kg <= 2) {
                 g_force[i][0] = t; g_force[i][1] = sp; g_force[i][2] = kg;
             } else {
                 return fail(RY_EINVAL, "RY_PLAN: expected layer:tile:splits:kgroups[,...]");
@@ -1554,49 +1438,16 @@ static int read_plan_env() {
 }
 
 static int read_env_switches() {
-    if (const char* e = getenv("RY_ILV")) g_ilv = atoi(e);
-    if (const char* e = getenv("RY_TIMING")) g_timing = atoi(e);
-    if (const char* e = getenv("RY_LDSDMA")) g_ldsdma = atoi(e);
-    if (const char* e = getenv("RY_KGROUPS")) g_kgroups = atoi(e);
-    if (const char* e = getenv("RY_PATCH")) g_patch = atoi(e);
+    g_autotune = 0; g_autotune_reps = 3; g_autotune_max = 0; g_autotune_pick = -1;      // (re-read by ry_debug_plan_igemm: an absent variable means the defaults)
+    if (const char* e = getenv("RY_AUTOTUNE")) {                                        // "1[:reps[:max[:pick]]]"
+        int on = 0, reps = 3, mx = 0, pick = -1;
+        if (sscanf(e, "%d:%d:%d:%d", &on, &reps, &mx, &pick) < 1) return fail(RY_EINVAL, "RY_AUTOTUNE: expected 1[:reps[:max[:pick]]]");
+        g_autotune = on; g_autotune_reps = reps > 0 ? reps : 1; g_autotune_max = mx; g_autotune_pick = pick;
+    }
+    g_x3_min_m = 128; g_s2_crop = 2; g_igemm_dbg = 0;
     if (const char* e = getenv("RY_X3_MINM")) g_x3_min_m = atoi(e);
-    if (const char* e = getenv("RY_X3_LAST")) g_x3_last = atoi(e);
-    g_autotune = 0; g_autotune_reps = 3; g_autotune_max = 0;      // (re-read by ry_debug_plan_igemm: absent variables mean the defaults)
-    if (const char* e = getenv("RY_AUTOTUNE")) g_autotune = atoi(e);
-    if (const char* e = getenv("RY_AUTOTUNE_REPS")) g_autotune_reps = atoi(e) > 0 ? atoi(e) : 1;
-    if (const char* e = getenv("RY_AUTOTUNE_MAX")) g_autotune_max = atoi(e);
-    g_autotune_pick = -1;
-    if (const char* e = getenv("RY_AUTOTUNE_PICK")) g_autotune_pick = atoi(e);
-    if (const char* e = getenv("RY_PLAN_X3_PEAK")) g_x3_peak = atof(e) * 1e6;
-    if (const char* e = getenv("RY_PLAN_X3_KG2")) g_x3_kg2 = atof(e);
-    if (const char* e = getenv("RY_XCD_GROUPS")) g_xcd_groups = atoi(e);
-    if (const char* e = getenv("RY_LAST_BAND")) g_last_band = atoi(e);
     if (const char* e = getenv("RY_S2_CROP")) g_s2_crop = atoi(e);
-    if (const char* e = getenv("RY_VC_STAGGER")) g_vc_stagger = atoi(e);
-    if (const char* e = getenv("RY_S1_OS")) g_s1_os = atoi(e);
-    if (const char* e = getenv("RY_S1_PADFUSE")) g_s1_padfuse = atoi(e);
-    if (const char* e = getenv("RY_S1_TIMING")) g_s1_timing = atoi(e);
-    if (const char* e = getenv("RY_S1_UNITS")) g_s1_units = atoi(e) > 0 ? atoi(e) : 1;
-    memset(g_s1_force, 0, sizeof(g_s1_force));
-    if (const char* e = getenv("RY_S1_CFG")) {
-        for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
-            int i = -1, cb = 0, tp = 0;
-            if (sscanf(q, "%d:%d:%d", &i, &cb, &tp) == 3 && i >= 0 && i < 16 && (cb == 2 || cb == 4) && (tp == 4 || tp == 8)) { g_s1_force[i][0] = cb; g_s1_force[i][1] = tp; }
-            else return fail(RY_EINVAL, "RY_S1_CFG: expected layer:cb:tp[,...] with cb in {2,4}, tp in {4,8}");
-        }
-    }
-    if (const char* e = getenv("RY_S1_WGS")) g_s1_wgs = atoi(e);
-    if (const char* e = getenv("RY_S1_MAXS")) g_s1_maxs = atoi(e);
     if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);
-    if (const char* e = getenv("RY_TILE2D")) g_tile2d = atoi(e);
-    if (const char* e = getenv("RY_BIGTILE")) g_bigtile = atoi(e);
-#ifndef RY_HOST_EMU
-    if (g_timing && !g_dbg) {
-        RT_TRY(hipMalloc((void**)&g_dbg, 8 * sizeof(unsigned long long)));
-        RT_TRY(hipMemset(g_dbg, 0, 8 * sizeof(unsigned long long)));
-    }
-#endif
-    if (const char* e = getenv("RY_TILE64")) g_tile64 = atoi(e) == 256 ? TILE_256x64 : TILE_128x64;
     return read_plan_env();
 }
 
@@ -1691,13 +1542,7 @@ int ry_net_create(ry_ctx* ctx, const ry_net_desc* desc, const float* weights, si
     if (const char* e = getenv("RY_GRAPH")) net->use_graph = atoi(e) != 0;
     RT_TRY(rt::stream_create(&net->stream));
     RT_TRY(rt::event_create_fast(&net->done));
-    RT_TRY(rt::event_create_fast(&net->mid));
     net->has_done = true;
-    // RY_S2_SPLIT=5 (off by default): stage 2 as two graphs cut after encoder c4 with an event between them, so that stage 1 of the next
-    // window can be held back (RY_VC_STAGGER) until the six weight-streaming layers at the bottom of the U-Net run.  Measured on one box,
-    // interleaved: 1.3477 ms per step with the cut and the stagger, 1.3477 without either, 1.3544 with the cut alone (the second graph
-    // launch costs ~5 us and the stagger only wins it back): the ~30 us a step takes beyond stage 2 alone is not stage-1 interference.
-    if (desc->ndim == 2) { net->split_at = 0; if (const char* e = getenv("RY_S2_SPLIT")) net->split_at = atoi(e); }
     size_t off = 0;
     for (Layer& l : net->layers) {
         const size_t nw = (size_t)l.cin() * l.cout * ipow((size_t)l.k, desc->ndim);
@@ -1720,12 +1565,11 @@ int ry_net_clone(ry_net* src, ry_net** out) {
     ry_ctx* ctx = src->ctx;
     RT_TRY(rt::set_device(ctx->device));
     std::unique_ptr<ry_net> net(new ry_net());
-    net->ctx = ctx; net->desc = src->desc; net->dtype = src->dtype; net->use_graph = src->use_graph; net->split_at = src->split_at;
+    net->ctx = ctx; net->desc = src->desc; net->dtype = src->dtype; net->use_graph = src->use_graph;
     net->layers = src->layers;                       // device pointers into the shared arena
     net->weights = src->weights;
     RT_TRY(rt::stream_create(&net->stream));
     RT_TRY(rt::event_create_fast(&net->done));
-    RT_TRY(rt::event_create_fast(&net->mid));
     net->has_done = true;
     ctx->nets.push_back(net.get());
     *out = net.release();
@@ -1741,7 +1585,7 @@ void ry_net_destroy(ry_net* net) {
     for (size_t i = 0; i < v.size(); ++i)
         if (v[i] == net) { v.erase(v.begin() + i); break; }
     net->plans.clear();
-    if (net->has_done) { rt::event_destroy(net->done); rt::event_destroy(net->mid); }
+    if (net->has_done) rt::event_destroy(net->done);
     rt::stream_destroy(net->stream);
     delete net;
 }
@@ -1809,7 +1653,6 @@ int ry_net_set_dtype(ry_net* net, int dtype) {
     RY_TRY(read_plan_env());
     if (dtype == 2) {
         if (const char* e = getenv("RY_X3_MINM")) g_x3_min_m = atoi(e);      // read again here so that a test / sweep can move it per call
-        if (const char* e = getenv("RY_X3_LAST")) g_x3_last = atoi(e);
         for (Layer& l : net->layers) {
             if (!l.wig || l.wigx3 || l.cin_a % 64 != 0 || l.cin_b % 64 != 0) continue;
             const TapTable t = make_taps(l);
@@ -1984,9 +1827,6 @@ struct ry_vc {
     // window's one-round grids and its weight-streaming bottom layers are filled by the other windows' kernels.
     int disc_front = 0, disc_back = 0;   // ry_vc_set_discard: frames of every window the caller throws away (stage 2 does not compute them)
     int lanes = 1;
-    int stagger_at = 0;      // > 0 with several lanes: every stage-2 forward runs as two graphs cut before layer `stagger_at`, and the forward of the
-                             // next window (other lane) starts when this one reaches the cut: the two windows in flight are always in different halves
-    ry_net* last_s2 = nullptr;
     ry_net* l1[MAX_LANES] = {nullptr, nullptr, nullptr};
     ry_net* l2[MAX_LANES] = {nullptr, nullptr, nullptr};
     // a clone follows the arithmetic mode of the handle it was made from (ry_net_set_dtype on the caller's handle converts the filters
@@ -2087,22 +1927,9 @@ static int vc_enqueue_mid(ry_vc* vc, ry_net* s1, const float* y1, const int* row
     return RY_OK;
 }
 
-// stage 2 of one window on its lane; with several lanes and a cut (ry_vc::stagger_at) it starts when the previous window's forward,
-// on another lane, has reached the cut
+// stage 2 of one window on its lane
 static int vc_run_stage2(ry_vc* vc, ry_net* s2, const float* sp_in, float* sp_out, int n_frames) {
-    if (vc->lanes > 1 && vc->stagger_at > 0 && vc->last_s2 && vc->last_s2 != s2 && vc->last_s2->mid_recorded)
-        RT_TRY(rt::stream_wait_event(s2->stream, vc->last_s2->mid));
-    RY_TRY(ry_sr_convert_rows(s2, sp_in, sp_out, 1, n_frames, vc->disc_front, vc->disc_back, 1));
-    vc->last_s2 = s2;
-    return RY_OK;
-}
-
-// Stage 1 of a window is timed to start when the PREVIOUS window's stage 2 has finished its large encoder layers (ry_net::mid):
-// it then runs under the six weight-streaming layers at the bottom of the U-Net, which leave most of the chip idle, instead of
-// taking workgroup slots from the one-round grids of the MFMA-bound layers.
-static int vc_stagger(ry_net* s1, ry_net* s2) {
-    if (g_vc_stagger && s2->mid_recorded) RT_TRY(rt::stream_wait_event(s1->stream, s2->mid));
-    return RY_OK;
+    return ry_sr_convert_rows(s2, sp_in, sp_out, 1, n_frames, vc->disc_front, vc->disc_back, 1);
 }
 
 static int vc_check(const ry_vc* vc, const int* row_of, int n_eff, int n_frames, bool host_rows) {
@@ -2190,12 +2017,6 @@ int ry_vc_set_lanes(ry_vc* vc, int lanes) {
         vc->l1[vc->lanes] = a; vc->l2[vc->lanes] = b;
         ++vc->lanes;
     }
-    vc->stagger_at = 0;
-    if (const char* e = getenv("RY_VC_STAGGER_AT")) vc->stagger_at = atoi(e);
-    if (vc->stagger_at < 1 || vc->stagger_at > 15 || vc->lanes < 2) vc->stagger_at = 0;
-    for (int k = 0; k < vc->lanes; ++k)
-        if (vc->l2[k]->split_at != vc->stagger_at) { vc->l2[k]->split_at = vc->stagger_at; vc->l2[k]->plans.clear(); vc->l2[k]->mid_recorded = false; }
-    vc->last_s2 = nullptr;
     return RY_OK;
 }
 
@@ -2217,7 +2038,6 @@ int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, in
         memcpy(sl.h_row, row_of, (size_t)n_eff * sizeof(int));
         RT_TRY(rt::h2d(sl.d_x, sl.h_x, (size_t)n_eff * cin * sizeof(float), st1));
         RT_TRY(rt::h2d(sl.d_row, sl.h_row, (size_t)n_eff * sizeof(int), st1));
-        RY_TRY(vc_stagger(s1, s2));
         RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1));                       // stage-1 CNN on the effective frames
     }
     RY_TRY(vc_enqueue_mid(vc, s1, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp));
@@ -2358,7 +2178,7 @@ int ry_vc_submit_wave(ry_vc* vc, const float* wave, int n_samples, int hop, int 
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
     int n_eff = 0;
     RY_TRY(vc_gate_into_slot(vc, s1, sl, wave, n_samples, hop, fft_length, p_effective, p_all, feat, n_frames, &n_eff));
-    if (n_eff > 0) { RY_TRY(vc_stagger(s1, s2)); RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1)); }
+    if (n_eff > 0) RY_TRY(ry_ac_convert(s1, sl.d_x, sl.d_y1, 1, n_eff, 1));
     RY_TRY(vc_enqueue_mid(vc, s1, sl.d_y1, sl.d_row, n_eff, n_frames, sp_floor, sl.d_mc, sl.d_sp));
     RT_TRY(rt::d2h(sl.h_mc, sl.d_mc, (size_t)n_frames * M * sizeof(float), st1));
     RT_TRY(rt::event_record(sl.ev_mid, st1));
@@ -2399,7 +2219,7 @@ int ry_vc_enqueue_device(ry_vc* vc, const float* x_eff_dev, const int* row_of_de
     ++vc->dev_count;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
     if (sl.used) RT_TRY(rt::stream_wait_event(st1, sl.ev_done));                        // the slot's previous window has left d_sp
-    if (n_eff > 0) { RY_TRY(vc_stagger(s1, s2)); RY_TRY(ry_ac_convert(s1, x_eff_dev, sl.d_y1, 1, n_eff, 1)); }
+    if (n_eff > 0) RY_TRY(ry_ac_convert(s1, x_eff_dev, sl.d_y1, 1, n_eff, 1));
     RY_TRY(vc_enqueue_mid(vc, s1, sl.d_y1, row_of_dev, n_eff, n_frames, sp_floor, mc_out_dev, sl.d_sp));
     RT_TRY(rt::event_record(sl.ev_mid, st1));
     RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));
@@ -2835,20 +2655,6 @@ int ry_debug_plan_igemm_bf16(int mode, int M, int Cout, int nphases, int nk, int
     return RY_OK;
 }
 
-// diagnostics: read and reset the phase totals of the RY_TIMING=1 kernel variant (8 counters)
-int ry_debug_igemm_phases(ry_ctx* ctx, unsigned long long* out8) {
-    if (!ctx || !out8) return fail(RY_EINVAL, "null argument");
-    for (int i = 0; i < 8; ++i) out8[i] = 0;
-#ifndef RY_HOST_EMU
-    if (g_dbg) {
-        RT_TRY(hipDeviceSynchronize());
-        RT_TRY(hipMemcpy(out8, g_dbg, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        RT_TRY(hipMemset(g_dbg, 0, 8 * sizeof(unsigned long long)));
-    }
-#endif
-    return RY_OK;
-}
-
 // ---- single operators -------------------------------------------------------------------------
 int ry_conv1d(ry_ctx* ctx, const float* x, int B, int L, int Cin, const float* W, const float* bias, const float* bn,
               int Cout, int k, int stride, int pad, int dilate, int transposed, int act, int splits, float* y) {
@@ -2941,10 +2747,9 @@ int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin
         lp.any_m_patch = true;
         tile &= 15;
         lp.tile = tile; lp.splits = splits;
-        if (tile < 0 || tile > TILE_256x128) return fail(RY_EINVAL, "unknown tile");
-        if ((tile == TILE_256x64 || tile == TILE_128x64) ? Cout % 64 : (tile != 0 && Cout % 128)) return fail(RY_EINVAL, "tile does not divide Cout");
+        if (tile < 0 || tile > TILE_96x128 || tile == 2) return fail(RY_EINVAL, "unknown tile");
+        if (tile == TILE_128x64 ? Cout % 64 : (tile != 0 && Cout % 128)) return fail(RY_EINVAL, "tile does not divide Cout");
         const bool op16 = lp.path == PATH_IGEMM_BF16;
-        if (op16 && (tile == TILE_256x64 || tile == TILE_256x128)) return fail(RY_EINVAL, "no bf16 instantiation of that tile");
         choose_igemm(l, M, t.nphases, t.ntaps * (lp.x3 ? 3 * Cin / 64 : Cin / (op16 ? 64 : 32)), &lp.tile, &lp.splits, &lp.kg, lp.x3 ? 2 : (op16 ? 1 : 0));
         if (lp.x3) {
             std::vector<float> w32;

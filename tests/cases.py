@@ -29,9 +29,9 @@ CONV2D_CASES = [
     (1, 12, 16, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '32x128', 0),
     (1, 12, 16, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '64x128', 2),
     (2, 16, 16, 64, 128, 4, 2, 1, False, 'lrelu', 'igemm', '128x128', 1),
-    (1, 16, 36, 32, 64, 4, 2, 1, False, 'relu', 'igemm', '256x64', 3),
+    (1, 16, 36, 32, 64, 4, 2, 1, False, 'relu', 'igemm', '128x64', 3),
     (1, 3, 4, 64, 128, 4, 2, 1, True, 'relu', 'igemm', '32x128', 0),   # M = 12 rows: ragged tile
-    (1, 6, 10, 32, 64, 4, 2, 1, True, 'relu', 'igemm', '256x64', 2),
+    (1, 6, 10, 32, 64, 4, 2, 1, True, 'relu', 'igemm', '128x64', 2),
     (1, 5, 7, 64, 128, 3, 1, 1, False, None, 'igemm', '64x128', 0),
     (1, 5, 7, 32, 128, 1, 1, 0, False, 'relu', 'igemm', '32x128', 1),
     (1, 2, 4, 64, 128, 4, 2, 1, False, 'lrelu', 'igemm', None, 0),     # deepest encoder layer, auto tile/split
@@ -42,7 +42,7 @@ CONV2D_CASES = [
     (2, 5, 32, 128, 1, 3, 1, 1, False, None, 'last', None, 0),         # rolling-window form (W % 16 == 0, 128 channels)
     (1, 3, 16, 128, 1, 3, 1, 1, False, None, 'last', None, 0),
     (1, 16, 20, 32, 64, 4, 2, 1, False, 'relu', 'igemm', '128x64', 2),
-    (1, 32, 64, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '256x128', 1),  # 512 rows: 2 tiles of 256 (4 waves of 128x64), 2-D 16x16 tiles
+    (1, 32, 64, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '64x128', 1),   # 512 rows: 8 tiles of 64, 2-D 4x16 pixel tiles
     (1, 32, 64, 32, 128, 4, 2, 1, False, 'lrelu', 'igemm', '128x128', 1),  # 16x32 outputs: 2-D 8x16 pixel tiles
     (2, 8, 16, 32, 128, 4, 2, 1, True, 'relu', 'igemm', '64x128', 1),      # deconv, batch 2, 2-D 4x16 tiles over the input grid
     (1, 24, 32, 32, 128, 4, 2, 1, False, 'relu', 'igemm', '96x128', 2),    # 12x16 outputs: 2-D 6x16 tiles, split-K

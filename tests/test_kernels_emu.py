@@ -170,11 +170,6 @@ def test_stage2_x3_pipeline_emu(emu_ctx, monkeypatch):
     monkeypatch.setenv('RY_X3_MINM', '1')             # every implicit-GEMM layer on the split path (mixed-format copies gone)
     net.set_dtype('bf16x3')
     assert rel_max(net.forward(x), ref) < 2e-5
-    monkeypatch.setenv('RY_X3_LAST', '1')             # the last layer on the producers' [hi | lo] copies (opt-in A/B switch)
-    net.set_dtype('bf16x3')
-    assert rel_max(net.forward(x), ref) < 2e-5
-    assert [q['name'] for q in net.profile(1, 16, 1) if q['layer'] == 'decoder/c7'] == ['ry_sr_last<true>']
-    monkeypatch.setenv('RY_X3_LAST', '0')
     net.set_dtype('f32')
     assert numpy.array_equal(net.forward(x), y32)     # the exact path comes back bit for bit
     # the SuperResolution.convert wrapper (pad 'minimum' / log / drop bin ... exp / edge / crop fused around the predictor) in both modes
@@ -244,7 +239,7 @@ def test_stage2_discarded_frames_are_not_computed_emu(emu_ctx, discard):
 
 def test_autotuned_plans_stay_correct_emu(emu_ctx, monkeypatch):
     """RY_AUTOTUNE=1 (opt-in): candidate launch plans of every implicit-GEMM layer are run on the device when a plan is built and
-    the fastest replaces the planner's pick.  The emulator has no clock, so RY_AUTOTUNE_PICK forces a non-default candidate per
+    the fastest replaces the planner's pick.  The emulator has no clock, so the `pick` field of RY_AUTOTUNE forces a non-default candidate per
     layer (another tile / K-group / split-K combination, slabs re-allocated): results must not move beyond summation order,
     in the exact fp32 mode and in the split-bf16 mode."""
     import ctypes
@@ -260,9 +255,8 @@ def test_autotuned_plans_stay_correct_emu(emu_ctx, monkeypatch):
         net.set_dtype(mode)
         base[mode] = [(q['layer'], q['name'], q['grid']) for q in net.profile(1, 8, 1)]
     try:
-        monkeypatch.setenv('RY_AUTOTUNE', '1'); monkeypatch.setenv('RY_AUTOTUNE_REPS', '1'); monkeypatch.setenv('RY_AUTOTUNE_MAX', '3')
         for pick in (0, 2):
-            monkeypatch.setenv('RY_AUTOTUNE_PICK', str(pick)); reread()
+            monkeypatch.setenv('RY_AUTOTUNE', '1:1:3:%d' % pick); reread()                # on : 1 timed round : 3 candidates : take candidate `pick`
             for mode in (('f32',) if pick == 0 else ('f32', 'bf16x3')):
                 net.set_dtype(mode)
                 if pick != 0 and mode == 'f32':                         # candidate 0 is the planner's pick (covered by every other test); the split-bf16
@@ -270,8 +264,7 @@ def test_autotuned_plans_stay_correct_emu(emu_ctx, monkeypatch):
                 plan = [(q['layer'], q['name'], q['grid']) for q in net.profile(1, 8, 1)]
                 assert (plan == base[mode]) == (pick == 0), (pick, mode, plan)      # candidate 0 is the planner's pick
     finally:
-        for k in ('RY_AUTOTUNE', 'RY_AUTOTUNE_REPS', 'RY_AUTOTUNE_MAX', 'RY_AUTOTUNE_PICK'):
-            monkeypatch.delenv(k, raising=False)
+        monkeypatch.delenv('RY_AUTOTUNE', raising=False)
         reread()                                                       # the session-wide context goes back to the defaults
     net.set_dtype('f32')
     net.close()
