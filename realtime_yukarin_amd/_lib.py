@@ -27,9 +27,21 @@ TILES.update({k + 'k1': v + 32 for k, v in list(TILES.items()) if isinstance(k, 
 # The window call runs up to two windows side by side on their own pairs of HIP streams (ry_vc_set_lanes): the streams only overlap when
 # each has a hardware queue of its own.  ROCm hands out 4 by default and folds further streams onto them (measured on MI355X: with a
 # second runtime user in the process two lanes then gain nothing, 1.29 ms per window; with 16 every pair of streams overlaps
-# (scripts/gpu_r2_queues.py) and two lanes run at 1.16 ms).  Read when the HIP runtime
-# starts, so it is set here, at import, unless the caller chose a value.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+# (scripts/gpu_queues.py) and two lanes run at 1.16 ms).  Read when the HIP runtime starts, so it is set here, at import, unless the
+# caller chose a value.  This is a side effect on `os.environ` of the importing process: other users of the HIP
+# runtime in the process (torch, RCCL) and child processes see it too -- and it comes too late if the runtime is already up.
+if 'GPU_MAX_HW_QUEUES' not in os.environ:
+    import sys as _sys
+    _t = _sys.modules.get('torch')
+    try:
+        _late = _t is not None and _t.cuda.is_initialized()
+    except Exception:
+        _late = False
+    if _late:
+        import warnings
+        warnings.warn('realtime_yukarin_amd: the HIP runtime of this process started before GPU_MAX_HW_QUEUES=16 could be set; the two window '
+                      'lanes may share hardware queues and serialise (set GPU_MAX_HW_QUEUES=16 in the environment, or import this package first)')
+    os.environ['GPU_MAX_HW_QUEUES'] = '16'
 
 ABI_SYMBOLS = (
     'ry_init', 'ry_shutdown', 'ry_sync', 'ry_stream', 'ry_device_count', 'ry_last_error',

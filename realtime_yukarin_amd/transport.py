@@ -24,10 +24,12 @@ import os
 import pickle
 import queue
 import struct
+import threading
 import time
 from multiprocessing import get_context, resource_tracker, shared_memory
 
 ALIGN = 64
+_ATTACH_LOCK = threading.Lock()
 _HEAD = struct.Struct('<QI')      # in-band length, number of out-of-band buffers
 _LEN = struct.Struct('<Q')
 
@@ -46,12 +48,13 @@ def _attach(name: str) -> shared_memory.SharedMemory:
         return shared_memory.SharedMemory(name=name, track=False)            # Python >= 3.13
     except TypeError:
         pass
-    real = resource_tracker.register
-    resource_tracker.register = lambda *a, **k: None
-    try:
-        return shared_memory.SharedMemory(name=name)
-    finally:
-        resource_tracker.register = real
+    with _ATTACH_LOCK:                                    # the patch is process-global: one attaching thread at a time
+        real = resource_tracker.register
+        resource_tracker.register = lambda *a, **k: None
+        try:
+            return shared_memory.SharedMemory(name=name)
+        finally:
+            resource_tracker.register = real
 
 
 class FeatureQueue(object):
