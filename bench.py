@@ -64,8 +64,9 @@ def parse(argv=None):
 def source_hash():
     """Identifies the kernel build a PMC summary belongs to (profiles/*pmc_summary.txt carry it in their header)."""
     h = hashlib.sha1()
-    for f in ('ry_kernels.h', 'ry_net.cpp', 'ry_dev.h'):
-        h.update((ROOT / 'realtime_yukarin_amd' / 'csrc' / f).read_bytes())
+    for f in sorted((ROOT / 'realtime_yukarin_amd' / 'csrc').glob('ry_*')):          # every unit and header of libry355.so
+        if f.suffix in ('.cpp', '.h'):
+            h.update(f.read_bytes())
     return h.hexdigest()[:12]
 
 

@@ -10,7 +10,8 @@ CSRC = PKG / 'csrc'
 LIB = PKG / 'libry355.so'
 EMU_DIR = ROOT / 'tests' / 'emu'
 EMU_LIB = EMU_DIR / 'libry355_emu.so'
-SOURCES = [CSRC / 'ry_net.cpp', CSRC / 'ry_kernels.h', CSRC / 'ry_dev.h', ROOT / 'include' / 'ry355.h']
+UNITS = [CSRC / 'ry_net.cpp', CSRC / 'ry_vc.cpp', CSRC / 'ry_comm.cpp']          # translation units of libry355.so
+SOURCES = UNITS + [CSRC / 'ry_kernels.h', CSRC / 'ry_vc_kernels.h', CSRC / 'ry_host.h', CSRC / 'ry_dev.h', ROOT / 'include' / 'ry355.h']
 
 
 def _stale(target: Path, deps) -> bool:
@@ -31,7 +32,7 @@ def build_product(force: bool = False) -> Path:
     """hipcc --offload-arch=gfx950 -> realtime_yukarin_amd/libry355.so (cross-compiles without a GPU)."""
     if force or _stale(LIB, SOURCES):
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value',
-               '-x', 'hip', str(CSRC / 'ry_net.cpp'), '-o', str(LIB)]
+               '-x', 'hip'] + [str(u) for u in UNITS] + ['-o', str(LIB)]
         subprocess.run(cmd, check=True, cwd=str(ROOT))
     return LIB
 
@@ -44,7 +45,7 @@ def build_emu(force: bool = False) -> Path:
         if not Path(cxx).exists():
             cxx = shutil.which('clang++') or shutil.which('g++')
         cmd = [cxx, '-x', 'c++', '-DRY_HOST_EMU', '-O2', '-std=c++17', '-shared', '-fPIC', '-pthread', '-Wno-psabi',
-               '-I' + str(EMU_DIR), '-I' + str(CSRC), str(CSRC / 'ry_net.cpp'), str(EMU_DIR / 'ry_emu.cpp'), '-o', str(EMU_LIB)]
+               '-I' + str(EMU_DIR), '-I' + str(CSRC)] + [str(u) for u in UNITS] + [str(EMU_DIR / 'ry_emu.cpp'), '-o', str(EMU_LIB)]
         subprocess.run(cmd, check=True, cwd=str(ROOT))
     return EMU_LIB
 

@@ -1,0 +1,23 @@
+"""Worker-side hooks of tests/test_dispatch.py, in a module of their own: a spawned worker process imports the module its hook lives in,
+and this one pulls in neither torch nor the oracle (seconds per worker)."""
+import time
+
+from realtime_yukarin_amd import engine
+
+
+def emu_hook(rank):
+    """Runs inside every worker process (tests only): the lazily created context becomes the emulator build, and worker 0 is slow."""
+    from realtime_yukarin_amd import _lib, build
+    ctx = engine.Context(0, _lib.Ry355Lib(build.build_emu()))
+    engine.get_context = lambda device=0, lib=None: ctx
+
+    def per_window(index):
+        if rank == 0:
+            time.sleep(0.25)
+    return per_window
+
+
+def dying_hook(rank):
+    emu_hook(rank)
+    if rank == 1:
+        raise RuntimeError('worker %d cannot see its GPU' % rank)

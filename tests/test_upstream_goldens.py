@@ -153,11 +153,11 @@ def test_generator_and_consumer_dry_run_emu(tmp_path, emu_ctx, monkeypatch):
     """generator (--provider shim, emulator) -> manifest + npz -> the consumer's oracle leg and shim leg: the plumbing works end to end."""
     monkeypatch.setattr(engine, 'get_context', lambda device=0, lib=None: emu_ctx)
     gen = load_generator()
-    monkeypatch.setitem(gen.CASES, 'SYN-8', [60, 128])
+    monkeypatch.setitem(gen.CASES, 'SYN-8', [40])
     out = tmp_path / 'dry'
     m = gen.main(['--provider', 'shim', '--out', str(out), '--models', 'SYN-8', '--gpu', '0'])
-    assert m['provider'].startswith('shim') and (out / 'MANIFEST.json').exists() and len(m['cases']) == 2 + 2 + 2
+    assert m['provider'].startswith('shim') and (out / 'MANIFEST.json').exists() and len(m['cases']) == 2 + 2 + 1
     m = manifest_of(out, allow_dry_run=True)
-    assert check_oracle(out, m, ['SYN-8']) == 2
+    assert check_oracle(out, m, ['SYN-8']) == 1
     (tmp_path / 'models').mkdir()
-    assert check_shims(out, m, ['SYN-8'], tmp_path / 'models', tol=1e-5) == 2
+    assert check_shims(out, m, ['SYN-8'], tmp_path / 'models', tol=1e-5) == 1

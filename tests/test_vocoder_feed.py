@@ -72,6 +72,8 @@ def test_bound_over_the_reference_class_it_gives_the_reference_result(monkeypatc
     for p in (str(ROOT / 'tests' / 'stubs'), str(REF)):
         monkeypatch.syspath_prepend(p)
     world4py_fake.install(monkeypatch)
+    for m in [k for k in sys.modules if k.startswith('realtime_voice_conversion')]:      # an earlier test may have imported it over the stub world4py
+        sys.modules.pop(m)
     voc = importlib.import_module('realtime_voice_conversion.yukarin_wrapper.vocoder')
 
     def make():
