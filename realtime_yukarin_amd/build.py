@@ -28,12 +28,28 @@ def _hipcc() -> str:
     raise RuntimeError('hipcc not found: cannot build libry355.so')
 
 
+def _compile_units(cc, flags, obj_dir: Path, suffix: str, extra_sources=()):
+    """Every translation unit to its own object file, side by side (ry_net.cpp carries the implicit-GEMM instantiations and takes most of
+    the time), then the caller links them."""
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir.mkdir(parents=True, exist_ok=True)
+    jobs = [(u, obj_dir / (Path(u).stem + suffix + '.o')) for u in list(UNITS) + list(extra_sources)]
+
+    def one(job):
+        src, obj = job
+        subprocess.run([cc] + flags + ['-c', str(src), '-o', str(obj)], check=True, cwd=str(ROOT))
+        return obj
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        return [str(o) for o in ex.map(one, jobs)]
+
+
 def build_product(force: bool = False) -> Path:
     """hipcc --offload-arch=gfx950 -> realtime_yukarin_amd/libry355.so (cross-compiles without a GPU)."""
     if force or _stale(LIB, SOURCES):
-        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value',
-               '-x', 'hip'] + [str(u) for u in UNITS] + ['-o', str(LIB)]
-        subprocess.run(cmd, check=True, cwd=str(ROOT))
+        cc = _hipcc()
+        objs = _compile_units(cc, ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-x', 'hip'],
+                              ROOT / 'gpurun_out' / '_obj', '')
+        subprocess.run([cc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', str(LIB)], check=True, cwd=str(ROOT))
     return LIB
 
 
@@ -44,9 +60,11 @@ def build_emu(force: bool = False) -> Path:
         cxx = '/opt/rocm/lib/llvm/bin/clang++'
         if not Path(cxx).exists():
             cxx = shutil.which('clang++') or shutil.which('g++')
-        cmd = [cxx, '-x', 'c++', '-DRY_HOST_EMU', '-O2', '-std=c++17', '-shared', '-fPIC', '-pthread', '-Wno-psabi',
-               '-I' + str(EMU_DIR), '-I' + str(CSRC)] + [str(u) for u in UNITS] + [str(EMU_DIR / 'ry_emu.cpp'), '-o', str(EMU_LIB)]
-        subprocess.run(cmd, check=True, cwd=str(ROOT))
+        objs = _compile_units(cxx, ['-x', 'c++', '-DRY_HOST_EMU', '-O2', '-std=c++17', '-fPIC', '-pthread', '-Wno-psabi',
+                                    '-I' + str(EMU_DIR), '-I' + str(CSRC)], ROOT / 'gpurun_out' / '_obj', '_emu', [EMU_DIR / 'ry_emu.cpp'])
+        tmp = EMU_LIB.with_suffix('.so.tmp%d' % os.getpid())              # several test workers may build at once: link aside, then rename
+        subprocess.run([cxx, '-shared', '-fPIC', '-pthread'] + objs + ['-o', str(tmp)], check=True, cwd=str(ROOT))
+        os.replace(str(tmp), str(EMU_LIB))
     return EMU_LIB
 
 

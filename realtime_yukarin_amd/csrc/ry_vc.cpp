@@ -73,11 +73,18 @@ struct ry_vc {
     ry_net* lane2(int slot) const { return follow(l2[slot % lanes], s2); }
     void sync_lanes() { for (int k = 0; k < lanes; ++k) { rt::stream_sync(l1[k]->stream); rt::stream_sync(l2[k]->stream); } }
     // several windows per call (ry_vc_enqueue_device_batch): their own intermediates, re-allocated when a larger batch arrives
-    Arena batch_bufs;
-    float *b_y1 = nullptr, *b_sp = nullptr;
-    size_t b_cap_y1 = 0, b_cap_sp = 0;
-    rt::Event b_mid, b_done;
-    bool b_ev = false, b_used = false;
+    // ... TWO sets that take turns, so that stage 1 of one call runs under stage 2 of the call before it (with one set it had to wait
+    // for that stage 2 to leave the buffers: every call paid its whole stage 1 in the open)
+    struct BatchSet {
+        Arena bufs;
+        float *y1 = nullptr, *sp = nullptr;
+        size_t cap_y1 = 0, cap_sp = 0;
+        rt::Event mid, done;
+        bool used = false;
+    };
+    BatchSet bset[2];
+    int b_turn = 0;
+    bool b_ev = false;
     void free_pinned() { for (VcSlot& sl : slot) sl.free_pinned(); }
 };
 
@@ -205,7 +212,7 @@ void ry_vc_destroy(ry_vc* vc) {
     vc->sync_lanes();
     for (int k = 1; k < vc->lanes; ++k) { ry_net_destroy(vc->l1[k]); ry_net_destroy(vc->l2[k]); }
     if (vc->has_ev) for (VcSlot& sl : vc->slot) { rt::event_destroy(sl.ev_mid); rt::event_destroy(sl.ev_done); }
-    if (vc->b_ev) { rt::event_destroy(vc->b_mid); rt::event_destroy(vc->b_done); }
+    if (vc->b_ev) for (ry_vc::BatchSet& bs : vc->bset) { rt::event_destroy(bs.mid); rt::event_destroy(bs.done); }
     vc->free_pinned();
     delete vc;
 }
@@ -483,25 +490,26 @@ int ry_vc_enqueue_device_batch(ry_vc* vc, int n_windows, const float* x_eff_dev,
     const int cin = s1->desc.in_ch, M = vc->M, F = vc->F;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
     if (!vc->b_ev) {
-        RT_TRY(rt::event_create_fast(&vc->b_mid)); RT_TRY(rt::event_create_fast(&vc->b_done));
+        for (ry_vc::BatchSet& q : vc->bset) { RT_TRY(rt::event_create_fast(&q.mid)); RT_TRY(rt::event_create_fast(&q.done)); }
         vc->b_ev = true;
     }
     const size_t need_y1 = (size_t)(total_eff > 0 ? total_eff : 1) * M, need_sp = (size_t)n_windows * n_frames * F;
-    if (need_y1 > vc->b_cap_y1 || need_sp > vc->b_cap_sp) {
+    ry_vc::BatchSet& bs = vc->bset[vc->b_turn++ & 1];
+    if (need_y1 > bs.cap_y1 || need_sp > bs.cap_sp) {
         RT_TRY(rt::stream_sync(st1)); RT_TRY(rt::stream_sync(st2));       // queued work may still use the old buffers
-        vc->batch_bufs.release();
-        vc->b_cap_y1 = vc->b_cap_sp = 0;
-        RY_TRY(vc->batch_bufs.alloc(&vc->b_y1, need_y1));
-        RY_TRY(vc->batch_bufs.alloc(&vc->b_sp, need_sp));
-        vc->b_cap_y1 = need_y1; vc->b_cap_sp = need_sp;
+        bs.bufs.release();
+        bs.cap_y1 = bs.cap_sp = 0; bs.used = false;
+        RY_TRY(bs.bufs.alloc(&bs.y1, need_y1));
+        RY_TRY(bs.bufs.alloc(&bs.sp, need_sp));
+        bs.cap_y1 = need_y1; bs.cap_sp = need_sp;
     }
-    if (vc->b_used) RT_TRY(rt::stream_wait_event(st1, vc->b_done));         // the previous batch has left b_sp
+    if (bs.used) RT_TRY(rt::stream_wait_event(st1, bs.done));               // the call before the previous one has left this set
     if (total_eff > 0) {
-        if (same) RY_TRY(ry_ac_convert(s1, x_eff_dev, vc->b_y1, n_windows, n_eff[0], 1));
+        if (same) RY_TRY(ry_ac_convert(s1, x_eff_dev, bs.y1, n_windows, n_eff[0], 1));
         else {
             long long off = 0;
             for (int w = 0; w < n_windows; ++w) {
-                if (n_eff[w] > 0) RY_TRY(ry_ac_convert(s1, x_eff_dev + off * cin, vc->b_y1 + off * M, 1, n_eff[w], 1));
+                if (n_eff[w] > 0) RY_TRY(ry_ac_convert(s1, x_eff_dev + off * cin, bs.y1 + off * M, 1, n_eff[w], 1));
                 off += n_eff[w];
             }
         }
@@ -513,7 +521,7 @@ int ry_vc_enqueue_device_batch(ry_vc* vc, int n_windows, const float* x_eff_dev,
         for (int w = 0; w < n_windows; ++w) {
             if (n_eff[w] > 0) {
                 RyScatterParams sc;
-                sc.src = vc->b_y1 + off * M; sc.row_of = row_of_dev + off; sc.dst = mc_out_dev + (size_t)w * n_frames * M; sc.n_src = n_eff[w]; sc.cols = M;
+                sc.src = bs.y1 + off * M; sc.row_of = row_of_dev + off; sc.dst = mc_out_dev + (size_t)w * n_frames * M; sc.n_src = n_eff[w]; sc.cols = M;
                 dim3 sg((unsigned)(((long long)n_eff[w] * M + 255) / 256));
                 RY_TRY(Lc.begin("ry_scatter_rows", "combine_silent", 0, 0, sg));
                 RY_LAUNCH(ry_scatter_rows, sg, 256, st1, sc);
@@ -522,17 +530,17 @@ int ry_vc_enqueue_device_batch(ry_vc* vc, int n_windows, const float* x_eff_dev,
             off += n_eff[w];
         }
         RyMc2spParams mp;
-        mp.mc = mc_out_dev; mp.mtx = vc->d_mtx; mp.sp = vc->b_sp; mp.n = n_windows * n_frames; mp.m = M; mp.f = F; mp.floor = sp_floor;
+        mp.mc = mc_out_dev; mp.mtx = vc->d_mtx; mp.sp = bs.sp; mp.n = n_windows * n_frames; mp.m = M; mp.f = F; mp.floor = sp_floor;
         dim3 mg((unsigned)(((long long)n_windows * n_frames * F + 255) / 256));
         RY_TRY(Lc.begin("ry_mc2sp", "decode_spectrogram", 0, 0, mg));
         RY_LAUNCH(ry_mc2sp, mg, 256, st1, mp);
         RY_TRY(Lc.end());
     }
-    RT_TRY(rt::event_record(vc->b_mid, st1));
-    RT_TRY(rt::stream_wait_event(st2, vc->b_mid));
-    RY_TRY(ry_sr_convert_rows(s2, vc->b_sp, sp_out_dev, n_windows, n_frames, vc->disc_front, vc->disc_back, 1));
-    RT_TRY(rt::event_record(vc->b_done, st2));
-    vc->b_used = true;
+    RT_TRY(rt::event_record(bs.mid, st1));
+    RT_TRY(rt::stream_wait_event(st2, bs.mid));
+    RY_TRY(ry_sr_convert_rows(s2, bs.sp, sp_out_dev, n_windows, n_frames, vc->disc_front, vc->disc_back, 1));
+    RT_TRY(rt::event_record(bs.done, st2));
+    bs.used = true;
     vc->split_eff = -1;
     return RY_OK;
 }
