@@ -41,8 +41,9 @@ struct VcSlot {
 };
 
 struct ry_vc {
-    static const int RING = 6;            // windows in flight: two per lane with three lanes (stage 1 of a lane's next window runs under stage 2 of its previous one)
-    static const int MAX_LANES = 3;
+    static const int RING = 16;           // ring slots that exist; `ring` of them are in use: six up to three lanes, else two per lane
+    static const int MAX_LANES = 8;
+    int ring = 6;                         // windows in flight (stage 1 of a lane's next window runs under stage 2 of its previous one)
     ry_net* s1 = nullptr;
     ry_net* s2 = nullptr;
     int M = 0, F = 0;
@@ -58,8 +59,9 @@ struct ry_vc {
     // window's one-round grids and its weight-streaming bottom layers are filled by the other windows' kernels.
     int disc_front = 0, disc_back = 0;   // ry_vc_set_discard: frames of every window the caller throws away (stage 2 does not compute them)
     int lanes = 1;
-    ry_net* l1[MAX_LANES] = {nullptr, nullptr, nullptr};
-    ry_net* l2[MAX_LANES] = {nullptr, nullptr, nullptr};
+    ry_net* l1[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ry_net* l2[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int lane_xcds = 0;                    // > 0: every lane owns this many XCDs (ry_vc_set_lane_xcds)
     // a clone follows the arithmetic mode of the handle it was made from (ry_net_set_dtype on the caller's handle converts the filters
     // once; the clone takes the pointers and drops its launch plans)
     static ry_net* follow(ry_net* n, ry_net* src) {
@@ -135,10 +137,10 @@ static int vc_reserve_slot(ry_vc* vc, VcSlot& sl, int n_eff, int n_frames) {
 
 // every slot (ry_vc_reserve_frames: ahead of time, nothing may be in flight)
 static int vc_reserve(ry_vc* vc, int n_eff, int n_frames) {
-    for (VcSlot& sl : vc->slot)
+    for (int i = 0; i < vc->ring; ++i) { VcSlot& sl = vc->slot[i];
         if (sl.ticket >= 0 && (n_eff > sl.cap_eff || n_frames > sl.cap_frames))
-            return fail(RY_ESTATE, "ticket %d is still in flight: ry_vc_wait it before reserving a larger ring", sl.ticket);
-    for (VcSlot& sl : vc->slot) RY_TRY(vc_reserve_slot(vc, sl, n_eff, n_frames));
+            return fail(RY_ESTATE, "ticket %d is still in flight: ry_vc_wait it before reserving a larger ring", sl.ticket); }
+    for (int i = 0; i < vc->ring; ++i) RY_TRY(vc_reserve_slot(vc, vc->slot[i], n_eff, n_frames));
     return RY_OK;
 }
 
@@ -210,6 +212,7 @@ void ry_vc_destroy(ry_vc* vc) {
     if (!vc) return;
     rt::set_device(vc->s1->ctx->device);
     vc->sync_lanes();
+    if (vc->lane_xcds) { ry_net_set_cu_mask(vc->s1, nullptr, 0); ry_net_set_cu_mask(vc->s2, nullptr, 0); }    // lane 0 is the caller's pair: give it the chip back
     for (int k = 1; k < vc->lanes; ++k) { ry_net_destroy(vc->l1[k]); ry_net_destroy(vc->l2[k]); }
     if (vc->has_ev) for (VcSlot& sl : vc->slot) { rt::event_destroy(sl.ev_mid); rt::event_destroy(sl.ev_done); }
     if (vc->b_ev) for (ry_vc::BatchSet& bs : vc->bset) { rt::event_destroy(bs.mid); rt::event_destroy(bs.done); }
@@ -231,7 +234,7 @@ int ry_vc_set_discard(ry_vc* vc, int front, int back) {
     return RY_OK;
 }
 
-// 1 .. 3 lanes: ring slot k runs on its own pair of predictor handles (clones of the caller's: same filters, own streams, plans,
+// 1 .. 8 lanes (six ring slots up to three lanes, else two per lane): ring slot k runs on its own pair of predictor handles (clones of the caller's: same filters, own streams, plans,
 // activations and graphs), so that up to `lanes` windows really run side by side.  Measured at 300 frames (scripts/gpu_r2_twostream.py):
 // 1.281 / 1.200 / 1.160 ms per window with 1 / 2 / 3 lanes -- the one-round grids of one window leave tails and its bottom layers leave
 // most of the chip idle; the other windows' kernels fill both.  Results do not change (same plans, same arithmetic).
@@ -255,6 +258,36 @@ int ry_vc_set_lanes(ry_vc* vc, int lanes) {
         vc->l1[vc->lanes] = a; vc->l2[vc->lanes] = b;
         ++vc->lanes;
     }
+    vc->ring = lanes <= 3 ? 6 : 2 * lanes;
+    vc->dev_count = 0;
+    if (vc->lane_xcds) {                                  // the lane count changed: back to the whole chip for every lane
+        vc->lane_xcds = 0;
+        for (int k = 0; k < vc->lanes; ++k) { RY_TRY(ry_net_set_cu_mask(vc->l1[k], nullptr, 0)); RY_TRY(ry_net_set_cu_mask(vc->l2[k], nullptr, 0)); }
+    }
+    return RY_OK;
+}
+
+// Every lane gets its own XCDs: with `lanes` = 2 / 4 / 8 lanes, lane k runs on the 8 / lanes XCDs k, k + lanes, ... (compute-unit masks on
+// the streams of its predictor pair; on gfx950 bit i of a CU mask belongs to XCD i % 8).  A window then runs from its first to its last
+// kernel inside the L2s it owns, every layer is several rounds of workgroups on 128 / 64 / 32 CUs (no one-round tails, launch plans
+// rebuilt for that CU count), and the lanes never wait for each other's grids -- at the price of the latency of one window, which
+// grows with the number of lanes.  A throughput setting (a backlog, offline conversion, many sessions); `on` = 0 gives the whole chip
+// back to every lane.  Results do not depend on it beyond summation order (other plans).
+int ry_vc_set_lane_xcds(ry_vc* vc, int on) {
+    if (!vc) return fail(RY_EINVAL, "null argument");
+    if (on && vc->lanes != 2 && vc->lanes != 4 && vc->lanes != 8) return fail(RY_EINVAL, "XCD lanes need 2, 4 or 8 lanes (got %d)", vc->lanes);
+    for (int i = 0; i < vc->ring; ++i)
+        if (vc->slot[i].ticket >= 0) return fail(RY_ESTATE, "ticket %d is still in flight: ry_vc_wait it first", vc->slot[i].ticket);
+    vc->sync_lanes();
+    for (int k = 0; k < vc->lanes; ++k) {
+        unsigned mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (on)
+            for (int cu = 0; cu < 256; ++cu)
+                if ((cu >> 3) % vc->lanes == k) mask[cu >> 5] |= 1u << (cu & 31);   // CU (cu >> 3) of XCD (cu & 7): every lane gets 32 / lanes CUs of EVERY XCD
+        RY_TRY(ry_net_set_cu_mask(vc->l1[k], on ? mask : nullptr, on ? 8 : 0));
+        RY_TRY(ry_net_set_cu_mask(vc->l2[k], on ? mask : nullptr, on ? 8 : 0));
+    }
+    vc->lane_xcds = on ? 8 / vc->lanes : 0;
     return RY_OK;
 }
 
@@ -264,9 +297,9 @@ int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, in
     RY_TRY(vc_check(vc, row_of, n_eff, n_frames, true));
     RT_TRY(rt::set_device(vc->s1->ctx->device));
     const int t = vc->next_ticket;
-    VcSlot& sl = vc->slot[t % ry_vc::RING];
-    ry_net *s1 = vc->lane1(t % ry_vc::RING), *s2 = vc->lane2(t % ry_vc::RING);
-    if (sl.ticket >= 0) return fail(RY_ESTATE, "all %d ring slots are in flight: ry_vc_wait ticket %d first", ry_vc::RING, sl.ticket);
+    VcSlot& sl = vc->slot[t % vc->ring];
+    ry_net *s1 = vc->lane1(t % vc->ring), *s2 = vc->lane2(t % vc->ring);
+    if (sl.ticket >= 0) return fail(RY_ESTATE, "all %d ring slots are in flight: ry_vc_wait ticket %d first", vc->ring, sl.ticket);
     RY_TRY(vc_reserve_slot(vc, sl, n_eff, n_frames));
     const int cin = s1->desc.in_ch, M = vc->M, F = vc->F;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
@@ -296,7 +329,7 @@ int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, in
 int ry_vc_wait(ry_vc* vc, int ticket, float* mc_out, float* sp_out) {
     if (!vc || !mc_out || !sp_out) return fail(RY_EINVAL, "null argument");
     if (ticket < 0) return fail(RY_EINVAL, "bad ticket %d", ticket);
-    VcSlot& sl = vc->slot[ticket % ry_vc::RING];
+    VcSlot& sl = vc->slot[ticket % vc->ring];
     if (sl.ticket != ticket) return fail(RY_ESTATE, "ticket %d is not in flight (already waited for, or never submitted)", ticket);
     RT_TRY(rt::set_device(vc->s1->ctx->device));
     RT_TRY(rt::event_sync(sl.ev_done));            // ev_done follows ev_mid in stream order (stage-2 waited for it)
@@ -408,9 +441,9 @@ int ry_vc_submit_wave(ry_vc* vc, const float* wave, int n_samples, int hop, int 
     if (!ticket) return fail(RY_EINVAL, "null argument");
     RT_TRY(rt::set_device(vc->s1->ctx->device));
     const int t = vc->next_ticket;
-    VcSlot& sl = vc->slot[t % ry_vc::RING];
-    ry_net *s1 = vc->lane1(t % ry_vc::RING), *s2 = vc->lane2(t % ry_vc::RING);
-    if (sl.ticket >= 0) return fail(RY_ESTATE, "all %d ring slots are in flight: ry_vc_wait ticket %d first", ry_vc::RING, sl.ticket);
+    VcSlot& sl = vc->slot[t % vc->ring];
+    ry_net *s1 = vc->lane1(t % vc->ring), *s2 = vc->lane2(t % vc->ring);
+    if (sl.ticket >= 0) return fail(RY_ESTATE, "all %d ring slots are in flight: ry_vc_wait ticket %d first", vc->ring, sl.ticket);
     RY_TRY(vc_reserve_slot(vc, sl, n_frames, n_frames));
     const int M = vc->M, F = vc->F;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
@@ -435,7 +468,7 @@ int ry_vc_submit_wave(ry_vc* vc, const float* wave, int n_samples, int hop, int 
 int ry_vc_wait_wave(ry_vc* vc, int ticket, float* mc_out, float* sp_out, unsigned char* effective_out, int* n_eff_out) {
     if (!vc || !effective_out) return fail(RY_EINVAL, "null argument");
     if (ticket < 0) return fail(RY_EINVAL, "bad ticket %d", ticket);
-    VcSlot& sl = vc->slot[ticket % ry_vc::RING];
+    VcSlot& sl = vc->slot[ticket % vc->ring];
     if (sl.ticket != ticket || !sl.gated) return fail(RY_ESTATE, "ticket %d is not a window submitted with ry_vc_submit_wave", ticket);
     memcpy(effective_out, sl.h_mask, (size_t)sl.n_frames);      // (already on the host: the submit waited for the count)
     if (n_eff_out) *n_eff_out = sl.n_eff;
@@ -450,9 +483,9 @@ int ry_vc_enqueue_device(ry_vc* vc, const float* x_eff_dev, const int* row_of_de
     if (!vc || !mc_out_dev || !sp_out_dev || (n_eff > 0 && (!x_eff_dev || !row_of_dev))) return fail(RY_EINVAL, "null argument");
     RY_TRY(vc_check(vc, nullptr, n_eff, n_frames, false));
     RT_TRY(rt::set_device(vc->s1->ctx->device));
-    VcSlot& sl = vc->slot[vc->dev_count % ry_vc::RING];
-    ry_net *s1 = vc->lane1(vc->dev_count % ry_vc::RING), *s2 = vc->lane2(vc->dev_count % ry_vc::RING);
-    if (sl.ticket >= 0) return fail(RY_ESTATE, "ring slot %d is held by ticket %d: ry_vc_wait it first", vc->dev_count % ry_vc::RING, sl.ticket);
+    VcSlot& sl = vc->slot[vc->dev_count % vc->ring];
+    ry_net *s1 = vc->lane1(vc->dev_count % vc->ring), *s2 = vc->lane2(vc->dev_count % vc->ring);
+    if (sl.ticket >= 0) return fail(RY_ESTATE, "ring slot %d is held by ticket %d: ry_vc_wait it first", vc->dev_count % vc->ring, sl.ticket);
     RY_TRY(vc_reserve_slot(vc, sl, n_eff, n_frames));
     ++vc->dev_count;
     ry_stream_t st1 = s1->stream, st2 = s2->stream;
