@@ -75,10 +75,6 @@ void ry_net_destroy(ry_net* net);
 /* A second handle on the same predictor: the filters are shared (freed with the last handle), the clone has its own stream, launch
  * plans, activation buffers and captured graphs.  ry_net_set_dtype on one handle does not change the others. */
 int ry_net_clone(ry_net* net, ry_net** out);
-/* The predictor's kernels run only on the compute units named by `mask` (bit i = CU i; on gfx950 bit i belongs to XCD i % 8; n_words 32-bit
- * words, 0 = the whole chip again): the stream is replaced and the launch plans are rebuilt for that many CUs. */
-int ry_net_set_cu_mask(ry_net* net, const unsigned* mask, int n_words);
-
 /* BASELINE config #5: dtype 1 runs the stage-2 implicit-GEMM layers with bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate,
  * bf16 activations between those layers; filters converted once).  dtype 2 ("split-bf16") runs them as three bf16 products per fp32
  * product -- x = hi + lo, w = hi + lo, x w ~ hi hi + lo hi + hi lo -- on the same instruction with fp32 accumulation: results agree
@@ -146,10 +142,6 @@ int ry_vc_set_discard(ry_vc* vc, int front, int back);
  * one stage-2 forward after the other.  Same results.  Device-pointer callers (ry_vc_enqueue_device) must then give windows that are in
  * flight together their own output blocks.  No ticket may be in flight when the lane count changes.  Default 1. */
 int ry_vc_set_lanes(ry_vc* vc, int lanes);
-/* Every lane on its own XCDs (2 / 4 / 8 lanes -> 4 / 2 / 1 XCDs each; compute-unit masks on the lane's streams): a window runs inside the L2s
- * its lane owns, every layer is several rounds of workgroups on 128 / 64 / 32 CUs, the lanes never wait for each other's grids.  A
- * THROUGHPUT setting -- the latency of one window grows with the number of lanes; on = 0 gives the whole chip back to every lane. */
-int ry_vc_set_lane_xcds(ry_vc* vc, int on);
 int ry_vc_wait(ry_vc* vc, int ticket, float* mc_out, float* sp_out);
 /* All pointers on the device, nothing waited for (ry_sync / your own event): consecutive calls pipeline by themselves -- stage-1 of
  * window i + 1 runs on its stream under stage-2 of window i.  bench.py times this. */
@@ -226,9 +218,6 @@ int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat*
 /* The same for the convert wrapper on ONE window of n_frames (what ry_ac_convert / ry_sr_convert / the ry_vc_* window call run:
  * pad kernel, layers, fused crop; stage 2 skips the decoder rows that only feed the padding the wrapper throws away). */
 int ry_net_profile_window(ry_net* net, int n_frames, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats);
-
-/* diagnostics: hist8[x] = workgroups (of 4096) of a probe kernel on a CU-masked stream that ran on XCD x (checks the bit -> XCD rule above) */
-int ry_debug_xcc_histogram(ry_ctx* ctx, const unsigned* mask, int n_words, unsigned* hist8);
 
 /* diagnostics: ratio[i * n + j] = wall time of a `us`-microsecond spin kernel on each of two fresh streams i and j, divided by `us`:
  * ~1 when the two streams run side by side, ~2 when one waits for the other (scripts/gpu_r2_queues.py). */

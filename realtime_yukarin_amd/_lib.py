@@ -45,11 +45,11 @@ if 'GPU_MAX_HW_QUEUES' not in os.environ:
 
 ABI_SYMBOLS = (
     'ry_init', 'ry_shutdown', 'ry_sync', 'ry_stream', 'ry_device_count', 'ry_last_error',
-    'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_clone', 'ry_net_set_cu_mask', 'ry_net_set_dtype', 'ry_net_forward',
+    'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_clone', 'ry_net_set_dtype', 'ry_net_forward',
     'ry_ac_convert', 'ry_sr_convert', 'ry_sr_convert_rows', 'ry_conv1d', 'ry_conv2d', 'ry_conv2d_dilated',
-    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_net_profile_window', 'ry_debug_plan_igemm', 'ry_debug_stream_overlap', 'ry_debug_xcc_histogram', 'ry_debug_plan_igemm_bf16',
+    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_net_profile_window', 'ry_debug_plan_igemm', 'ry_debug_stream_overlap', 'ry_debug_plan_igemm_bf16',
     'ry_vc_create', 'ry_vc_destroy', 'ry_vc_convert', 'ry_mc2sp',
-    'ry_vc_submit', 'ry_vc_set_lanes', 'ry_vc_set_lane_xcds', 'ry_vc_set_discard', 'ry_vc_wait', 'ry_vc_enqueue_device', 'ry_vc_enqueue_device_batch', 'ry_vc_stage1', 'ry_vc_stage2_from_mc', 'ry_vc_mid_sp', 'ry_vc_reserve_frames',
+    'ry_vc_submit', 'ry_vc_set_lanes', 'ry_vc_set_discard', 'ry_vc_wait', 'ry_vc_enqueue_device', 'ry_vc_enqueue_device_batch', 'ry_vc_stage1', 'ry_vc_stage2_from_mc', 'ry_vc_mid_sp', 'ry_vc_reserve_frames',
     'ry_vc_submit_wave', 'ry_vc_wait_wave', 'ry_vc_gate',
     'ry_comm_unique_id', 'ry_comm_init', 'ry_comm_destroy', 'ry_comm_bcast_weights', 'ry_comm_allreduce_max', 'ry_comm_barrier',
     'ry_dev_alloc', 'ry_dev_free', 'ry_dev_upload', 'ry_dev_download',
@@ -125,9 +125,6 @@ class Ry355Lib(object):
         d.ry_vc_submit.argtypes = [_VP, _FP, _IP, ctypes.c_int, ctypes.c_int, ctypes.c_float, _IP]
         d.ry_vc_wait.argtypes = [_VP, ctypes.c_int, _FP, _FP]
         d.ry_vc_set_lanes.argtypes = [_VP, ctypes.c_int]
-        d.ry_vc_set_lane_xcds.argtypes = [_VP, ctypes.c_int]
-        d.ry_net_set_cu_mask.argtypes = [_VP, ctypes.POINTER(ctypes.c_uint), ctypes.c_int]
-        d.ry_debug_xcc_histogram.argtypes = [_VP, ctypes.POINTER(ctypes.c_uint), ctypes.c_int, ctypes.POINTER(ctypes.c_uint)]
         d.ry_vc_set_discard.argtypes = [_VP, ctypes.c_int, ctypes.c_int]
         d.ry_sr_convert_rows.argtypes = [_VP, _FP, _FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         d.ry_debug_stream_overlap.argtypes = [_VP, ctypes.c_int, ctypes.c_int, _FP]

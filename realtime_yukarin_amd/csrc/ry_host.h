@@ -30,7 +30,6 @@ static const char* err_str(err_t) { return "emu"; }
 static err_t set_device(int) { return 0; }
 static err_t device_count(int* n) { *n = 1; return 0; }
 static err_t stream_create(ry_stream_t* s) { *s = nullptr; return 0; }
-static err_t stream_create_masked(ry_stream_t* s, const unsigned*, int) { *s = nullptr; return 0; }
 static err_t stream_destroy(ry_stream_t) { return 0; }
 static err_t stream_sync(ry_stream_t) { return 0; }
 static err_t dmalloc(void** p, size_t bytes) { *p = aligned_alloc(256, (bytes + 255) / 256 * 256); return *p ? 0 : 1; }
@@ -56,8 +55,6 @@ static const char* err_str(err_t e) { return hipGetErrorString(e); }
 static err_t set_device(int d) { return hipSetDevice(d); }
 static err_t device_count(int* n) { return hipGetDeviceCount(n); }
 static err_t stream_create(ry_stream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
-// a stream whose kernels run only on the compute units named by the mask (bit i = CU i; on gfx950 bit i belongs to XCD i % 8, checked by ry_debug_xcc_histogram)
-static err_t stream_create_masked(ry_stream_t* s, const unsigned* mask, int words) { return hipExtStreamCreateWithCUMask(s, (uint32_t)words, mask); }
 static err_t stream_destroy(ry_stream_t s) { return hipStreamDestroy(s); }
 static err_t stream_sync(ry_stream_t s) { return hipStreamSynchronize(s); }
 static err_t dmalloc(void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 256); }
@@ -242,8 +239,6 @@ struct ry_net {
     std::shared_ptr<Arena> weights = std::make_shared<Arena>();   // filters, scale / shift: shared by the clones of a predictor (ry_net_clone)
     std::map<std::tuple<int, int, int, int>, std::unique_ptr<Plan>> plans;
     bool use_graph = true;
-    int n_cus = 256;                         // compute units the predictor's stream may use (ry_net_set_cu_mask): the stage-2 planner sizes grids for them
-    std::vector<unsigned> cu_mask;           // empty = the whole chip
     // profiling hook
     std::vector<KernelRec>* rec = nullptr;
     std::vector<std::pair<rt::Event, rt::Event>>* rec_events = nullptr;

@@ -306,7 +306,6 @@ static const char* tile_name(int tile, int kg, bool bf16, int patch) {
 // buffer, limited to 3 by its VGPR budget.
 static thread_local double g_plan_peak = 157.3e6;   // flop per microsecond the planner prices the main loop at (fp32 MFMA peak; bf16: see choose_igemm)
 static thread_local int g_plan_ck = 32;             // input channels per K chunk of the kernel being planned
-static thread_local int g_plan_cus = 256;           // compute units the launch may use (a predictor on a CU-masked stream: ry_net_set_cu_mask)
 // split-bf16 kernels (measured, profiles/r01_n_x3_plansweep_n300.txt): the main-loop rate the planner prices them at (three times
 // the K of the bf16 mode per tile: the fixed costs weigh less, 128x128 tiles reach 730-800 TF of bf16 products = 0.7 x 1150),
 // and the price of two K groups in one 512-thread workgroup against two 256-thread workgroups on the same CU (the GEMM alone
@@ -333,7 +332,7 @@ static double cu_rate(int r) {
 // last round runs at the rate of its fewer resident groups); external split-K adds the slab traffic and a reduce launch.
 static double est_time(long blocks, int bm, int bn, int s, int occ, int kg, int M, int N, int nk) {
     const long g = blocks * s;
-    const long per_cu = (g + g_plan_cus - 1) / g_plan_cus;
+    const long per_cu = (g + 255) / 256;
     const long full = per_cu / occ, rem = per_cu % occ;
     const double tile_us = 2.0 * bm * bn * ((double)g_plan_ck * nk) / (g_plan_peak / 256.0);   // one tile on one CU at the peak (157.3 TFLOP/s over 256 CUs)
     const double w = tile_us / (double)(s * kg);                              // work of one four-wave group
@@ -350,7 +349,7 @@ static int best_split(long blocks, int bm, int bn, int nk, bool tinyM, int occ, 
     int best = 1; double bt = 1e30;
     for (int s = 1; s <= smax && s <= (nk >= min_chunks ? nk / min_chunks : 1); ++s) {
         double t;
-        if (tinyM) { const long g = blocks * s, want = 2L * g_plan_cus; t = g >= want ? 1.0 + 1e-4 * s : (double)want / (double)g; }   // weight streaming: two workgroups per CU keep enough loads in flight (1024 measured 30 % slower: more slabs, same bandwidth)
+        if (tinyM) { const long g = blocks * s; t = g >= 512 ? 1.0 + 1e-4 * s : 512.0 / (double)g; }   // weight streaming: two workgroups per CU keep enough loads in flight (1024 measured 30 % slower: more slabs, same bandwidth)
         else t = est_time(blocks, bm, bn, s, occ, kg, M, N, nk);
         if (t < bt - 1e-9) { bt = t; best = s; }
     }
@@ -706,7 +705,6 @@ static int launch_c1d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
 // ------------------------------------------------------------------------------------------------
 static int build_plan(ry_net* net, Plan& P) {
     const ry_net_desc& d = net->desc;
-    g_plan_cus = net->n_cus > 0 ? net->n_cus : 256;
     const int nd = d.ndim, B = P.B;
     P.lp.assign(16, LayerPlan());
     int H = nd == 2 ? P.T : 1, W = nd == 2 ? d.width : P.T;
@@ -918,7 +916,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
             // gains nothing by itself, but the CUs it leaves idle go to the window on the other lane (ry_vc_set_lanes): 1.160 -> 1.137 ms
             // per window with two lanes, so it is cropped too (RY_S2_CROP=1 keeps such grids whole)
             const long wgs = (long)(((long)B * Mh * Mw + bm - 1) / bm) * (l.cout / bn) * (l.deconv ? 4 : 1) * lp.splits;
-            if (g_s2_crop >= 2 || wgs > net->n_cus) { crop0[i] = r0; crop[i] = r1 - r0; need0 = r0; need1 = r1; }
+            if (g_s2_crop >= 2 || wgs > 256) { crop0[i] = r0; crop[i] = r1 - r0; need0 = r0; need1 = r1; }
             else { need0 = 0; need1 = lp.Hi; }                      // this layer runs whole: it reads every row of its producer
         }
     }
@@ -1301,11 +1299,10 @@ int ry_net_clone(ry_net* src, ry_net** out) {
     ry_ctx* ctx = src->ctx;
     RT_TRY(rt::set_device(ctx->device));
     std::unique_ptr<ry_net> net(new ry_net());
-    net->ctx = ctx; net->desc = src->desc; net->dtype = src->dtype; net->use_graph = src->use_graph; net->n_cus = src->n_cus; net->cu_mask = src->cu_mask;
+    net->ctx = ctx; net->desc = src->desc; net->dtype = src->dtype; net->use_graph = src->use_graph;
     net->layers = src->layers;                       // device pointers into the shared arena
     net->weights = src->weights;
-    if (net->cu_mask.empty()) RT_TRY(rt::stream_create(&net->stream));
-    else RT_TRY(rt::stream_create_masked(&net->stream, net->cu_mask.data(), (int)net->cu_mask.size()));
+    RT_TRY(rt::stream_create(&net->stream));
     RT_TRY(rt::event_create_fast(&net->done));
     net->has_done = true;
     ctx->nets.push_back(net.get());
@@ -1325,28 +1322,6 @@ void ry_net_destroy(ry_net* net) {
     if (net->has_done) rt::event_destroy(net->done);
     rt::stream_destroy(net->stream);
     delete net;
-}
-
-// The predictor's kernels run only on the compute units named by `mask` (bit i = CU i, n_words 32-bit words; n_words = 0: the whole chip
-// again).  The stream is replaced, the launch plans are dropped and rebuilt for that many CUs.  Used by the window lanes to give every lane
-// its own XCDs (ry_vc_set_lane_xcds): a window then runs start to end inside the L2s it owns and the lanes never wait for each other's
-// one-round grids.
-int ry_net_set_cu_mask(ry_net* net, const unsigned* mask, int n_words) {
-    if (!net || n_words < 0 || n_words > 16 || (n_words > 0 && !mask)) return fail(RY_EINVAL, "bad CU mask");
-    RT_TRY(rt::set_device(net->ctx->device));
-    RT_TRY(rt::stream_sync(net->stream));
-    int cus = 0;
-    for (int i = 0; i < n_words; ++i) cus += __builtin_popcount(mask[i]);
-    if (n_words > 0 && cus < 1) return fail(RY_EINVAL, "the CU mask is empty");
-    ry_stream_t st = nullptr;
-    if (n_words == 0) RT_TRY(rt::stream_create(&st));
-    else RT_TRY(rt::stream_create_masked(&st, mask, n_words));
-    net->plans.clear();
-    rt::stream_destroy(net->stream);
-    net->stream = st;
-    net->cu_mask.assign(mask, mask + n_words);
-    net->n_cus = n_words == 0 ? 256 : (cus > 256 ? 256 : cus);
-    return RY_OK;
 }
 
 static unsigned short host_f2bf(float f) {
@@ -1535,49 +1510,6 @@ static int profile_plan(ry_net* net, Plan* P, int reps, ry_kernel_stat* stats, i
     return RY_OK;
 }
 
-
-// diagnostics: on which compute units do the workgroups of a kernel launched on a CU-masked stream run?  hist[x] = distinct CUs of XCD x
-// that ran at least one of 8192 short workgroups.  What ry_vc_set_lane_xcds relies on: bit i of the mask belongs to XCD i % 8.
-#ifndef RY_HOST_EMU
-__global__ void ry_xcc_probe_kernel(unsigned* hist, unsigned* cus, unsigned long long ticks) {
-    if (threadIdx.x == 0) {
-        unsigned x, h;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h));
-        atomicAdd(hist + (x & 7u), 1u);
-        // HW_ID (gfx9): CU_ID [11:8], SH_ID [12], SE_ID [15:13]: one counter per (XCD, SE, SH, CU)
-        const unsigned key = ((x & 7u) << 8) | (((h >> 13) & 7u) << 5) | (((h >> 12) & 1u) << 4) | ((h >> 8) & 15u);
-        atomicAdd(cus + key, 1u);
-        const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < ticks) {}
-    }
-}
-#endif
-int ry_debug_xcc_histogram(ry_ctx* ctx, const unsigned* mask, int n_words, unsigned* hist8) {
-    if (!ctx || !hist8 || n_words < 0 || n_words > 16) return fail(RY_EINVAL, "bad argument");
-    for (int i = 0; i < 8; ++i) hist8[i] = 0;
-#ifndef RY_HOST_EMU
-    RT_TRY(rt::set_device(ctx->device));
-    ry_stream_t st = nullptr;
-    if (n_words == 0) RT_TRY(rt::stream_create(&st));
-    else RT_TRY(rt::stream_create_masked(&st, mask, n_words));
-    unsigned* d = nullptr;
-    RT_TRY(hipMalloc((void**)&d, (8 + 2048) * sizeof(unsigned)));
-    RT_TRY(hipMemsetAsync(d, 0, (8 + 2048) * sizeof(unsigned), st));
-    int khz = 100000;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
-    hipLaunchKernelGGL(ry_xcc_probe_kernel, dim3(8192), dim3(64), 0, st, d, d + 8, (unsigned long long)khz / 50ull);   // 20 us per workgroup: every enabled CU gets some
-    std::vector<unsigned> h(8 + 2048);
-    RT_TRY(hipMemcpyAsync(h.data(), d, (8 + 2048) * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    RT_TRY(rt::stream_sync(st));
-    unsigned distinct = 0;
-    for (int i = 0; i < 8; ++i) hist8[i] = 0;
-    for (int k = 0; k < 2048; ++k) if (h[8 + k]) { ++distinct; ++hist8[k >> 8]; }      // hist8[x] = distinct (SE, SH, CU) slots used on XCD x
-    (void)distinct;
-    hipFree(d); rt::stream_destroy(st);
-#endif
-    return RY_OK;
-}
 
 // diagnostics: do two HIP streams of this process really run side by side?  A one-wave kernel that spins for `us` microseconds is put on
 // stream i and on stream j; ratio[i * n + j] = wall time of the pair / us: ~1 when the two hardware queues are served together, ~2 when

@@ -61,7 +61,6 @@ struct ry_vc {
     int lanes = 1;
     ry_net* l1[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ry_net* l2[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int lane_xcds = 0;                    // > 0: every lane owns this many XCDs (ry_vc_set_lane_xcds)
     // a clone follows the arithmetic mode of the handle it was made from (ry_net_set_dtype on the caller's handle converts the filters
     // once; the clone takes the pointers and drops its launch plans)
     static ry_net* follow(ry_net* n, ry_net* src) {
@@ -212,7 +211,6 @@ void ry_vc_destroy(ry_vc* vc) {
     if (!vc) return;
     rt::set_device(vc->s1->ctx->device);
     vc->sync_lanes();
-    if (vc->lane_xcds) { ry_net_set_cu_mask(vc->s1, nullptr, 0); ry_net_set_cu_mask(vc->s2, nullptr, 0); }    // lane 0 is the caller's pair: give it the chip back
     for (int k = 1; k < vc->lanes; ++k) { ry_net_destroy(vc->l1[k]); ry_net_destroy(vc->l2[k]); }
     if (vc->has_ev) for (VcSlot& sl : vc->slot) { rt::event_destroy(sl.ev_mid); rt::event_destroy(sl.ev_done); }
     if (vc->b_ev) for (ry_vc::BatchSet& bs : vc->bset) { rt::event_destroy(bs.mid); rt::event_destroy(bs.done); }
@@ -234,7 +232,9 @@ int ry_vc_set_discard(ry_vc* vc, int front, int back) {
     return RY_OK;
 }
 
-// 1 .. 8 lanes (six ring slots up to three lanes, else two per lane): ring slot k runs on its own pair of predictor handles (clones of the caller's: same filters, own streams, plans,
+// 1 .. 8 lanes (six ring slots up to three lanes, else two per lane; measured in round 3 at 300 frames: 1.133 / 1.166 / 1.156 / 1.147 / 1.121 ms per
+// window with 2 / 3 / 4 / 6 / 8 lanes, profiles/r03_h_lane_experiments.txt; the default stays 2: the latency of a window grows with the lanes):
+// ring slot k runs on its own pair of predictor handles (clones of the caller's: same filters, own streams, plans,
 // activations and graphs), so that up to `lanes` windows really run side by side.  Measured at 300 frames (scripts/gpu_r2_twostream.py):
 // 1.281 / 1.200 / 1.160 ms per window with 1 / 2 / 3 lanes -- the one-round grids of one window leave tails and its bottom layers leave
 // most of the chip idle; the other windows' kernels fill both.  Results do not change (same plans, same arithmetic).
@@ -260,34 +260,6 @@ int ry_vc_set_lanes(ry_vc* vc, int lanes) {
     }
     vc->ring = lanes <= 3 ? 6 : 2 * lanes;
     vc->dev_count = 0;
-    if (vc->lane_xcds) {                                  // the lane count changed: back to the whole chip for every lane
-        vc->lane_xcds = 0;
-        for (int k = 0; k < vc->lanes; ++k) { RY_TRY(ry_net_set_cu_mask(vc->l1[k], nullptr, 0)); RY_TRY(ry_net_set_cu_mask(vc->l2[k], nullptr, 0)); }
-    }
-    return RY_OK;
-}
-
-// Every lane gets its own XCDs: with `lanes` = 2 / 4 / 8 lanes, lane k runs on the 8 / lanes XCDs k, k + lanes, ... (compute-unit masks on
-// the streams of its predictor pair; on gfx950 bit i of a CU mask belongs to XCD i % 8).  A window then runs from its first to its last
-// kernel inside the L2s it owns, every layer is several rounds of workgroups on 128 / 64 / 32 CUs (no one-round tails, launch plans
-// rebuilt for that CU count), and the lanes never wait for each other's grids -- at the price of the latency of one window, which
-// grows with the number of lanes.  A throughput setting (a backlog, offline conversion, many sessions); `on` = 0 gives the whole chip
-// back to every lane.  Results do not depend on it beyond summation order (other plans).
-int ry_vc_set_lane_xcds(ry_vc* vc, int on) {
-    if (!vc) return fail(RY_EINVAL, "null argument");
-    if (on && vc->lanes != 2 && vc->lanes != 4 && vc->lanes != 8) return fail(RY_EINVAL, "XCD lanes need 2, 4 or 8 lanes (got %d)", vc->lanes);
-    for (int i = 0; i < vc->ring; ++i)
-        if (vc->slot[i].ticket >= 0) return fail(RY_ESTATE, "ticket %d is still in flight: ry_vc_wait it first", vc->slot[i].ticket);
-    vc->sync_lanes();
-    for (int k = 0; k < vc->lanes; ++k) {
-        unsigned mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (on)
-            for (int cu = 0; cu < 256; ++cu)
-                if ((cu >> 3) % vc->lanes == k) mask[cu >> 5] |= 1u << (cu & 31);   // CU (cu >> 3) of XCD (cu & 7): every lane gets 32 / lanes CUs of EVERY XCD
-        RY_TRY(ry_net_set_cu_mask(vc->l1[k], on ? mask : nullptr, on ? 8 : 0));
-        RY_TRY(ry_net_set_cu_mask(vc->l2[k], on ? mask : nullptr, on ? 8 : 0));
-    }
-    vc->lane_xcds = on ? 8 / vc->lanes : 0;
     return RY_OK;
 }
 

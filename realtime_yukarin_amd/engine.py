@@ -127,7 +127,6 @@ class VcCore(object):
         stage1._dependents.add(self); stage2._dependents.add(self)       # `ry_vc` holds raw pointers to both predictors: they must outlive it (Net.close)
         self._pending = {}
         self.discard = (0, 0)
-        self.lane_xcds = 0
         # lanes: the six ring slots spread over two pairs of predictor handles (`ry_vc_set_lanes`), so that two windows really run side by side
         # (RY_VC_LANES=1: one stage-2 forward after the other; 3 measured slower than 2)
         self.lanes = int(os.environ.get('RY_VC_LANES', '2')) if lanes is None else int(lanes)
@@ -157,18 +156,11 @@ class VcCore(object):
     def set_lanes(self, lanes: int):
         self.lib.check(self.lib.dll.ry_vc_set_lanes(self.handle, int(lanes)))
         self.lanes = int(lanes)
-        self.lane_xcds = 0
 
     @property
     def ring(self) -> int:
         """Windows that may be in flight: six ring slots up to three lanes, else two per lane."""
         return 6 if self.lanes <= 3 else 2 * self.lanes
-
-    def set_lane_xcds(self, on: bool = True):
-        """`ry_vc_set_lane_xcds`: with 2 / 4 / 8 lanes, every lane on its own 4 / 2 / 1 XCDs (a throughput setting: no lane waits for another's
-        one-round grids, every layer is several rounds of workgroups on its share of the chip; the latency of one window grows with the lanes)."""
-        self.lib.check(self.lib.dll.ry_vc_set_lane_xcds(self.handle, int(bool(on))))
-        self.lane_xcds = (8 // self.lanes) if on else 0
 
     @staticmethod
     def _rows(effective):

@@ -245,29 +245,21 @@ def test_closing_a_predictor_takes_its_window_cores_with_it(emu_ctx, monkeypatch
             c.convert(x[e], e)                          # a closed core raises in Python; it never reaches the library with a dangling handle
 
 
-def test_eight_lanes_on_their_own_xcds_return_the_same_windows(emu_ctx):
-    """`ry_vc_set_lanes(8)` + `ry_vc_set_lane_xcds`: sixteen ring slots, two per lane, every lane's streams masked to one XCD (the emulator
-    ignores the mask; the ring, the lane rotation and the plan rebuild are what is checked here): the same windows come back, in order."""
+def test_eight_lanes_sixteen_ring_slots(emu_ctx):
+    """`ry_vc_set_lanes(8)`: sixteen ring slots, two per lane (a throughput setting, measured 1 % ahead of two lanes at 300 frames): the ring,
+    the lane rotation and the clones are what is checked here -- the same windows come back, in order, with nine in flight."""
     (d1, P1), (d2, P2) = synth.model_params('SYN-8')
     n1 = engine.Net(emu_ctx, d1, flatten_params(d1, P1))
     n2 = engine.Net(emu_ctx, d2, flatten_params(d2, P2), width=128)
     mtx = sptk.mc2sp_matrix(8, sptk.mcepalpha(16000), 256)
-    wins = [window(12 + (i % 3), 80 + i) for i in range(5)]
+    wins = [window(10 + (i % 2), 80 + i) for i in range(3)]
     one = engine.VcCore(n1, n2, mtx, lanes=1)
     ref = [one.convert(x[e], e) for x, e in wins]
     one.close()
     c = engine.VcCore(n1, n2, mtx, lanes=8)
     assert c.ring == 16
-    with pytest.raises(_lib.Ry355Error, match='2, 4 or 8 lanes'):
-        engine.VcCore(n1, n2, mtx, lanes=3).set_lane_xcds(True)
-    c.set_lane_xcds(True)
-    assert c.lane_xcds == 1
-    tickets = [c.submit(x[e], e) for x, e in wins + wins + wins]              # fifteen windows in flight (sixteen slots)
+    tickets = [c.submit(x[e], e) for x, e in wins * 3]                         # nine windows in flight: more than the six slots of the default ring
     got = [c.wait(t) for t in tickets]
     for i, (mc, sp) in enumerate(got):
-        rmc, rsp = ref[i % 5]
-        assert numpy.array_equal(mc, rmc) and float(numpy.abs(sp / rsp - 1).max()) < 1e-5
-    c.set_lane_xcds(False)
-    mc, sp = c.convert(*[(x[e], e) for x, e in wins][0])
-    assert numpy.array_equal(sp, ref[0][1])
+        assert numpy.array_equal(mc, ref[i % 3][0]) and numpy.array_equal(sp, ref[i % 3][1])
     c.close(); n1.close(); n2.close()
