@@ -220,7 +220,7 @@ int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat*
 int ry_net_profile_window(ry_net* net, int n_frames, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats);
 
 /* diagnostics: ratio[i * n + j] = wall time of a `us`-microsecond spin kernel on each of two fresh streams i and j, divided by `us`:
- * ~1 when the two streams run side by side, ~2 when one waits for the other (scripts/gpu_r2_queues.py). */
+ * ~1 when the two streams run side by side, ~2 when one waits for the other (scripts/gpu_queues.py). */
 int ry_debug_stream_overlap(ry_ctx* ctx, int n, int us, float* ratio);
 
 /* diagnostics: the launch configuration the stage-2 planner picks for an implicit-GEMM layer with M output rows (pixels of

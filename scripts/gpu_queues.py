@@ -1,4 +1,4 @@
-"""Which pairs of fresh HIP streams run side by side on this box?  usage: python scripts/gpu_r2_queues.py [n_streams] [torch]"""
+"""Which pairs of fresh HIP streams run side by side on this box?  usage: python scripts/gpu_queues.py [n_streams] [torch]"""
 import os, sys
 from pathlib import Path
 import numpy
