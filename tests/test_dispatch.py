@@ -167,3 +167,23 @@ def test_dispatcher_with_one_gpu_and_the_rccl_broadcast_gpu(tmp_path, gpu_ctx):
     assert [i for i, _ in got] == [100, 101, 102, 103] and workers == [0, 0, 0, 0]
     for (_, out), (wave, feat, _) in zip(got, wins):
         e2e.check(out, e2e.expected(t1, t2, ac.f0_converter, wave, feat, 300, 60), 300, 'dispatcher G=1 (RCCL broadcast)')
+
+
+@pytest.mark.gpu
+def test_two_worker_processes_on_one_gpu_gpu(tmp_path, gpu_ctx):
+    """G = 2 worker PROCESSES on the real hardware -- both on GPU 0, the only one of the box, so the weights go to each by pickle
+    (`comm='host'`; RCCL refuses two ranks on one device): two HIP contexts, two window cores, the shared-memory rings, round-robin
+    hand-out and in-order release against the composed oracle, and against the single-worker run bit for bit."""
+    from oracle import torch_ref
+    P1, P2 = e2e.write_models(tmp_path, 'SYN-64')
+    ac, sr = e2e.build_converters(tmp_path)
+    t1, t2 = torch_ref.TorchUNet(P1), torch_ref.TorchUNet(P2)
+    wins = windows(300, 6)
+    two, workers, _ = run(ac, sr, [0, 0], wins, None, comm='host', pad=100)
+    one, _, _ = run(ac, sr, [0], wins, None, comm='host', pad=100)
+    assert workers == [0, 1, 0, 1, 0, 1] and [i for i, _ in two] == list(range(100, 106))
+    for (_, a), (_, b), (wave, feat, _) in zip(two, one, wins):
+        assert a.sp.shape == (100, 513) and all(numpy.array_equal(getattr(a, k), getattr(b, k)) for k in KEYS)
+        exp = e2e.expected(t1, t2, ac.f0_converter, wave, feat, 300, 60)
+        assert float(numpy.abs(a.sp.astype(numpy.float64) / exp['sp'][100:200] - 1).max()) < 1e-4           # the kept frames of the window
+        assert float(numpy.abs(a.mc - exp['mc'][100:200]).max() / numpy.abs(exp['mc']).max()) < 1e-4
