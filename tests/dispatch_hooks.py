@@ -13,7 +13,7 @@ def emu_hook(rank):
 
     def per_window(index):
         if rank == 0:
-            time.sleep(0.25)
+            time.sleep(0.2)
     return per_window
 
 
