@@ -27,8 +27,10 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 OUT = sys.argv[2] if len(sys.argv) > 2 else str(ROOT / 'gpurun_out' / ('r3_lanesweep_n%d.txt' % N))
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 80
 NAMES = ['encoder/c%d' % i for i in range(8)] + ['decoder/c%d' % i for i in range(8)]
-TILES = {1: '128x128', 6: '96x128', 3: '64x128', 5: '128x64', 2: '256x64'}
-LAYERS = (12, 13, 14, 11, 1, 2, 3, 4)                                # biggest first
+TILES = {1: '128x128', 6: '96x128', 3: '64x128', 5: '128x64', 4: '32x128'}
+LAYERS = tuple(int(v) for v in os.environ.get('SWEEP_LAYERS', '12,13,14,11,1,2,3,4').split(','))     # default: the eight MFMA-bound layers, biggest first
+SWEEP_TILES = tuple(int(v) for v in os.environ['SWEEP_TILES'].split(',')) if os.environ.get('SWEEP_TILES') else None
+SWEEP_SPLITS = tuple(int(v) for v in os.environ.get('SWEEP_SPLITS', '1,2,3,4').split(','))
 
 EMU = bool(os.environ.get('SWEEP_EMU'))                             # flow check of this script on the CPU emulator (numbers mean nothing)
 (d1, P1), (d2, P2) = synth.model_params('SYN-8' if EMU else 'SYN-64')
@@ -108,10 +110,10 @@ def plan_str(extra=None):
 cur = b2
 for layer in LAYERS:
     cands = []
-    tiles = (5, 2) if layer == 14 else (6, 1, 3)
+    tiles = SWEEP_TILES if SWEEP_TILES else ((5,) if layer == 14 else (6, 1, 3))
     for tile in tiles[:1] if EMU else tiles:
-        for kg in ((1,) if tile == 2 or EMU else (1, 2)):
-            for sp in (1,) if EMU else (1, 2, 3, 4):
+        for kg in ((1,) if EMU else (1, 2)):
+            for sp in (1,) if EMU else SWEEP_SPLITS:
                 cands.append('%d:%d:%d' % (tile, sp, kg))
     best = (cur, None)
     for c in cands:
