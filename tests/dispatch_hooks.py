@@ -21,3 +21,15 @@ def dying_hook(rank):
     emu_hook(rank)
     if rank == 1:
         raise RuntimeError('worker %d cannot see its GPU' % rank)
+
+
+def failing_window_hook(rank):
+    """Worker 0 fails on its second window (after start-up): the dispatcher must report it to the caller instead of waiting for ever."""
+    emu_hook(rank)
+    seen = []
+
+    def per_window(index):
+        seen.append(index)
+        if rank == 0 and len(seen) == 2:
+            raise RuntimeError('window %d: device lost' % index)
+    return per_window

@@ -23,7 +23,7 @@ REF = Path('/root/reference')
 KEYS = ('f0', 'ap', 'sp', 'voiced', 'mc')
 
 
-from dispatch_hooks import dying_hook, emu_hook      # top-level functions of a LIGHT module: every spawned worker imports the module of its hook
+from dispatch_hooks import dying_hook, emu_hook, failing_window_hook      # top-level functions of a LIGHT module: every spawned worker imports the module of its hook
 
 
 def windows(n_frames, count):
@@ -87,6 +87,22 @@ def test_a_dead_worker_is_reported_not_waited_for(tmp_path):
     with pytest.raises(RuntimeError, match='cannot see its GPU|exited with code'):
         dispatch.ChunkDispatcher(ac, sr, [0, 0], comm='host', worker_hook=dying_hook, start_timeout=600)
     assert time.time() - t0 < 300
+
+
+def test_a_worker_that_fails_mid_stream_is_reported(tmp_path):
+    """An exception inside a worker after start-up (the reference's loop has no try / except either, convert_worker.py:45-59: the worker
+    dies) reaches the caller of `collect` as a RuntimeError carrying the worker's traceback; the dispatcher closes itself."""
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    wins = windows(24, 3)
+    d = dispatch.ChunkDispatcher(ac, sr, [0], threshold=60, comm='host', worker_hook=failing_window_hook, start_timeout=600)
+    with pytest.raises(RuntimeError, match='device lost'):
+        for i, (_, _, f) in enumerate(wins):
+            d.submit(i, f)
+        d.drain(timeout=300)
+    assert d.closed
+    with pytest.raises(RuntimeError, match='closed'):
+        d.submit(9, wins[0][2])
 
 
 def test_weightless_copies_for_the_broadcast_receivers(tmp_path):
