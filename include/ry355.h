@@ -107,7 +107,7 @@ int ry_conv1d(ry_ctx* ctx, const float* x, int B, int L, int Cin, const float* W
               int Cout, int k, int stride, int pad, int dilate, int transposed, int act, int splits, float* y);
 /* L.Convolution2D / L.Deconvolution2D.  x [B][H][W][Cin] -> y [B][Ho][Wo][Cout].  path: 0 auto, 1 implicit-GEMM (MFMA),
  * 2 direct (VALU), 3 SR first layer (1 -> N, 3x3), 4 SR last layer (C -> 1, 3x3, channels read as two sources), 5 implicit-GEMM with bf16 operands,
- * 6 implicit-GEMM in split-bf16 form (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate; the input is split on the host here); tile: 0 auto, 1 = 128x128, 2 = 256x64, 3 = 64x128, 4 = 32x128, 5 = 128x64, 6 = 96x128, 7 = 256x128. */
+ * 6 implicit-GEMM in split-bf16 form (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate; the input is split on the host here); tile: 0 auto, 1 = 128x128, 3 = 64x128, 4 = 32x128, 5 = 128x64, 6 = 96x128 (+16: two K groups per workgroup, +32: one). */
 int ry_conv2d(ry_ctx* ctx, const float* x, int B, int H, int W, int Cin, const float* Wt, const float* bias, const float* bn,
               int Cout, int k, int stride, int pad, int transposed, int act, int path, int tile, int splits, float* y);
 /* the same with a dilation (plain convolution on the implicit-GEMM or the direct path): out = (H + 2 pad - dilate (k - 1) - 1) / stride + 1 */
