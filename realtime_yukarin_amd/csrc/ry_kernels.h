@@ -1287,7 +1287,7 @@ struct RyC1dOsParams {
     int tiles;                  // position tiles per window (one tile = PG x TP rows) = gridDim.y; gridDim.z = windows
     int kt_shift;               // log2 of the waves that share one position group (0 / 1 / 2 for <= 64 / <= 128 / more input channels)
     int n_real;                 // PADMIN instantiations: real rows per window in `sa`; rows n_real .. Lin - 1 are the per-channel minimum
-    unsigned long long* dbg;    // diagnostics (RY_S1_TIMING=1): per-workgroup s_memtime stamps at the phase boundaries, else null
+    unsigned long long* dbg;    // diagnostics (-DRY_S1_STAMPS builds): per-workgroup s_memtime stamps at the phase boundaries, else null
 };
 
 // Keeps two values in separate registers: without it the compiler rewrites `c ? v[a] : v[b]` on a register array into a
@@ -1354,7 +1354,7 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = ry_uniform(tid >> 6);
 #if defined(RY_HOST_EMU) || !defined(RY_S1_STAMPS)
 #define RY_OS_STAMP(i)
-#else       // diagnostic build (-DRY_S1_STAMPS, RY_S1_TIMING=1): s_memtime at the phase boundaries, one record per workgroup
+#else       // diagnostic build (-DRY_S1_STAMPS): s_memtime at the phase boundaries, one record per workgroup
     unsigned long long* const dbgp = p.dbg ? p.dbg + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 : nullptr;
 #define RY_OS_STAMP(i) if (dbgp && tid == 0) dbgp[i] = __builtin_amdgcn_s_memtime();
 #endif

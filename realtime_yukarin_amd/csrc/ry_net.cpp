@@ -911,7 +911,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
                 if (bm % tw == 0 && Mw % tw == 0 && Mh % (bm / tw) == 0) { const int th = bm / tw; r0 = r0 / th * th; r1 = (r1 + th - 1) / th * th; break; }
             if (r1 > lp.Hi) r1 = lp.Hi;
             if (r0 <= 0 && r1 >= lp.Hi) break;
-            // measured at 300 frames (scripts/gpu_r2_ab3.sh): decoder c6 (1536 -> 1216 workgroups, six per CU -> five) 208 -> 177 us, decoder c5
+            // measured at 300 frames (round 2, interleaved A/B on one box): decoder c6 (1536 -> 1216 workgroups, six per CU -> five) 208 -> 177 us, decoder c5
             // (512 -> 416, two per CU) 198 -> 193 us, decoder c4 (256 -> 224, one per CU) 196 -> 194 us: a grid of one workgroup per CU
             // gains nothing by itself, but the CUs it leaves idle go to the window on the other lane (ry_vc_set_lanes): 1.160 -> 1.137 ms
             // per window with two lanes, so it is cropped too (RY_S2_CROP=1 keeps such grids whole)
@@ -1155,7 +1155,7 @@ int ry_device_count(void) {
 
 // process-wide A/B and diagnostic switches, read when a context is created
 // RY_PLAN="layer:tile:splits:kgroups,...": read when a context is created and again at every ry_net_set_dtype (which drops
-// the launch plans), so that one process can sweep plans (scripts/gpu_x3_plansweep.py)
+// the launch plans), so that one process can sweep plans (scripts/gpu_x3_plansweep.py, scripts/gpu_r3_lanesweep.py)
 static int read_plan_env() {
     memset(g_force, 0, sizeof(g_force));
     if (const char* e = getenv("RY_PLAN")) {
@@ -1226,7 +1226,7 @@ int ry_timer_start(ry_ctx* ctx) {
     if (!ctx) return fail(RY_ESTATE, "null context");
     // Everything queued so far is waited for on the HOST, then t0 is recorded and waited for: whatever is enqueued afterwards starts after
     // t0 without a cross-stream wait.  (The former form -- every predictor stream waits on t0 with hipStreamWaitEvent -- left the two
-    // window lanes of ry_vc serialised for the rest of the run: 1.32 instead of 1.16 ms per window, scripts/gpu_r2_lanes_ab.sh.)
+    // window lanes of ry_vc serialised for the rest of the run: 1.32 instead of 1.16 ms per window, round 2.)
     for (ry_net* n : ctx->nets) RT_TRY(rt::stream_sync(n->stream));
     RT_TRY(rt::stream_sync(ctx->stream));
     RT_TRY(rt::event_record(ctx->t0, ctx->stream));
