@@ -60,6 +60,8 @@ def build_emu(force: bool = False) -> Path:
         cxx = '/opt/rocm/lib/llvm/bin/clang++'
         if not Path(cxx).exists():
             cxx = shutil.which('clang++') or shutil.which('g++')
+        # plain -O2 on purpose: with AVX-512 enabled (-march=native on this host) ROCm's clang drops the tail of the fminf chain in
+        # ry_pad_min_rows<16> (the remainder after the 8-wide gather is only run when a NaN was seen) -- found with the emulator tests
         objs = _compile_units(cxx, ['-x', 'c++', '-DRY_HOST_EMU', '-O2', '-std=c++17', '-fPIC', '-pthread', '-Wno-psabi',
                                     '-I' + str(EMU_DIR), '-I' + str(CSRC)], ROOT / 'gpurun_out' / '_obj', '_emu', [EMU_DIR / 'ry_emu.cpp'])
         tmp = EMU_LIB.with_suffix('.so.tmp%d' % os.getpid())              # several test workers may build at once: link aside, then rename

@@ -1,7 +1,9 @@
 // ry_emu.cpp -- fiber scheduler of the host-side SIMT emulator.  TEST INFRASTRUCTURE ONLY.
 #include "ry_emu.h"
 
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 
 #include <atomic>
 #include <cstdio>
@@ -16,15 +18,54 @@ namespace {
 constexpr size_t kStack = 256 * 1024;
 constexpr int kMaxWaves = 16;
 
+#if defined(__x86_64__)
+// A context switch without system calls: glibc's swapcontext saves and restores the signal mask with two rt_sigprocmask calls per switch,
+// and a 64-lane wave exchanging operands for ONE emulated MFMA switches ~250 times -- the system calls were most of the CPU suite's time.
+// ry_ctx_switch(&save_sp, new_sp): push the callee-saved registers + mxcsr / x87 control word, store the stack pointer, load the other one,
+// pop, return.  A fresh fiber's stack is prepared so that the first switch to it "returns" into fiber_entry.
+extern "C" void ry_ctx_switch(void** save_sp, void* new_sp);
+asm(R"(
+    .text
+    .globl ry_ctx_switch
+    .type ry_ctx_switch,@function
+ry_ctx_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size ry_ctx_switch, .-ry_ctx_switch
+)");
+struct Context { void* sp = nullptr; };
+#else
+struct Context { ucontext_t uc; };
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Context ctx;
     char* stack = nullptr;
     bool done = false;
 };
 
 struct State {
     std::vector<Fiber> fibers;
-    ucontext_t sched;
+    Context sched;
     int cur = 0;
     int nthreads = 0;
     int live = 0;                      // fibers that have not returned yet: a barrier waits for these only (like the hardware)
@@ -36,15 +77,49 @@ struct State {
 };
 thread_local State* S = nullptr;
 
-void yield_to_sched() { swapcontext(&S->fibers[S->cur].ctx, &S->sched); }
+#if defined(__x86_64__)
+void switch_ctx(Context& from, Context& to) { ry_ctx_switch(&from.sp, to.sp); }
+#else
+void switch_ctx(Context& from, Context& to) { swapcontext(&from.uc, &to.uc); }
+#endif
+
+void yield_to_sched() { switch_ctx(S->fibers[S->cur].ctx, S->sched); }
 
 void trampoline() {
     (*S->body)();
     S->fibers[S->cur].done = true;
     // a thread that returns no longer takes part in barriers: release one that was only waiting for it
     if (--S->live > 0 && S->bar_arrived == S->live) { S->bar_arrived = 0; ++S->bar_gen; }
-    // falls through to uc_link (= scheduler)
+    // back to the scheduler (x86-64: explicitly, for good; else through uc_link)
+#if defined(__x86_64__)
+    for (;;) yield_to_sched();
+#endif
 }
+
+#if defined(__x86_64__)
+void fiber_entry() { trampoline(); }
+
+void prepare(Fiber& f, Context&) {
+    // [A] = return address (fiber_entry), below it six zeroed callee-saved registers and the default mxcsr / x87 control word;
+    // A is 16-byte aligned, so that fiber_entry starts with the stack alignment of a called function
+    uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+    uint64_t* A = (uint64_t*)(top - 16);
+    A[0] = (uint64_t)(uintptr_t)&fiber_entry;
+    for (int i = 1; i <= 6; ++i) A[-i] = 0;
+    uint32_t* cw = (uint32_t*)(A - 7);
+    cw[0] = 0x1F80u;                   // mxcsr: all exceptions masked, round to nearest
+    cw[1] = 0x037Fu;                   // x87 control word
+    f.ctx.sp = (void*)(A - 7);
+}
+#else
+void prepare(Fiber& f, Context& sched) {
+    getcontext(&f.ctx.uc);
+    f.ctx.uc.uc_stack.ss_sp = f.stack;
+    f.ctx.uc.uc_stack.ss_size = kStack;
+    f.ctx.uc.uc_link = &sched.uc;
+    makecontext(&f.ctx.uc, (void (*)())trampoline, 0);
+}
+#endif
 
 int wave_size(int w) {
     int lo = w * 64, hi = lo + 64;
@@ -77,11 +152,7 @@ void run_block(State& st, dim3 bidx, dim3 grid, dim3 block) {
         Fiber& f = st.fibers[i];
         if (!f.stack) f.stack = (char*)malloc(kStack);
         f.done = false;
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = kStack;
-        f.ctx.uc_link = &st.sched;
-        makecontext(&f.ctx, (void (*)())trampoline, 0);
+        prepare(f, st.sched);
     }
     g_blockIdx = bidx;
     g_gridDim = grid;
@@ -93,7 +164,7 @@ void run_block(State& st, dim3 bidx, dim3 grid, dim3 block) {
             if (f.done) continue;
             st.cur = i;
             g_threadIdx = dim3((unsigned)i, 0, 0);
-            swapcontext(&st.sched, &f.ctx);
+            switch_ctx(st.sched, f.ctx);
             g_threadIdx = dim3((unsigned)i, 0, 0);
             if (f.done) --remaining;
         }

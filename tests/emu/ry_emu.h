@@ -1,7 +1,7 @@
 // ry_emu.h -- host-side SIMT emulator for the gfx950 kernel sources.  TEST INFRASTRUCTURE ONLY.
 //
 // Compiles realtime_yukarin_amd/csrc/*.h kernels as plain C++ (-DRY_HOST_EMU): every GPU thread is
-// a cooperative fiber (ucontext), a workgroup is a set of fibers on one OS thread, `__shared__` is a
+// a cooperative fiber (own x86-64 context switch; ucontext elsewhere), a workgroup is a set of fibers on one OS thread, `__shared__` is a
 // thread_local static shared by those fibers, `__syncthreads()` / wave collectives are fiber
 // rendezvous, and v_mfma_f32_32x32x2_f32 is emulated with the fragment maps documented in
 // /opt/skills/guides/cdna_hip_programming.md section 3.  Used by tests/ (-m "not gpu") to check kernel index
