@@ -276,7 +276,8 @@ static void tile_dims(int tile, int* bm, int* bn) {
 // Process-wide switches (INTEGRATION.md section 6 lists every one).  Round 3 removed the A/B switches of closed experiments (register-staged
 // kernel, 256-row tiles, burst loads, raster tiles, two-graph cut + stagger, stage-1 tuning aids, ...): their measurements are in DESIGN.md.
 static int g_s2_crop = 2;     // RY_S2_CROP=0: every decoder layer of the convert wrapper computes all padded rows (A/B of the dead-row crop, used by the bit-identity tests); 1: only grids of more than one workgroup per CU
-static int g_igemm_dbg = 0;   // RY_IGEMM_DBG: ablation bits of ry_igemm_ldsdma (diagnostics; WRONG results): 4 no stores, 8 no K loop, 128 no loads in the K loop
+static int g_igemm_dbg = 0;   // RY_IGEMM_DBG: ablation bits (diagnostics; WRONG results): ry_igemm_ldsdma 4 no stores, 8 no K loop, 128 no loads in the K loop;
+                              // stage-2 forward: 16 no split-K reduce launches, 32 no encoder c5 .. decoder c2 (scripts/gpu_r3_ablate.sh)
 static int g_force[16][3];    // RY_PLAN="layer:tile:splits:kgroups,...": tuning aid, fixes the stage-2 plan of single layers (0 = planner's choice)
 static int g_x3_min_m = 128;  // RY_X3_MINM: split-bf16 mode runs a layer on the bf16 pipe from this many GEMM rows (per phase) up (measured at 300 frames: 1 / 32 / 64 / 128 / 512 / 2048 -> 0.861 / 0.865 / 0.867 / 0.864 vs 0.840 / 0.928 ms per step on two boxes; 128 beat 512 by 1 % in the same-box A/B)
 static int g_autotune = 0;    // RY_AUTOTUNE="1[:reps[:max[:pick]]]": time candidate launch plans of every stage-2 implicit-GEMM layer on the device when a plan is built (autotune_plan)
@@ -506,7 +507,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         }
 #undef RY_IGEMM_LAUNCH
         RY_TRY(Lc.end());
-        if (lp.splits > 1) {
+        if (lp.splits > 1 && !(g_igemm_dbg & 16)) {
             RyReduceParams r;
             const size_t ro = B == 1 ? oo : 0;                                    // one window: only the rows this launch wrote
             r.slabs = lp.slabs + ro; r.splits = lp.splits; r.slab_stride = p.slab_stride;
@@ -923,6 +924,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
     for (int i = lo; i < hi; ++i) {
         const Layer& l = net->layers[i];
         const LayerPlan& lp = P.lp[i];
+        if ((g_igemm_dbg & 32) && nd == 2 && i >= 5 && i <= 10) continue;
         if (nd == 1 && P.s1_os) {
             const bool fused_pad = l.src_a < 0 && padfuse_now;
             const float* sa = l.src_a < 0 ? ((P.mode == 1 && !padfuse_now) ? P.x_in : P.cur_in) : P.lp[l.src_a].out;
