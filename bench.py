@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-split-bf16', action='store_true', help="skip the extra 'split_bf16' measurement of an f32 run")
     ap.add_argument('--no-extras', action='store_true', help='headline + roofline only (no host-path, cold-cache, batch or gate measurements)')
+    ap.add_argument('--chained-batch', default='8', help='windows per call of the batched window call measured next to the headline (comma-separated)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--profile-reps', type=int, default=5)
     ap.add_argument('--profile-only', action='store_true', help='only print the per-kernel-family profile of stage-2 (tuning aid)')
@@ -455,22 +456,22 @@ def main(argv=None):
                                                 'max_rel_diff_vs_single_window': float(numpy.abs(yb.astype(numpy.float64) / ref1 - 1.0).max())}
                 ctx.dev_free(d_b_in); ctx.dev_free(d_b_out)
             # the whole chained window call for 8 windows at once (ry_vc_enqueue_device_batch): stage 1 as one batch, the hop on the device, stage 2 as one batch
-            bw = 8
-            xb = synth.stage1_input(N, max(NW, Wn), seed=synth.SEED_INPUT + 10 * rank)[:bw].copy()
-            xb[0] = x_checked                                                        # window 0 is the window the timed step converted last
-            d_bx = ctx.dev_alloc(bw * N * d1.in_ch); d_br = ctx.dev_alloc(bw * N)
-            d_bmc = ctx.dev_alloc(bw * N * d1.out_ch); d_bsp = ctx.dev_alloc(bw * N * synth.FFT_BINS)
-            ctx.dev_upload(d_bx, xb); ctx.dev_upload(d_br, numpy.tile(rows_host, bw))
-            cb_ms = time_only(lambda: core.enqueue_device_batch(d_bx, d_br, [N] * bw, N, d_bmc, d_bsp, SP_FLOOR), reps=10)
-            spb = numpy.empty((bw, N, synth.FFT_BINS), numpy.float32); ctx.dev_download(d_bsp, spb)
-            out['chained_batch8'] = {'windows_per_call': bw, 'ms_per_call': round(cb_ms, 4), 'ms_per_window': round(cb_ms / bw, 4),
-                                     'frames_per_s': round(bw * N / (cb_ms * 1e-3), 1), 'x_realtime': round(bw * N / (cb_ms * 1e-3) * 0.005, 1),
-                                     'effective_x_realtime': round(bw * (N - 2 * extra) * 0.005 / (cb_ms * 1e-3), 1),
-                                     'max_rel_diff_window0_vs_timed_step': float(numpy.abs(spb[0].astype(numpy.float64) / sp_gpu - 1.0).max()),
-                                     'note': 'the same chained core on 8 independent windows per call (streams served side by side / a backlog); not the headline: '
-                                             'the headline step is one 0.5 s buffer at a time, as the reference converts'}
-            for q in (d_bx, d_br, d_bmc, d_bsp):
-                ctx.dev_free(q)
+            for bw in [int(v) for v in args.chained_batch.split(',') if v]:
+                xb = synth.stage1_input(N, max(NW, Wn, bw), seed=synth.SEED_INPUT + 10 * rank)[:bw].copy()
+                xb[0] = x_checked                                                        # window 0 is the window the timed step converted last
+                d_bx = ctx.dev_alloc(bw * N * d1.in_ch); d_br = ctx.dev_alloc(bw * N)
+                d_bmc = ctx.dev_alloc(bw * N * d1.out_ch); d_bsp = ctx.dev_alloc(bw * N * synth.FFT_BINS)
+                ctx.dev_upload(d_bx, xb); ctx.dev_upload(d_br, numpy.tile(rows_host, bw))
+                cb_ms = time_only(lambda: core.enqueue_device_batch(d_bx, d_br, [N] * bw, N, d_bmc, d_bsp, SP_FLOOR), reps=10)
+                spb = numpy.empty((bw, N, synth.FFT_BINS), numpy.float32); ctx.dev_download(d_bsp, spb)
+                out['chained_batch%d' % bw] = {'windows_per_call': bw, 'ms_per_call': round(cb_ms, 4), 'ms_per_window': round(cb_ms / bw, 4),
+                                         'frames_per_s': round(bw * N / (cb_ms * 1e-3), 1), 'x_realtime': round(bw * N / (cb_ms * 1e-3) * 0.005, 1),
+                                         'effective_x_realtime': round(bw * (N - 2 * extra) * 0.005 / (cb_ms * 1e-3), 1),
+                                         'max_rel_diff_window0_vs_timed_step': float(numpy.abs(spb[0].astype(numpy.float64) / sp_gpu - 1.0).max()),
+                                         'note': 'the same chained core on %d independent windows per call (streams served side by side / a backlog); not the headline: '
+                                                 'the headline step is one 0.5 s buffer at a time, as the reference converts' % bw}
+                for q in (d_bx, d_br, d_bmc, d_bsp):
+                    ctx.dev_free(q)
             # the same step when the caller announces the frames it will throw away (ConvertStream.process keeps the buffer in the middle of
             # the window it converted; worker.convert_worker passes its pad): stage 2 computes the kept rows only.  NOT the headline -- the
             # headline returns every frame of every window -- but what a live stream built on the mirror worker runs.
