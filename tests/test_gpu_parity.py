@@ -307,6 +307,18 @@ def test_device_resident_voice_changer_core(syn64):
         mc2, _ = core.convert(x[eff], eff)
         ref2 = numpy.zeros_like(mc_ref); ref2[eff] = torch_ref.stage1_convert_core(t1, x[eff])
         assert rel_max(mc2, ref2) < cases.TOL
+    # the ragged ends: no effective frame at all (voice_changer.py:32-35: the stage-1 CNN is not called, mc stays the all-silent zeros and
+    # stage 2 converts mc2sp(0) + 1e-16), and a single effective frame (stage 1 pads 1 -> 128 with that frame)
+    none = numpy.zeros(n, bool)
+    mc0, sp0 = core.convert(x[none], none)
+    flat = (omc.mc2sp(numpy.zeros((n, synth.MC_DIMS)), omc.mcepalpha(16000), 1024) + 1e-16).astype(numpy.float32)
+    assert not mc0.any() and float(numpy.abs(sp0 / torch_ref.stage2_convert(t2, flat) - 1).max()) < cases.TOL
+    lone = none.copy(); lone[137] = True
+    mc1, sp1 = core.convert(x[lone], lone)
+    ref1 = numpy.zeros_like(mc_ref); ref1[lone] = torch_ref.stage1_convert_core(t1, x[lone])
+    assert rel_max(mc1, ref1) < cases.TOL and not mc1[~lone].any()
+    sp1_ref = torch_ref.stage2_convert(t2, (omc.mc2sp(ref1, omc.mcepalpha(16000), 1024) + 1e-16).astype(numpy.float32))
+    assert float(numpy.abs(sp1 / sp1_ref - 1).max()) < cases.TOL
     core.close()
 
 
