@@ -232,8 +232,8 @@ class VcCore(object):
     def convert_stream(self, windows, sp_floor: float = 1e-16, depth: int = 2):
         """Generator over (x_eff, effective) pairs -> (mc, sp) in order, keeping `depth` windows in flight: the copies of one window
         run under the kernels of another."""
-        if not 1 <= depth <= 6:
-            raise ValueError('depth must be 1..6 (six ring slots up to three lanes)')
+        if not 1 <= depth <= self.ring:
+            raise ValueError('depth must be 1..%d (six ring slots up to three lanes, else two per lane)' % self.ring)
         tickets = []
         for x_eff, effective in windows:
             tickets.append(self.submit(x_eff, effective, sp_floor))

@@ -357,6 +357,11 @@ def test_window_call_lanes_discard_and_batch(syn64):
         assert float(numpy.abs(sp / rsp - 1).max()) < 1e-5 and float(numpy.abs(mc - rmc).max()) <= 1e-5 * float(numpy.abs(rmc).max())
     mc, sp = core.convert(*wins[0])
     assert numpy.array_equal(sp, ref[0][1])
+    core.set_lanes(4)                                                           # four lanes, eight ring slots: still the same bits
+    assert core.ring == 8
+    got = list(core.convert_stream(wins + wins, depth=8))
+    for (mc, sp), (rmc, rsp) in zip(got, ref + ref):
+        assert numpy.array_equal(mc, rmc) and numpy.array_equal(sp, rsp)
     core.close()
 
 
