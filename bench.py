@@ -39,6 +39,12 @@ def parse(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--repeats', type=int, default=7,
+                    help='the K-step bracket is timed this many times back to back (same K, same fences); `value` comes from the MEDIAN bracket, every '
+                         'bracket is listed in `brackets`')
+    ap.add_argument('--details-out', default=None,
+                    help='file for the long form of the result (per-kernel table, batch / host-path / discard measurements, notes); default '
+                         'gpurun_out/bench_details_<N>gpu.json.  The printed line carries the headline, the brackets and the roofline objects only')
     ap.add_argument('--frames', type=int, default=300, help='real frames per window (N)')
     ap.add_argument('--extra-frames', type=int, default=None,
                     help='overlap frames on EACH side of the window that ConvertStream throws away (convert_stream.py:40-42); default 100 '
@@ -208,8 +214,8 @@ def main(argv=None):
             wsets[kind].append(dict(d_x=dx, d_rows=dr, n_eff=int(len(rows)), eff=eff, w=w))
     d_x = [q['d_x'] for q in wsets['all']]
     d_rows = wsets['all'][0]['d_rows']
-    # windows that are in flight together write their own result blocks (six ring slots)
-    NB = 6 * Wn
+    # windows that are in flight together write their own result blocks: one block per ring slot (six up to three lanes, else two per lane)
+    NB = core.ring * Wn
     d_mc = [ctx.dev_alloc(N * d1.out_ch) for _ in range(NB)]
     d_sp = [ctx.dev_alloc(N * synth.FFT_BINS) for _ in range(NB)]
     turn = {'n': 0, 'w0': 0, 'set': 'all', 'win': 0, 'w0_win': 0}
@@ -252,51 +258,66 @@ def main(argv=None):
         sync_all()
 
     primed = {'done': False}
+    import math
+    n_prime = 0 if emu else min(144, NB * NW // math.gcd(NB, NW))         # every (result block, window) pair once: 18 with six ring slots and nine windows
 
-    def timed():
-        # launch plans and captured graphs of every ring slot are built before the warm-up (one-off set-up, like loading the weights)
-        if not primed['done']:
-            for _ in range(0 if emu else 3 * 6):
-                step()
-            primed['done'] = True
-        # W untimed warm-up steps, then exactly K steps between barrier + synchronize fences; the maximum over the ranks
-        for _ in range(args.warmup):
-            step()
-        # Opening bracket: barrier + synchronize (fence), then four more untimed steps and a LOCAL synchronize.  The barrier leaves the chip
-        # idle for as long as the slowest rank and the collective take, and what runs right behind it runs slower for a millisecond or two
-        # (measured: 40 steps at 1.13 -> 1.19 ms per step after a 10 ms pause, with or without torch.distributed; behind a torch.distributed
-        # barrier 1.173 / 1.145 / 1.137 ms with 0 / 2 / 8 such steps; queueing the steps UNDER the barrier instead does not help: 1.179).
-        # The clock starts microseconds after the chip last worked, the ranks as aligned as the barrier left them four steps earlier.
+    def bracket():
+        """ONE timed bracket of exactly K steps: (wall seconds, max over the ranks; seconds to enqueue the steps; device milliseconds between HIP
+        events on rank 0).  Opening: barrier + synchronize (fence), then four more untimed steps and a LOCAL synchronize -- the barrier leaves
+        the chip idle for as long as the slowest rank and the collective take, and what runs right behind it runs slower for a millisecond or two
+        (measured: 40 steps at 1.13 -> 1.19 ms per step after a 10 ms pause, with or without torch.distributed; behind a torch.distributed
+        barrier 1.173 / 1.145 / 1.137 ms with 0 / 2 / 8 such steps; queueing the steps UNDER the barrier instead does not help: 1.179).
+        The clock starts microseconds after the chip last worked, the ranks as aligned as the barrier left them four steps earlier."""
         fence()
         for _ in range(0 if emu else 4):
             step()
         sync_all()
+        ctx.timer_start()                       # every stream is idle: an event on the context stream, nothing joins the lanes
         t0 = time.perf_counter()
-        ctx.timer_start()
         for _ in range(args.steps):
             step()
         t_enq = time.perf_counter() - t0
         sync_all()                              # this rank's K steps are done: its clock stops here; the ranks started together (fence above) and
         el = time.perf_counter() - t0           # the job time is the maximum over the ranks (comm.max below) -- the closing barrier itself is not work
-        fence()
-        el_fenced = time.perf_counter() - t0
-        if os.environ.get('BENCH_DEBUG_FENCE'):
-            print('rank %d: %.3f ms for the steps (%.3f ms to enqueue them), %.3f ms with the closing barrier' % (rank, el * 1e3, t_enq * 1e3, el_fenced * 1e3), file=sys.stderr, flush=True)
-        # device-side stamp AFTER the fence: ry_timer_stop while the lanes still have work queued (an event record on every predictor
-        # stream plus cross-stream waits) was measured to cost the two lanes their overlap for the whole run (1.33 vs 1.16 ms per window)
+        # device-side stamp AFTER the local synchronize: ry_timer_stop while the lanes still have work queued (an event record on every
+        # predictor stream plus cross-stream waits) was measured to cost the two lanes their overlap for the whole run (1.33 vs 1.16 ms)
         dms = ctx.timer_stop()
+        fence()
+        if os.environ.get('BENCH_DEBUG_FENCE'):
+            print('rank %d: %.3f ms for the steps (%.3f ms to enqueue them, %.3f ms between device events), %.3f ms with the closing barrier'
+                  % (rank, el * 1e3, t_enq * 1e3, dms, (time.perf_counter() - t0) * 1e3), file=sys.stderr, flush=True)
         if comm is not None:
             el = comm.max(el)
-        return el, dms
+        return el, t_enq, dms
 
-    elapsed, dev_ms = timed()
+    def timed(repeats=1):
+        """W untimed warm-up steps, then `repeats` brackets of exactly K steps each, back to back.  One bracket of the default K is some tens of
+        milliseconds of chip time: a single one is at the mercy of anything else that touches the box in that instant (round 3's driver run
+        landed on 2.31 ms per step where every other run of the same binary measured 1.13), so the headline is the MEDIAN bracket and every
+        bracket is reported."""
+        # launch plans and captured graphs of every ring slot are built before the warm-up (one-off set-up, like loading the weights)
+        if not primed['done']:
+            for _ in range(n_prime):
+                step()
+            primed['done'] = True
+        for _ in range(args.warmup):
+            step()
+        return [bracket() for _ in range(max(1, repeats))]
+
+    def median_of(brs):
+        els = sorted(b[0] for b in brs)
+        return els[(len(els) - 1) // 2]                                   # the lower middle for an even count: never an average of two brackets
+
+    brs = timed(args.repeats)
+    elapsed = median_of(brs)
+    dev_ms = [b[2] for b in brs if b[0] == elapsed][0]
     sp_gpu = numpy.empty((N, synth.FFT_BINS), numpy.float32); ctx.dev_download(d_sp[turn['w0']], sp_gpu)      # window 0 of the last timed step
     mc_gpu = numpy.empty((N, d1.out_ch), numpy.float32); ctx.dev_download(d_mc[turn['w0']], mc_gpu)
     x_checked = xs_host[turn['w0_win']]                                                                        # ... which converted this input
     assert numpy.isfinite(sp_gpu).all() and numpy.isfinite(mc_gpu).all() and (sp_gpu > 0).all()
     # the same K steps over the 'mixed' set (one window in three cut by the silence gate); every rank runs it (the fences hold barriers)
     turn['set'] = 'mixed'; primed['done'] = False
-    elapsed_mixed, _ = timed()
+    elapsed_mixed = median_of(timed(min(3, args.repeats)))
     # a gated window of that region for the parity check: run the shortest one once more, synchronously, into a block of its own
     qm = wsets['mixed'][8 % len(wsets['mixed'])]
     sync_all(); core.enqueue_device(qm['d_x'], qm['d_rows'], qm['n_eff'], N, d_mc[0], d_sp[0], SP_FLOOR); sync_all()
@@ -304,7 +325,7 @@ def main(argv=None):
     mc_gated = numpy.empty((N, d1.out_ch), numpy.float32); ctx.dev_download(d_mc[0], mc_gated)
     assert not mc_gated[~qm['eff']].any() and numpy.isfinite(sp_gated).all()
     turn['set'] = 'all'; primed['done'] = False
-    for _ in range(0 if emu else 18):
+    for _ in range(n_prime):
         step()
     sync_all(); primed['done'] = True
 
@@ -317,13 +338,19 @@ def main(argv=None):
         'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic' if not emu else 'synthetic (EMULATOR: CPU test mode, the numbers mean nothing)',
+        # `value` / `ms_per_step` come from the MEDIAN of `repeats` brackets of exactly K steps each (same fences); every bracket is listed:
+        # wall ms (max over the ranks), ms the host needed to enqueue the K steps, ms between HIP events on rank 0
+        'device_ms_per_step_rank0': round(dev_ms / args.steps, 4),
+        'repeats': len(brs), 'value_from': 'median bracket',
+        'brackets': [{'wall_ms': round(b[0] * 1e3, 3), 'enq_ms': round(b[1] * 1e3, 3), 'dev_ms': round(b[2], 3)} for b in brs],
+        'spread': round((max(b[0] for b in brs) - min(b[0] for b in brs)) / elapsed, 4),
+        'slow_brackets': [i for i, b in enumerate(brs) if b[0] > 1.2 * elapsed],
         # every frame handed to convert counts in `value`; ConvertStream keeps only the buffer in the middle of a
         # window with extra_time (convert_stream.py:40-42): effective x real-time = buffer_time / t_wall
         'x_realtime': round(value * 0.005, 1), 'x_realtime_per_gpu': round(value * 0.005 / world, 1),
         'effective_x_realtime': round((N - 2 * extra) * 0.005 / (ms_window * 1e-3), 1),
         'effective_x_realtime_note': '%d of the %d frames of a window are overlap context that ConvertStream discards; buffer_time %.2f s / %.4f ms per window'
                                      % (2 * extra, N, (N - 2 * extra) * 0.005, ms_window),
-        'device_ms_per_step_rank0': round(dev_ms / args.steps, 4),
         'step': 'chained device-resident core (ry_vc_enqueue_device): stage-1 -> combine_silent -> mc2sp + 1e-16 -> stage-2, two windows in flight; '
                 '%d distinct windows take turns, every frame effective' % NW,
         'mixed_stream': {'value': round(frames_total / elapsed_mixed, 1), 'unit': 'frames/s', 'ms_per_step': round(elapsed_mixed / args.steps * 1e3, 4),
@@ -520,7 +547,7 @@ def main(argv=None):
         if args.dtype == 'f32' and not args.no_split_bf16 and not args.no_extras and world == 1:
             net2.set_dtype('bf16x3')
             primed['done'] = False
-            el3, _ = timed()
+            el3 = median_of(timed(min(3, args.repeats)))
             _, sp3 = convert_now(turn['w0_win'])                                   # one window in split-bf16 mode ...
             net2.set_dtype('f32')
             _, sp3_f32 = convert_now(turn['w0_win'])                               # ... and the same window on the exact fp32 path
@@ -561,7 +588,8 @@ def main(argv=None):
                            'frac': round(ach / peak_tf, 4),
                            'frac_source': ('%s: avg %.3f us per launch (rocprofv3 --kernel-trace --stats, one window at a time)' % (rpf_file, rp_us)) if rp_us
                                           else 'HIP events of this run (no rocprofv3 summary of source %s under profiles/)' % source_hash(),
-                           'achieved_events': round(ach_ev, 2), 'frac_events': round(ach_ev / peak_tf, 4),
+                           'achieved_events': round(ach_ev, 2), 'frac_events': round(ach_ev / peak_tf, 4),      # HIP events around every launch, THIS run
+                           'frac_rocprof': round(ach / peak_tf, 4) if rp_us else None,                         # committed rocprofv3 summary of the same source
                            'traffic': pmc.get(dname.replace(' ', ''), (None,))[0],
                            'traffic_unit': 'HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)',
                            'traffic_source': pmc_file, 'source_hash': source_hash(),
@@ -605,11 +633,51 @@ def main(argv=None):
                                                gated=(xs_host[qm['w']], qm['eff'], mc_gated, sp_gated))
             out['mixed_stream']['gpu_result_of_a_gated_window_vs_cpu_restatement'] = out['cpu_baseline'].pop('gated_window')
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        details = args.details_out or str(ROOT / 'gpurun_out' / ('bench_details_%dgpu.json' % world))
+        try:
+            Path(details).parent.mkdir(parents=True, exist_ok=True)
+            Path(details).write_text(json.dumps(out, indent=1))
+        except OSError as e:
+            details = 'not written (%s)' % e
+        print(json.dumps(compact_line(out, details)), flush=True)
     core.close(); net1.close(); net2.close()
     if comm is not None:
         comm.close()
     return out
+
+
+def compact_line(out, details):
+    """The ONE printed line: headline, brackets, roofline objects, CPU baseline and a few secondary figures -- short enough (< 6 KB) that a
+    tail of the output still holds `value`, `brackets` and `device_ms_per_step_rank0`.  Everything else (`kernels`, batch / host-path /
+    discard measurements, the notes) is in the details file."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+            'device_ms_per_step_rank0', 'repeats', 'value_from', 'brackets', 'spread', 'slow_brackets', 'x_realtime', 'x_realtime_per_gpu',
+            'effective_x_realtime', 'comm', 'config', 'graph_replay_ms')
+    line = {k: out[k] for k in keep if k in out}
+
+    def pick(src, keys):
+        return {k: src[k] for k in keys if k in src}
+    if 'mixed_stream' in out:
+        line['mixed_stream'] = pick(out['mixed_stream'], ('value', 'unit', 'ms_per_step', 'gpu_result_of_a_gated_window_vs_cpu_restatement'))
+    if 'roofline' in out:
+        line['roofline'] = pick(out['roofline'], ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_source', 'frac_events', 'frac_rocprof',
+                                                  'traffic', 'traffic_source', 'source_hash', 'launches', 'avg_launch_ms', 'alg_flops_per_launch',
+                                                  'alg_bytes_per_launch', 'mfma_flops_per_alg_flop'))
+    if 'roofline_stage2_forward' in out:
+        line['roofline_stage2_forward'] = pick(out['roofline_stage2_forward'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'executed_gflop', 'padded_forward_gflop'))
+    if 'roofline_stage1' in out:
+        line['roofline_stage1'] = pick(out['roofline_stage1'], ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_graph_cold', 'traffic',
+                                                                'alg_bytes_per_forward', 'kernel_ms_per_forward'))
+    if 'cpu_baseline' in out:
+        line['cpu_baseline'] = pick(out['cpu_baseline'], ('value', 'unit', 'cores', 'kind', 'sample', 'frames_per_s_by_threads', 'gpu_over_cpu',
+                                                          'gpu_result_vs_this_baseline'))
+    if 'host_path' in out:
+        line['host_path'] = pick(out['host_path'], ('call_ms_per_window', 'call_ms_per_window_with_discard_hint', 'stream_ms_per_window', 'stream_frames_per_s'))
+    for k in ('small_window', 'dispatcher', 'split_bf16', 'discard_hint', 'chained_batch8', 'stage1_batch8'):
+        if k in out:
+            line[k] = {kk: vv for kk, vv in out[k].items() if kk != 'note' and not isinstance(vv, (dict, list))}
+    line['details'] = details
+    return line
 
 
 def cpu_baseline(args, torch, d1, d2, x, mc_gpu, sp_gpu, N, gpu_value, gated=None):
