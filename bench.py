@@ -63,6 +63,11 @@ def parse(argv=None):
     ap.add_argument('--chained-batch', default='8', help='windows per call of the batched window call measured next to the headline (comma-separated)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--profile-reps', type=int, default=5)
+    ap.add_argument('--dispatcher', action='store_true',
+                    help='measure the multi-GPU dispatcher instead (dispatch.ChunkDispatcher: host feature windows in, picked features out): null '
+                         'workers G = 1..8 (the central loop alone), paced null workers, and on the GPU G = 1 and two worker processes on one GPU')
+    ap.add_argument('--dispatcher-windows', type=int, default=400, help='windows per real-GPU dispatcher measurement')
+    ap.add_argument('--dispatcher-depth', type=int, default=2, help='windows a worker keeps in flight on its GPU')
     ap.add_argument('--profile-only', action='store_true', help='only print the per-kernel-family profile of stage-2 (tuning aid)')
     ap.add_argument('--layers-out', default=None, help='write the per-launch profile (layer, kernel, ms, TFLOP/s, GB/s) to this file')
     return ap.parse_args(argv)
@@ -125,8 +130,83 @@ def rocprof_table():
     return {}, None
 
 
+def dispatcher_bench(args):
+    """`--dispatcher`: the path a user of the reference runs on G GPUs -- `dispatch.ChunkDispatcher`, host feature windows in (what
+    `ConvertStream.fetch` returns: wave + f0 / ap / mc / voiced of N frames), the picked features out (`ConvertStream.process` keeps the
+    buffer in the middle, /root/reference/realtime_voice_conversion/stream/convert_stream.py:40-42; ordering contract /root/reference/run.py:171-183).
+    windows/s of (a) the central loop alone: null workers that answer at once with a payload of the real size, G = 1..8; (b) the same with
+    workers that take the GPU time of a window (paced: busy wait), i.e. what G GPUs could be fed; (c) one real worker on the GPU, (d) two
+    worker processes on the one GPU, (e) the same windows through the in-process window call (no transport) for comparison."""
+    import tempfile
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+    from realtime_yukarin_amd import dispatch, synth
+    emu = args.emulator
+    model = args.model or ('SYN-8' if emu else 'SYN-64')
+    N = args.frames
+    extra = args.extra_frames if args.extra_frames is not None else (100 if N == 300 else 0)
+    pick = (extra, -extra, dispatch.PICK_KEYS) if extra > 0 else None
+    tmp = Path(tempfile.mkdtemp(prefix='ry355-bench-'))
+    synth.write_model_files(tmp, model)
+    ac, sr = synth.build_converters(tmp)
+    wins = [synth.feature_window(N, 900 + i, silent_stretch=(i % 3 == 2)) for i in range(9)]       # one window in three cut by the silence gate
+    out = {'metric': 'dispatcher windows/s (host feature windows in, picked features out)', 'unit': 'windows/s', 'frames': N,
+           'kept_frames': N - 2 * extra, 'model': model, 'host_cpus': os.cpu_count(), 'depth': args.dispatcher_depth,
+           'bytes_up_per_window': int(sum(numpy.asarray(a).nbytes for a in (wins[0].wave.wave, wins[0].f0, wins[0].mc, wins[0].voiced))),
+           'bytes_down_per_window': int((N - 2 * extra) * (synth.FFT_BINS * 4 + 4 + 1 + synth.MC_DIMS * 4) + N),
+           'bytes_ap_not_shipped': int(wins[0].ap.nbytes + (N - 2 * extra) * synth.FFT_BINS * 4)}
+
+    def rate(devices, n, **kw):
+        with dispatch.ChunkDispatcher(ac, sr, devices, depth=args.dispatcher_depth, start_timeout=900, **kw) as d:
+            for i in range(min(n, 40)):                                   # plans, graphs, rings warm
+                d.submit(i, wins[i % 9], discard=(extra, extra), pick=pick); d.collect()
+            d.drain(timeout=600)
+            t0, got = time.perf_counter(), 0
+            for i in range(n):
+                d.submit(i, wins[i % 9], discard=(extra, extra), pick=pick)
+                got += len(d.collect())
+            got += len(d.drain(timeout=600))
+            el = time.perf_counter() - t0
+            assert got == n
+            return n / el
+    null_n = 200 if emu else 4000
+    out['null_workers'] = {str(G): round(rate([0] * G, null_n, comm='host', null_workers=True), 1) for G in (1, 2, 4, 8)}
+    out['null_workers_whole_objects'] = {str(G): round(rate([0] * G, null_n, comm='host', null_workers=True, lean=False), 1) for G in (1, 8)}
+    gpu_ms = 0.88                                                         # one window on one MI355X with the discard hint (DESIGN.md section 7)
+    if not emu and (os.cpu_count() or 1) >= 12:
+        out['paced_null_workers'] = {'ms_per_window_per_worker': gpu_ms, 'windows_per_s': {
+            str(G): round(rate([0] * G, 1000 * G, comm='host', null_workers=True, worker_hook=dispatch.paced(gpu_ms)), 1) for G in (1, 2, 4, 8)}}
+    if not emu:
+        nw = args.dispatcher_windows
+        out['gpu_one_worker'] = round(rate([0], nw, comm='native'), 1)                # weights by the (one-rank) RCCL broadcast
+        out['gpu_two_workers_one_gpu'] = round(rate([0, 0], nw, comm='host'), 1)
+        # the same windows through the in-process window call, `depth` in flight (what one worker does, minus the rings)
+        from realtime_yukarin_amd.voice_changer import VoiceChanger
+        vc = VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60)
+        import collections
+        pend = collections.deque()
+
+        def one_pass(n):
+            for i in range(n):
+                pend.append(vc.begin(wins[i % 9], discard=(extra, extra)))
+                if len(pend) >= args.dispatcher_depth:
+                    vc.finish(pend.popleft(), lean=True)
+            while pend:
+                vc.finish(pend.popleft(), lean=True)
+        one_pass(40)
+        t0 = time.perf_counter(); one_pass(nw); el = time.perf_counter() - t0
+        out['in_process_window_call'] = round(nw / el, 1)
+        out['gpu_one_worker_vs_in_process'] = round(out['gpu_one_worker'] / out['in_process_window_call'], 4)
+        vc.close(); ac.close(); sr.close()
+    out['null_ceiling_in_gpus'] = round(max(out['null_workers'].values()) / (1e3 / gpu_ms), 2)
+    print(json.dumps(out), flush=True)
+    return out
+
+
 def main(argv=None):
     args = parse(argv)
+    if args.dispatcher:
+        return dispatcher_bench(args)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC for RCCL / device-buffer sharing: before the HIP runtime comes up
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')             # one hardware queue per stream of the window lanes (realtime_yukarin_amd/_lib.py)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -258,7 +338,16 @@ def main(argv=None):
         sync_all()
 
     primed = {'done': False}
+    import gc
     import math
+    gc_log, gc_t = [], [0.0]
+
+    def gc_note(phase, info):                   # (generation, milliseconds) of every collection, so that a slow bracket can be attributed
+        if phase == 'start':
+            gc_t[0] = time.perf_counter()
+        else:
+            gc_log.append((info['generation'], round((time.perf_counter() - gc_t[0]) * 1e3, 2)))
+    gc.callbacks.append(gc_note)
     n_prime = 0 if emu else min(144, NB * NW // math.gcd(NB, NW))         # every (result block, window) pair once: 18 with six ring slots and nine windows
 
     def bracket():
@@ -272,16 +361,28 @@ def main(argv=None):
         for _ in range(0 if emu else 4):
             step()
         sync_all()
+        gc.disable()                            # (re-enabled below) a full collection is 34-38 ms with torch imported: two brackets' worth of chip time
         ctx.timer_start()                       # every stream is idle: an event on the context stream, nothing joins the lanes
+        n_gc = len(gc_log)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        if os.environ.get('BENCH_DEBUG_FENCE'):
+            t_prev, worst = t0, (0.0, -1)
+            for i in range(args.steps):
+                step()
+                t_now = time.perf_counter()
+                worst = max(worst, (t_now - t_prev, i)); t_prev = t_now
+            print('rank %d: slowest enqueue of the bracket: step %d, %.3f ms; garbage collections inside: %s'
+                  % (rank, worst[1], worst[0] * 1e3, gc_log[n_gc:]), file=sys.stderr, flush=True)
+        else:
+            for _ in range(args.steps):
+                step()
         t_enq = time.perf_counter() - t0
         sync_all()                              # this rank's K steps are done: its clock stops here; the ranks started together (fence above) and
         el = time.perf_counter() - t0           # the job time is the maximum over the ranks (comm.max below) -- the closing barrier itself is not work
         # device-side stamp AFTER the local synchronize: ry_timer_stop while the lanes still have work queued (an event record on every
         # predictor stream plus cross-stream waits) was measured to cost the two lanes their overlap for the whole run (1.33 vs 1.16 ms)
         dms = ctx.timer_stop()
+        gc.enable()
         fence()
         if os.environ.get('BENCH_DEBUG_FENCE'):
             print('rank %d: %.3f ms for the steps (%.3f ms to enqueue them, %.3f ms between device events), %.3f ms with the closing barrier'
@@ -302,6 +403,10 @@ def main(argv=None):
             primed['done'] = True
         for _ in range(args.warmup):
             step()
+        # Python's cyclic collector runs on allocation counts: a generation-2 pass (34-38 ms here, torch's object graph) lands in whichever
+        # bracket the script's own history puts it -- round 3's single bracket, profiles/r04_driver_cmd.txt.  Everything allocated during
+        # set-up is collected once and frozen (moved out of the collector's sight); inside a bracket the collector is off (`bracket`).
+        gc.collect(); gc.freeze()
         return [bracket() for _ in range(max(1, repeats))]
 
     def median_of(brs):
@@ -345,6 +450,7 @@ def main(argv=None):
         'brackets': [{'wall_ms': round(b[0] * 1e3, 3), 'enq_ms': round(b[1] * 1e3, 3), 'dev_ms': round(b[2], 3)} for b in brs],
         'spread': round((max(b[0] for b in brs) - min(b[0] for b in brs)) / elapsed, 4),
         'slow_brackets': [i for i, b in enumerate(brs) if b[0] > 1.2 * elapsed],
+        'gc': 'heap collected + frozen after set-up, collector off inside a bracket (a generation-2 pass is 34-38 ms: profiles/r04_driver_cmd.txt)',
         # every frame handed to convert counts in `value`; ConvertStream keeps only the buffer in the middle of a
         # window with extra_time (convert_stream.py:40-42): effective x real-time = buffer_time / t_wall
         'x_realtime': round(value * 0.005, 1), 'x_realtime_per_gpu': round(value * 0.005 / world, 1),
@@ -651,7 +757,7 @@ def compact_line(out, details):
     tail of the output still holds `value`, `brackets` and `device_ms_per_step_rank0`.  Everything else (`kernels`, batch / host-path /
     discard measurements, the notes) is in the details file."""
     keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
-            'device_ms_per_step_rank0', 'repeats', 'value_from', 'brackets', 'spread', 'slow_brackets', 'x_realtime', 'x_realtime_per_gpu',
+            'device_ms_per_step_rank0', 'repeats', 'value_from', 'brackets', 'spread', 'slow_brackets', 'gc', 'x_realtime', 'x_realtime_per_gpu',
             'effective_x_realtime', 'comm', 'config', 'graph_replay_ms')
     line = {k: out[k] for k in keep if k in out}
 

@@ -23,26 +23,30 @@ TILES = {None: 0, 'auto': 0, '128x128': 1, '64x128': 3, '32x128': 4, '128x64': 5
 TILES.update({k + 'k2': v + 16 for k, v in list(TILES.items()) if isinstance(k, str) and k != 'auto'})   # two K groups per workgroup
 TILES.update({k + 'k1': v + 32 for k, v in list(TILES.items()) if isinstance(k, str) and k[-2:] != 'k2' and k != 'auto'})           # force one
 
-# every symbol include/ry355.h declares (checked by tests/test_abi.py)
-# The window call runs up to two windows side by side on their own pairs of HIP streams (ry_vc_set_lanes): the streams only overlap when
-# each has a hardware queue of its own.  ROCm hands out 4 by default and folds further streams onto them (measured on MI355X: with a
-# second runtime user in the process two lanes then gain nothing, 1.29 ms per window; with 16 every pair of streams overlaps
-# (scripts/gpu_queues.py) and two lanes run at 1.16 ms).  Read when the HIP runtime starts, so it is set here, at import, unless the
-# caller chose a value.  This is a side effect on `os.environ` of the importing process: other users of the HIP
-# runtime in the process (torch, RCCL) and child processes see it too -- and it comes too late if the runtime is already up.
-if 'GPU_MAX_HW_QUEUES' not in os.environ:
-    import sys as _sys
-    _t = _sys.modules.get('torch')
+def ensure_hw_queues() -> None:
+    """The window call runs up to two windows side by side on their own pairs of HIP streams (ry_vc_set_lanes): the streams only overlap when
+    each has a hardware queue of its own.  ROCm hands out 4 by default and folds further streams onto them (measured on MI355X: with a
+    second runtime user in the process two lanes then gain nothing, 1.29 ms per window; with 16 every pair of streams overlaps
+    (scripts/gpu_queues.py) and two lanes run at 1.16 ms).  The HIP runtime reads GPU_MAX_HW_QUEUES when it starts, so the variable is set
+    when the product library is BOUND (`Ry355Lib.__init__`: the first GPU context of the process, `engine.get_context`) -- not at import:
+    importing the package changes nothing.  The entry points (bench.py, the worker processes of `dispatch`) set it themselves before
+    anything else.  A caller's own value is respected; a runtime that is already up gets a warning."""
+    if 'GPU_MAX_HW_QUEUES' in os.environ:
+        return
+    import sys
+    t = sys.modules.get('torch')
     try:
-        _late = _t is not None and _t.cuda.is_initialized()
+        late = t is not None and t.cuda.is_initialized()
     except Exception:
-        _late = False
-    if _late:
+        late = False
+    if late:
         import warnings
         warnings.warn('realtime_yukarin_amd: the HIP runtime of this process started before GPU_MAX_HW_QUEUES=16 could be set; the two window '
-                      'lanes may share hardware queues and serialise (set GPU_MAX_HW_QUEUES=16 in the environment, or import this package first)')
+                      'lanes may share hardware queues and serialise (set GPU_MAX_HW_QUEUES=16 in the environment before the first HIP call)')
     os.environ['GPU_MAX_HW_QUEUES'] = '16'
 
+
+# every symbol include/ry355.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     'ry_init', 'ry_shutdown', 'ry_sync', 'ry_stream', 'ry_device_count', 'ry_last_error',
     'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_clone', 'ry_net_set_dtype', 'ry_net_forward',
@@ -94,6 +98,7 @@ class Ry355Lib(object):
                 '%s not found: the MI355X HIP library is not built (run `python -c "import __graft_entry__ as g; '
                 'g.build()"` at the repo root). This package has no CPU fallback.' % path)
         self.path = path
+        ensure_hw_queues()
         self.dll = ctypes.CDLL(str(path))
         d = self.dll
         d.ry_last_error.restype = ctypes.c_char_p

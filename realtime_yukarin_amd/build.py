@@ -37,7 +37,9 @@ def _compile_units(cc, flags, obj_dir: Path, suffix: str, extra_sources=()):
 
     def one(job):
         src, obj = job
-        subprocess.run([cc] + flags + ['-c', str(src), '-o', str(obj)], check=True, cwd=str(ROOT))
+        tmp = obj.with_suffix('.o.tmp%d' % os.getpid())                    # several builders may run at once (xdist workers): nobody links a
+        subprocess.run([cc] + flags + ['-c', str(src), '-o', str(tmp)], check=True, cwd=str(ROOT))   # half-written object of somebody else
+        os.replace(str(tmp), str(obj))
         return obj
     with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
         return [str(o) for o in ex.map(one, jobs)]
@@ -49,7 +51,9 @@ def build_product(force: bool = False) -> Path:
         cc = _hipcc()
         objs = _compile_units(cc, ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-x', 'hip'],
                               ROOT / 'gpurun_out' / '_obj', '')
-        subprocess.run([cc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', str(LIB)], check=True, cwd=str(ROOT))
+        tmp = LIB.with_suffix('.so.tmp%d' % os.getpid())                   # link aside, then rename: a process that has the old library mapped keeps it
+        subprocess.run([cc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', str(tmp)], check=True, cwd=str(ROOT))
+        os.replace(str(tmp), str(LIB))
     return LIB
 
 

@@ -110,10 +110,32 @@ class TorchComm(object):
 
 
 # ------------------------------------------------------------------------------------------------ RCCL through the C ABI
+_comm_serial = [0]         # NativeComm objects built so far in this process: every rank builds them in the same order
+
+
+def _launcher_identity() -> str:
+    """`<pid>-<start time in clock ticks since boot>` of the process that launched the ranks (their common parent): unique per launch --
+    a recycled pid has another start time -- and the same for every rank, read from /proc/<ppid>/stat field 22.  (Round 3 used the mtime
+    of /proc/<ppid> as the launcher's start time; procfs stamps that inode at first lookup, so it was "roughly now", and a rank that
+    arrived more than two seconds after rank 0 wrote the id rejected it for the whole timeout.)  RY_COMM_NONCE, when a launcher sets it,
+    replaces the whole thing."""
+    nonce = os.environ.get('RY_COMM_NONCE')
+    if nonce:
+        return nonce
+    ppid = os.getppid()
+    try:
+        with open('/proc/%d/stat' % ppid, 'rb') as f:
+            fields = f.read().rsplit(b')', 1)[1].split()           # the command name may hold blanks and brackets: count from the last ')'
+        return '%d-%s' % (ppid, fields[19].decode())                # field 22 (1-based) = index 19 after (pid, comm)
+    except (OSError, IndexError):
+        return '%d-0' % ppid
+
+
 def _rendezvous_path() -> str:
-    """Where rank 0 leaves the 128-byte RCCL id for the other ranks of the same launch: a file in a directory only this user can
-    write (0700), named after the launcher's pid and MASTER_PORT -- every worker of one `torch.distributed.run` launch has the same
-    parent.  RY_COMM_RENDEZVOUS names the file explicitly (the dispatcher passes a path inside a fresh private directory)."""
+    """Where rank 0 leaves the 128-byte RCCL id for the other ranks of the same launch: a file in a directory only this user can write
+    (0700, ownership and mode checked), named after the launcher's identity (pid + start time: no other launch, past or concurrent, has
+    it), MASTER_PORT and the serial number of the communicator within the launch -- so a name is used once, and nothing older can be
+    mistaken for it.  RY_COMM_RENDEZVOUS names the file explicitly (the dispatcher passes a path inside a fresh private directory)."""
     p = os.environ.get('RY_COMM_RENDEZVOUS')
     if p:
         return p
@@ -122,15 +144,7 @@ def _rendezvous_path() -> str:
     st = os.stat(d)
     if st.st_uid != os.getuid() or (st.st_mode & 0o077):
         raise _lib.Ry355Error('%s is not a private directory of this user: refusing to exchange the RCCL id through it' % d)
-    return os.path.join(d, 'comm_%d_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0')))
-
-
-def _launch_time() -> float:
-    """Start of the process that launched the ranks (their common parent): an id file older than this is a leftover of another run."""
-    try:
-        return os.stat('/proc/%d' % os.getppid()).st_mtime
-    except OSError:
-        return 0.0
+    return os.path.join(d, 'comm_%s_%s_%d' % (_launcher_identity(), os.environ.get('MASTER_PORT', '0'), _comm_serial[0]))
 
 
 class NativeComm(object):
@@ -140,6 +154,7 @@ class NativeComm(object):
         lib = ctx.lib
         idb = ctypes.create_string_buffer(128)
         path = path or _rendezvous_path()
+        _comm_serial[0] += 1
         if self.rank == 0:
             lib.check(lib.dll.ry_comm_unique_id(idb))
             if self.world > 1:
@@ -153,11 +168,11 @@ class NativeComm(object):
                     f.write(idb.raw)
                 os.replace(path + '.tmp', path)
         else:
-            t0, born = time.time(), _launch_time() - 2.0
+            t0 = time.time()
             while True:
                 try:
                     st = os.stat(path)
-                    if st.st_mtime >= born and st.st_size == 128:     # written during THIS launch (a leftover is older than the launcher)
+                    if st.st_size == 128 and st.st_uid == os.getuid():    # rank 0 renames the complete file into place; the name belongs to this launch alone
                         break
                 except OSError:
                     pass

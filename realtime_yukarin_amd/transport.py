@@ -28,10 +28,19 @@ import threading
 import time
 from multiprocessing import get_context, resource_tracker, shared_memory
 
+import collections
+
+import numpy
+
 ALIGN = 64
 _ATTACH_LOCK = threading.Lock()
-_HEAD = struct.Struct('<QI')      # in-band length, number of out-of-band buffers
+_HEAD = struct.Struct('<QI')      # in-band length, number of out-of-band buffers (top bit: the slot holds a raw array message)
 _LEN = struct.Struct('<Q')
+_RAW = 1 << 31
+
+# A message of plain arrays that skips pickle altogether (`put_arrays`): what the multi-GPU dispatcher sends per window.  `get` returns it
+# as this tuple; the arrays are views of the receiver's private copy of the slot.
+Raw = collections.namedtuple('Raw', 'tag ints arrays')
 
 
 def _round_up(n: int) -> int:
@@ -115,6 +124,38 @@ class FeatureQueue(object):
     def put_nowait(self, obj) -> None:
         self.put(obj, False)
 
+    def put_arrays(self, tag: int, ints, arrays, block: bool = True, timeout=None) -> None:
+        """A message of one tag, a few integers and C-contiguous ndarrays, written WITHOUT pickle: a fixed little descriptor (dtype, shape) per
+        array in the slot header, the array bytes 64-byte aligned behind it.  `get` hands it back as `Raw(tag, ints, arrays)`.  For the
+        hot messages of the dispatcher: pickling the feature object and its five arrays out of band costs ~30 + 20 us per hop, this ~8."""
+        arrays = [numpy.ascontiguousarray(a) for a in arrays]
+        desc = [struct.pack('<qI', int(tag), len(ints)), struct.pack('<%dq' % len(ints), *[int(v) for v in ints])]
+        for a in arrays:
+            desc.append(struct.pack('<4sB%dI' % a.ndim, a.dtype.str.encode().ljust(4), a.ndim, *a.shape))
+        inband = b''.join(desc)
+        head_len = _round_up(_HEAD.size + _LEN.size * len(arrays) + len(inband))
+        total = head_len + sum(_round_up(a.nbytes) for a in arrays)
+        if total > self.slot_bytes:
+            raise ValueError('message needs %d bytes, FeatureQueue slots hold %d (raise slot_bytes)' % (total, self.slot_bytes))
+        if not self._free.acquire(block, timeout):
+            raise queue.Full
+        with self._put_lock:
+            base = (self._head.value % self.slots) * self.slot_bytes
+            mem = self._shm.buf
+            _HEAD.pack_into(mem, base, len(inband), len(arrays) | _RAW)
+            off = base + _HEAD.size
+            for a in arrays:
+                _LEN.pack_into(mem, off, a.nbytes)
+                off += _LEN.size
+            mem[off:off + len(inband)] = inband
+            off = base + head_len
+            for a in arrays:
+                if a.nbytes:
+                    mem[off:off + a.nbytes] = a.reshape(-1).view(numpy.uint8).data
+                off += _round_up(a.nbytes)
+            self._head.value += 1
+        self._filled.release()
+
     # ---- consumer ---------------------------------------------------------------------------------------------------
     def get(self, block: bool = True, timeout=None):
         if not self._filled.acquire(block, timeout):
@@ -123,6 +164,7 @@ class FeatureQueue(object):
             base = (self._tail.value % self.slots) * self.slot_bytes
             mem = self._shm.buf
             n_inband, n_bufs = _HEAD.unpack_from(mem, base)
+            raw, n_bufs = bool(n_bufs & _RAW), n_bufs & ~_RAW
             off = base + _HEAD.size
             lens = [_LEN.unpack_from(mem, off + i * _LEN.size)[0] for i in range(n_bufs)]
             off += _LEN.size * n_bufs
@@ -135,7 +177,17 @@ class FeatureQueue(object):
         for n in lens:
             views.append(view[off:off + n])
             off += _round_up(n)
-        return pickle.loads(inband, buffers=views)
+        if not raw:
+            return pickle.loads(inband, buffers=views)
+        tag, n_ints = struct.unpack_from('<qI', inband, 0)
+        ints = struct.unpack_from('<%dq' % n_ints, inband, 12)
+        pos, arrays = 12 + 8 * n_ints, []
+        for v in views:
+            dt, ndim = struct.unpack_from('<4sB', inband, pos)
+            shape = struct.unpack_from('<%dI' % ndim, inband, pos + 5)
+            pos += 5 + 4 * ndim
+            arrays.append(numpy.frombuffer(v, dtype=numpy.dtype(dt.decode().strip())).reshape(shape))
+        return Raw(tag, ints, arrays)
 
     def get_nowait(self):
         return self.get(False)

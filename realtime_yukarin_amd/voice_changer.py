@@ -93,9 +93,15 @@ class VoiceChanger(object):
         t = core.submit(numpy.asarray(f_eff.mc, dtype=numpy.float32), effective, SP_FLOOR)
         return ('host', core, t, f_eff, effective)
 
-    def finish(self, handle):
+    def finish(self, handle, lean: bool = False):
+        """lean=True (the multi-GPU dispatcher): everything of the result except `ap`, which the stage never touches
+        (`AcousticConverter.convert` passes it through, combine_silent zeroes the silent frames) -- the caller keeps its own `ap` and needs
+        `effective` to finish the job (`attach_ap`).  Same values and dtypes as the full result for f0 / voiced / mc / sp."""
         if handle[0] == 'done':
-            return handle[1]
+            f_out = handle[1]
+            if lean:
+                f_out.effective = None                      # generic path: `ap` came through the converters, nothing to re-attach
+            return f_out
         ac = self.acoustic_converter
         if handle[0] == 'wave':
             _, core, t, f_in = handle
@@ -104,10 +110,33 @@ class VoiceChanger(object):
         else:
             _, core, t, f_eff, effective = handle
             mc, sp = core.wait(t)
+        if lean:
+            from yukarin.acoustic_feature import AcousticFeature
+            n = len(effective)
+            f0, voiced = numpy.zeros((n, 1), numpy.float32), numpy.zeros((n, 1), bool)       # AcousticFeature.silent
+            if len(f_eff.f0):
+                f0[effective] = ac.f0_converter.convert(f_eff).f0 if ac.f0_converter is not None else f_eff.f0
+                voiced[effective] = f_eff.voiced
+            f_out = AcousticFeature(f0=f0, voiced=voiced, mc=mc, sp=sp)
+            f_out.effective = effective
+            return f_out
         f_out = ac.combine_silent(effective=effective, feature=self._passthrough(f_eff))
         f_out.mc = mc
         f_out.sp = sp
         return f_out
+
+    @staticmethod
+    def attach_ap(ap_in, effective, first: int, last: int, bins: int):
+        """The `ap` rows [first, last) of a window's result from the window's INPUT `ap`: `AcousticConverter.convert` passes ap through and
+        `combine_silent` leaves zeros on the frames the silence gate cut (float32, as `AcousticFeature.silent` allocates it)."""
+        n = last - first
+        if not isinstance(ap_in, numpy.ndarray):
+            return numpy.zeros((n, bins), numpy.float32)
+        ap = numpy.asarray(ap_in[first:last], dtype=numpy.float32)
+        if effective is not None and not effective[first:last].all():
+            ap = numpy.array(ap, copy=True)
+            ap[~effective[first:last]] = 0
+        return ap
 
     def _passthrough(self, f_eff):
         """f0 through the F0Converter, ap / voiced untouched -- what `AcousticConverter.convert` returns besides mc."""

@@ -33,3 +33,15 @@ def failing_window_hook(rank):
         if rank == 0 and len(seen) == 2:
             raise RuntimeError('window %d: device lost' % index)
     return per_window
+
+
+def stall_hook(rank):
+    """Worker 0 stalls for two seconds on its second window (a GPU that builds a new launch plan / captures graphs mid-stream): with a
+    backlog behind it every ring fills up.  No emulator context: for null workers."""
+    seen = []
+
+    def per_window(index):
+        seen.append(index)
+        if rank == 0 and len(seen) == 2:
+            time.sleep(2.0)
+    return per_window

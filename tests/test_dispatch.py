@@ -23,7 +23,7 @@ REF = Path('/root/reference')
 KEYS = ('f0', 'ap', 'sp', 'voiced', 'mc')
 
 
-from dispatch_hooks import dying_hook, emu_hook, failing_window_hook      # top-level functions of a LIGHT module: every spawned worker imports the module of its hook
+from dispatch_hooks import dying_hook, emu_hook, failing_window_hook, stall_hook      # top-level functions of a LIGHT module: every spawned worker imports the module of its hook
 
 
 def windows(n_frames, count):
@@ -103,6 +103,49 @@ def test_a_worker_that_fails_mid_stream_is_reported(tmp_path):
     assert d.closed
     with pytest.raises(RuntimeError, match='closed'):
         d.submit(9, wins[0][2])
+
+
+def test_a_stalled_worker_with_a_backlog_behind_it_does_not_deadlock(tmp_path):
+    """Round-3 advisor: with bounded rings everywhere, a caller that only submits while one GPU stalls used to end with the caller stuck in
+    `put` on the stalled worker's ring and every worker stuck in `put` on the return ring (nobody taking results).  `submit` now keeps
+    taking finished windows while it waits for a free slot, and every worker has a return ring of its own.  Null workers (no arithmetic):
+    two-slot rings, worker 0 sleeps on its second window, forty windows submitted back to back."""
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    wins = windows(24, 3)
+    t0 = time.time()
+    with dispatch.ChunkDispatcher(ac, sr, [0, 0], comm='host', null_workers=True, worker_hook=stall_hook, slots=2, start_timeout=600) as d:
+        got = []
+        for i in range(40):
+            d.submit(i, wins[i % 3][2], discard=(7, 7), pick=(7, -7, KEYS))
+        got += d.drain(timeout=120)
+    assert [i for i, _ in got] == list(range(40)) and time.time() - t0 < 60
+    assert d.max_out_of_order >= 2                                   # worker 1 ran ahead while worker 0 slept
+    for _, f in got:
+        assert f.sp.shape == (10, 513) and f.ap.shape == (10, 513)
+
+
+def test_lean_windows_and_whole_objects_return_the_same_bits(tmp_path):
+    """A window travels without its `ap` block (re-attached by the dispatcher, zeroed on the frames the silence gate cut) and as plain
+    arrays without pickle; `lean=False` ships the whole feature object both ways as round 3 did.  Same bits either way, every key, with and
+    without a pick -- the windows of `make_window` have a silent and a quiet stretch, so the re-attached `ap` has zero rows."""
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    wins = windows(64, 3)                                          # long enough for frames whose whole 1024-sample gate window is silent
+    res = {}
+    for lean in (True, False):
+        with dispatch.ChunkDispatcher(ac, sr, [0], threshold=60, comm='host', worker_hook=emu_hook, lean=lean, start_timeout=900) as d:
+            assert d.lean == lean
+            for i, (_, _, f) in enumerate(wins):
+                d.submit(i, f, discard=(7, 7), pick=(7, -7, KEYS))
+            d.submit(3, wins[0][2])                                  # no pick: every frame, every key convert_from_acoustic_feature sets
+            res[lean] = d.drain(timeout=900)
+    for (ia, a), (ib, b) in zip(res[True], res[False]):
+        assert ia == ib and same(a, b) and a.ap.dtype == b.ap.dtype == numpy.float32
+    full = res[True][3][1]
+    eff = e2e.oef.separate_effective_mask(wins[0][0], e2e.FS, 64, 60, 1024, e2e.FRAME_PERIOD)        # the oracle's gate on the same wave
+    assert full.sp.shape == (64, 513) and 0 < eff.sum() < 64
+    assert not full.ap[~eff].any() and numpy.array_equal(full.ap[eff], wins[0][1]['ap'][eff])
 
 
 def test_weightless_copies_for_the_broadcast_receivers(tmp_path):

@@ -58,9 +58,26 @@ def test_one_rank_rccl_broadcast_and_adoption(kind):
 
 @pytest.mark.parametrize('comm', ['torch', 'native'])
 def test_bench_force_dist(comm):
-    """bench.py through its `comm is not None` branches on one GPU: same JSON contract, value close to the plain run's."""
-    out = _run(['bench.py', '--force-dist', '--comm', comm, '--steps', '10', '--warmup', '2', '--no-cpu-baseline', '--no-extras'],
+    """bench.py through its `comm is not None` branches on one GPU, at the DRIVER'S step count (--steps 20 --warmup 5): same JSON contract,
+    the headline where the plain run has it (round 3's driver line was 130 k frames/s from one unrepeated bracket with a garbage collection
+    inside, and this test asked for 50 k at --steps 10: it would not have noticed)."""
+    out = _run(['bench.py', '--force-dist', '--comm', comm, '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-extras'],
                {'MASTER_PORT': '29613' if comm == 'torch' else '29614', 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1'})
     d = json.loads([ln for ln in out.splitlines() if ln.startswith('{')][-1])
-    assert d['n_gpus'] == 1 and d['comm'] is not None and d['value'] > 50000 and d['dtype'] == 'f32'
+    assert d['n_gpus'] == 1 and d['comm'] is not None and d['value'] > 200000 and d['dtype'] == 'f32'
     assert d['roofline']['frac'] > 0.5 and d['config']['frames'] == 300
+    assert d['repeats'] >= 5 and len(d['brackets']) == d['repeats'] and d['slow_brackets'] == [] and d['spread'] < 0.10
+
+
+def test_bench_at_the_drivers_own_command():
+    """`python3 bench.py --gpus 1 --steps 20 --warmup 5` (what the driver runs at round end) in a fresh process: the printed line is short
+    enough for an 8 KB tail, carries every bracket, and the brackets agree with each other."""
+    out = _run(['bench.py', '--gpus', '1', '--steps', '20', '--warmup', '5', '--no-extras', '--cpu-seconds', '2'])
+    line = [ln for ln in out.splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert len(line) < 6144, len(line)
+    assert d['steps'] == 20 and d['warmup'] == 5 and d['value'] > 200000 and d['value_from'] == 'median bracket'
+    walls = sorted(b['wall_ms'] for b in d['brackets'])
+    assert d['slow_brackets'] == [] and walls[-1] < 1.10 * walls[0], d['brackets']
+    assert abs(d['device_ms_per_step_rank0'] - d['ms_per_step']) < 0.05 * d['ms_per_step']
+    assert d['cpu_baseline']['gpu_result_vs_this_baseline']['sp_max_rel'] < 1e-4 and d['roofline']['frac'] > 0.5

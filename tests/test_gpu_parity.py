@@ -374,3 +374,69 @@ def test_errors_are_reported_not_fatal(gpu_ctx):
     assert 'multiple' in str(ei.value)
     assert net.forward(numpy.zeros((1, 128, 9), 'f4')).shape == (1, 128, 9)   # still usable afterwards
     net.close()
+
+
+def _chained_oracle(t1, t2, x, effective, n):
+    """voice_changer.py:33-41 on the oracle for one window: stage 1 on the effective rows, zeros elsewhere, mc2sp + 1e-16, stage 2."""
+    from oracle import mc2sp as omc
+    mc = numpy.zeros((n, synth.MC_DIMS), numpy.float32)
+    if effective.any():
+        mc[effective] = torch_ref.stage1_convert_core(t1, x)
+    sp_mid = (omc.mc2sp(mc, omc.mcepalpha(16000), 1024) + 1e-16).astype(numpy.float32)
+    return mc, torch_ref.stage2_convert(t2, sp_mid)
+
+
+def test_config5_bf16_through_the_chained_core_at_400_frames(syn64):
+    """BASELINE config #5 as BASELINE.json words it -- bf16 stage-2 on the matrix pipe, buffer_time 1.0 s (+ 2 x 0.5 s extra: N = 400 -> 512
+    padded frames) -- through the CHAINED window call (stage-1 fp32 -> combine_silent -> mc2sp -> stage-2 bf16), not the raw stage-2
+    convert: mc stays inside the fp32 bar, the spectrogram inside the stated 3e-2 on the log-spectrum, against the fp32 oracle."""
+    from realtime_yukarin_amd import sptk
+    (n1, t1), (n2, t2) = syn64
+    n = 400
+    rng = numpy.random.default_rng(405)
+    effective = rng.random(n) > 0.2
+    x = synth.stage1_input(n, seed=406)[0][effective]
+    mc_ref, sp_ref = _chained_oracle(t1, t2, x, effective, n)
+    core = engine.VcCore(n1, n2, sptk.mc2sp_matrix(8, sptk.mcepalpha(16000), 1024))
+    try:
+        n2.set_dtype('bf16')
+        got = list(core.convert_stream([(x, effective)] * 3, depth=3))            # both lanes (the clones follow the handle's mode), eager then graph replay
+    finally:
+        n2.set_dtype('f32')
+    mc32, sp32 = core.convert(x, effective)
+    core.close()
+    for mc, sp in got:
+        e16 = rel_max(numpy.log(sp), numpy.log(sp_ref))
+        assert rel_max(mc, mc_ref) < cases.TOL and not mc[~effective].any()
+        assert 1e-5 < e16 < BF16_TOL, e16
+        assert numpy.array_equal(sp, got[0][1])                                   # every lane, eager or replayed: the same bits
+    print('config #5 chained, 400 frames: bf16 log-spectrum error %.2e (stated %.0e); fp32 path element-wise %.2e'
+          % (rel_max(numpy.log(got[0][1]), numpy.log(sp_ref)), BF16_TOL, float(numpy.abs(sp32 / sp_ref - 1).max())))
+    assert float(numpy.abs(sp32 / sp_ref - 1).max()) < cases.TOL                # back in f32 mode: the exact path again
+
+
+def test_convert_batch_of_8_windows_against_the_oracle(syn64):
+    """`VcCore.convert_batch` / `ry_vc_enqueue_device_batch` -- eight different 300-frame windows in one call, two of them cut by the
+    silence gate (so stage 1 runs window by window) -- each window against the ORACLE directly (round 3 compared the batch call with
+    the single-window call only); then eight all-effective windows (stage 1 as one batch)."""
+    from realtime_yukarin_amd import sptk
+    (n1, t1), (n2, t2) = syn64
+    n = 300
+    rng = numpy.random.default_rng(808)
+    core = engine.VcCore(n1, n2, sptk.mc2sp_matrix(8, sptk.mcepalpha(16000), 1024))
+    for gated in ((2, 5), ()):
+        wins = []
+        for w in range(8):
+            e = numpy.ones(n, bool)
+            if w in gated:
+                e[40 * w:40 * w + 60] = False
+            wins.append((synth.stage1_input(n, seed=810 + w)[0][e], e))
+        res = core.convert_batch(wins)
+        worst_sp = worst_mc = 0.0
+        for (x, e), (mc, sp) in zip(wins, res):
+            mc_ref, sp_ref = _chained_oracle(t1, t2, x, e, n)
+            worst_mc = max(worst_mc, rel_max(mc, mc_ref)); worst_sp = max(worst_sp, float(numpy.abs(sp.astype(numpy.float64) / sp_ref - 1).max()))
+            assert not mc[~e].any()
+        print('convert_batch of 8 (gated windows: %s): worst mc %.2e, worst sp element-wise %.2e' % (list(gated), worst_mc, worst_sp))
+        assert worst_mc < cases.TOL and worst_sp < cases.TOL
+    core.close()

