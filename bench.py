@@ -401,12 +401,13 @@ def main(argv=None):
             for _ in range(n_prime):
                 step()
             primed['done'] = True
-        for _ in range(args.warmup):
-            step()
         # Python's cyclic collector runs on allocation counts: a generation-2 pass (34-38 ms here, torch's object graph) lands in whichever
         # bracket the script's own history puts it -- round 3's single bracket, profiles/r04_driver_cmd.txt.  Everything allocated during
         # set-up is collected once and frozen (moved out of the collector's sight); inside a bracket the collector is off (`bracket`).
+        # BEFORE the warm-up: the collection itself idles the chip for those 35 ms, and what runs behind a pause runs slower for a while.
         gc.collect(); gc.freeze()
+        for _ in range(args.warmup):
+            step()
         return [bracket() for _ in range(max(1, repeats))]
 
     def median_of(brs):
