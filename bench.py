@@ -650,6 +650,51 @@ def main(argv=None):
             out['silence_gate_host'] = {'ms_per_window': round(gate_ms, 4), 'fraction_of_window': round(gate_ms / ms_window, 4),
                                         'note': 'separate_effective mask (numpy, one host thread); it overlaps the GPU work of the previous window'}
 
+        # BASELINE config #3 / #4 literally: buffer_time 0.5 s and NO extra context = 100-frame windows (/root/reference/config.yaml:6,14 with
+        # convert_extra_time 0) -- what a low-latency live stream converts.  Same core, same bracket procedure; every grid of stage 2 is below
+        # one round of workgroups at 128 padded frames and the weight-streaming bottom of the U-Net costs what it costs at any window size.
+        if not args.no_extras and N > 100 and world == 1:
+            Ns = 100
+            xs_s = synth.stage1_input(Ns, NW, seed=synth.SEED_INPUT + 99)
+            d_xs = []
+            for w in range(NW):
+                q = ctx.dev_alloc(Ns * d1.in_ch); ctx.dev_upload(q, xs_s[w]); d_xs.append(q)
+            d_rows_s = ctx.dev_alloc(Ns); ctx.dev_upload(d_rows_s, numpy.arange(Ns, dtype=numpy.int32))
+            ks = {'n': 0}
+
+            def step_s():
+                k = ks['n'] % NB; ks['n'] += 1
+                core.enqueue_device(d_xs[ks['n'] % NW], d_rows_s, Ns, Ns, d_mc[k], d_sp[k], SP_FLOOR)      # (the 300-frame result blocks are large enough)
+            for _ in range(n_prime + 6):
+                step_s()
+            sync_all()
+            els = []
+            for _ in range(3):
+                for _ in range(4):
+                    step_s()
+                sync_all(); gc.disable(); ts = time.perf_counter()
+                for _ in range(2 * args.steps):
+                    step_s()
+                sync_all(); els.append((time.perf_counter() - ts) / (2 * args.steps)); gc.enable()
+            ms_s = sorted(els)[1] * 1e3
+            d_si = ctx.dev_alloc(Ns * synth.FFT_BINS); d_so = ctx.dev_alloc(Ns * synth.FFT_BINS)
+            ctx.dev_upload(d_si, synth.stage2_input(Ns)[0])
+            s2s_ms = time_only(lambda: net2.convert_device(d_si, d_so, 1, Ns))
+            run_s = sum(q['flops'] for q in net2.profile(1, Ns, 1, window=True))
+            per_s = []
+            for i in range(13):
+                tq = time.perf_counter(); step_s(); ctx.sync(); per_s.append((time.perf_counter() - tq) * 1e3)
+            out['small_window'] = {'frames': Ns, 'padded_frames': Ns + pad_frames(Ns), 'value': round(Ns / (ms_s * 1e-3), 1), 'unit': 'frames/s',
+                                   'ms_per_window': round(ms_s, 4), 'x_realtime': round(Ns / (ms_s * 1e-3) * 0.005, 1),
+                                   'chain_one_window_synced_ms': round(sorted(per_s[3:])[5], 4), 'stage2_alone_ms': round(s2s_ms, 4),
+                                   'stage2_forward_frac': round(run_s / (s2s_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TF if args.dtype == 'f32' else 2500.0), 4),
+                                   'note': 'BASELINE config #3 / #4 core: 100-frame windows (buffer_time 0.5 s, no extra context), two lanes; median of three brackets'}
+            for q in d_xs + [d_rows_s, d_si, d_so]:
+                ctx.dev_free(q)
+            for _ in range(n_prime):                                                 # back to the headline windows on every ring slot
+                step()
+            sync_all()
+
         # the same K steps with stage-2 in split-bf16 mode -- reported BESIDE the exact-fp32 headline, never as `value` of an f32 run
         if args.dtype == 'f32' and not args.no_split_bf16 and not args.no_extras and world == 1:
             net2.set_dtype('bf16x3')

@@ -57,7 +57,6 @@ struct ry_vc {
     // Lanes (ry_vc_set_lanes): ring slot k runs on the predictor pair l1 / l2 [k % lanes].  Lane 0 is the caller's pair; the others are
     // clones (same filters, own streams / plans / activations), so that the windows in flight really run side by side: the tails of one
     // window's one-round grids and its weight-streaming bottom layers are filled by the other windows' kernels.
-    int prefetch = 0;        // RY_VC_PREFETCH=<workgroups> (experiment): touch the filters of the stage-2 bottom layers on the stage-1 stream while the encoder runs
     int disc_front = 0, disc_back = 0;   // ry_vc_set_discard: frames of every window the caller throws away (stage 2 does not compute them)
     int lanes = 1;
     ry_net* l1[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -167,29 +166,6 @@ static int vc_enqueue_mid(ry_vc* vc, ry_net* s1, const float* y1, const int* row
     return RY_OK;
 }
 
-// Experiment (RY_VC_PREFETCH): one pass over the filters of encoder c5 .. decoder c2 of stage 2 on the STAGE-1 stream, queued right behind
-// the window's mc2sp -- it runs while the MFMA-bound encoder layers of the same window run on the stage-2 stream, so that the
-// weight-streaming layers find their 134 MB in the last-level cache instead of in HBM.  fp32 mode only.
-static int vc_prefetch_bottom(ry_vc* vc, ry_net* s1, ry_net* s2) {
-    if (vc->prefetch <= 0 || s2->dtype != 0 || s2->layers.size() < 16) return RY_OK;
-    RyTouchParams tp;
-    tp.nbuf = 0; tp.sink = vc->d_mtx;                                  // (never written)
-    for (int li = 5; li <= 10; ++li) {
-        const Layer& l = s2->layers[(size_t)li];
-        if (!l.wig) continue;
-        tp.buf[tp.nbuf] = l.wig;
-        tp.n16[tp.nbuf] = (unsigned)((size_t)l.k * l.k * l.cin() * l.cout / 4);
-        ++tp.nbuf;
-    }
-    if (tp.nbuf == 0) return RY_OK;
-    Launcher Lc{s1, s1->ctx, s1->stream, nullptr, nullptr};
-    dim3 g((unsigned)vc->prefetch);
-    RY_TRY(Lc.begin("ry_touch", "prefetch", 0, 0, g));
-    RY_LAUNCH(ry_touch, g, 64, s1->stream, tp);
-    RY_TRY(Lc.end());
-    return RY_OK;
-}
-
 // stage 2 of one window on its lane
 static int vc_run_stage2(ry_vc* vc, ry_net* s2, const float* sp_in, float* sp_out, int n_frames) {
     return ry_sr_convert_rows(s2, sp_in, sp_out, 1, n_frames, vc->disc_front, vc->disc_back, 1);
@@ -223,7 +199,6 @@ int ry_vc_create(ry_net* s1, ry_net* s2, const float* mtx, int M, int F, ry_vc**
     std::unique_ptr<ry_vc> vc(new ry_vc());
     vc->s1 = s1; vc->s2 = s2; vc->M = M; vc->F = F;
     vc->l1[0] = s1; vc->l2[0] = s2;
-    if (const char* e = getenv("RY_VC_PREFETCH")) vc->prefetch = atoi(e);
     std::vector<float> h(mtx, mtx + (size_t)M * F);
     RY_TRY(upload(vc->arena, s1->ctx, h, &vc->d_mtx));
     for (VcSlot& sl : vc->slot) { RT_TRY(rt::event_create_fast(&sl.ev_mid)); RT_TRY(rt::event_create_fast(&sl.ev_done)); }
@@ -312,7 +287,6 @@ int ry_vc_submit(ry_vc* vc, const float* x_eff, const int* row_of, int n_eff, in
     RT_TRY(rt::d2h(sl.h_mc, sl.d_mc, (size_t)n_frames * M * sizeof(float), st1));
     RT_TRY(rt::event_record(sl.ev_mid, st1));
     RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));                                      // stage-2 starts when the spectrogram is ready
-    RY_TRY(vc_prefetch_bottom(vc, s1, s2));
     RY_TRY(vc_run_stage2(vc, s2, sl.d_sp, sl.d_out, n_frames));
     vc_keep_rows(vc, n_frames, &sl.k0, &sl.k1);
     RT_TRY(rt::d2h(sl.h_sp + (size_t)sl.k0 * F, sl.d_out + (size_t)sl.k0 * F, (size_t)(sl.k1 - sl.k0) * F * sizeof(float), st2));
@@ -492,7 +466,6 @@ int ry_vc_enqueue_device(ry_vc* vc, const float* x_eff_dev, const int* row_of_de
     RY_TRY(vc_enqueue_mid(vc, s1, sl.d_y1, row_of_dev, n_eff, n_frames, sp_floor, mc_out_dev, sl.d_sp));
     RT_TRY(rt::event_record(sl.ev_mid, st1));
     RT_TRY(rt::stream_wait_event(st2, sl.ev_mid));
-    RY_TRY(vc_prefetch_bottom(vc, s1, s2));
     RY_TRY(vc_run_stage2(vc, s2, sl.d_sp, sp_out_dev, n_frames));
     RT_TRY(rt::event_record(sl.ev_done, st2));
     sl.used = true;

@@ -120,29 +120,3 @@ RY_KERNEL(256) void ry_mc2sp(RyMc2spParams p) {                 // sp[n][f] = ex
     for (int m = 0; m < p.m; ++m) z = fmaf(row[m], p.mtx[(size_t)m * p.f + f], z);
     p.sp[idx] = expf(z) + p.floor;
 }
-
-
-// ---------------------------------------------------------------------------------------------
-// ry_touch: read up to eight buffers once, 16 bytes per lane, eight loads in flight, and throw the data away -- pulls the filters of the
-// weight-streaming layers at the bottom of the stage-2 U-Net (encoder c5 .. decoder c2: 134 MB at SYN-64, they do not depend on the
-// activations) towards the chip's last-level cache while the MFMA-bound encoder layers of the same window run (ry_vc.cpp, experiment
-// behind RY_VC_PREFETCH).  One wave per workgroup: the kernel takes a wave slot, not a CU, from the implicit GEMM running next to it.
-// ---------------------------------------------------------------------------------------------
-struct RyTouchParams { const float* buf[8]; unsigned n16[8]; int nbuf; float* sink; };
-
-RY_KERNEL(64) void ry_touch(RyTouchParams p) {
-    float acc = 0.f;
-    const unsigned stride = (unsigned)gridDim.x * 64u;
-    for (int b = 0; b < p.nbuf; ++b) {
-        const float* q = p.buf[b];
-        const unsigned n = p.n16[b];
-        for (unsigned i = (unsigned)blockIdx.x * 64u + threadIdx.x; i < n; i += 8u * stride) {
-            f32x4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const unsigned j = i + (unsigned)u * stride; v[u] = ry_ld4(q + (size_t)(j < n ? j : i) * 4); }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u][0];
-        }
-    }
-    if (acc == 1.2345678e38f) p.sink[0] = acc;                 // never true in practice: keeps the loads alive
-}

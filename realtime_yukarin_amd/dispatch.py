@@ -374,7 +374,7 @@ class ChunkDispatcher(object):
 
 def convert_worker_multi_gpu(acoustic_converter, super_resolution, time_length: float, extra_time: float, input_silent_threshold: float,
                              queue_input, queue_output, acquired_lock, devices: Sequence[int] = (0,), comm: str = 'auto', depth: int = 2,
-                             worker_hook: Optional[Callable] = None, mp_context: str = 'spawn') -> None:
+                             worker_hook: Optional[Callable] = None, mp_context: str = 'spawn', **dispatcher_kwargs) -> None:
     """Drop-in process target for the reference's `convert_worker` (/root/reference/realtime_voice_conversion/worker/convert_worker.py:17-59):
     same arguments and `Item` protocol, the reference's own `ConvertStream` for `add` / `fetch` (imported from the maintainer's installed
     `realtime_voice_conversion` package at call time), the windows converted on `devices`.  An item of `None` ends the loop."""
@@ -388,7 +388,7 @@ def convert_worker_multi_gpu(acoustic_converter, super_resolution, time_length: 
     pad = round(extra_time * stream.in_segment_method.sampling_rate)           # convert_stream.py:40-42
     pick = (pad, -pad, PICK_KEYS) if pad > 0 else None
     disp = ChunkDispatcher(acoustic_converter, super_resolution, devices, threshold=input_silent_threshold, comm=comm, depth=depth,
-                           worker_hook=worker_hook, mp_context=mp_context)
+                           worker_hook=worker_hook, mp_context=mp_context, **dispatcher_kwargs)
     items = {}
     try:
         acquired_lock.release()
