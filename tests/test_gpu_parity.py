@@ -440,3 +440,22 @@ def test_convert_batch_of_8_windows_against_the_oracle(syn64):
         print('convert_batch of 8 (gated windows: %s): worst mc %.2e, worst sp element-wise %.2e' % (list(gated), worst_mc, worst_sp))
         assert worst_mc < cases.TOL and worst_sp < cases.TOL
     core.close()
+
+
+def test_long_windows_2000_frames(syn64):
+    """The far end of the window sizes: 2000 real frames (2048 padded; 10 s of audio in one window -- an offline caller's choice, five
+    times BASELINE config #2) through the chained window call against the oracle, with a silent stretch; then the same window cut to
+    its last frame before a pad boundary (1919 -> 1920 padded) so that both 128-multiples around it are exercised."""
+    from realtime_yukarin_amd import sptk
+    (n1, t1), (n2, t2) = syn64
+    core = engine.VcCore(n1, n2, sptk.mc2sp_matrix(8, sptk.mcepalpha(16000), 1024))
+    for n in (2000, 1919):
+        effective = numpy.ones(n, bool); effective[700:1100] = False
+        x = synth.stage1_input(n, seed=2000 + n)[0][effective]
+        mc, sp = core.convert(x, effective)
+        mc_ref, sp_ref = _chained_oracle(t1, t2, x, effective, n)
+        e_mc, e_sp = rel_max(mc, mc_ref), float(numpy.abs(sp.astype(numpy.float64) / sp_ref - 1).max())
+        print('chained window of %d frames: mc %.2e, sp element-wise %.2e' % (n, e_mc, e_sp))
+        assert mc.shape == (n, synth.MC_DIMS) and sp.shape == (n, synth.FFT_BINS)
+        assert e_mc < cases.TOL and e_sp < cases.TOL and not mc[~effective].any()
+    core.close()

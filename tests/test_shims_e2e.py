@@ -250,3 +250,66 @@ def test_shims_end_to_end_gpu_config5_bf16_at_400_frames(tmp_path, gpu_ctx, monk
     assert 1e-5 < e_log < 3e-2 and e_mc < TOL and not out.mc[~exp['eff']].any()
     assert numpy.allclose(out.f0, exp['f0'], rtol=1e-6) and numpy.array_equal(out.ap, exp['ap'])
     vc.close(); ac.close(); sr.close()
+
+
+# ---------------------------------------------------------------- a NON-canonical stage-1 configuration: "mel + f0" in, mel out
+def _noncanonical_models(d, in_features):
+    """Model files whose stage 1 reads more than the mel-cepstrum (north star: "(mel/f0/ap) frame blocks"): in_channels = the summed widths."""
+    widths = {'mc': 9, 'f0': 1, 'ap': 513}
+    cin = sum(widths[k] for k in in_features)
+    (d1, P1), (d2, P2) = synth.model_params('SYN-8', stage1_in=cin)
+    save_npz(d / 's1.npz', P1)
+    save_npz(d / 's2.npz', P2)
+    (d / 's1.json').write_text(json.dumps({
+        'dataset': {'acoustic_param': {'sampling_rate': FS, 'frame_period': FRAME_PERIOD, 'order': 8, 'alpha': 0.41},
+                    'in_features': list(in_features), 'out_features': ['mc']},
+        'model': {'in_channels': cin, 'out_channels': 9, 'generator_base_channels': d1.base, 'generator_extensive_layers': 8}}))
+    (d / 's2.json').write_text(json.dumps({
+        'dataset': {'param': {'voice_param': {'sample_rate': FS}, 'acoustic_feature_param': {'frame_period': FRAME_PERIOD, 'order': 8}}},
+        'model': {'generator_base_channels': d2.base, 'generator_extensive_layers': 8}}))
+    numpy.save(str(d / 'in_stat.npy'), {'mean': numpy.log(200.0), 'var': 0.04})
+    numpy.save(str(d / 'tg_stat.npy'), {'mean': numpy.log(300.0), 'var': 0.09})
+    return P1, P2
+
+
+def test_non_canonical_in_features_take_the_generic_path_and_whole_objects_emu(tmp_path, on_emulator):
+    """`in_features = ['mc', 'f0']` (C_in = 10): `AcousticConverter.convert` concatenates the columns (`encode_feature`), the window is NOT
+    fusable, so the mirror VoiceChanger runs the reference's step order call by call (stage-1 on the GPU, mc2sp on the host, stage-2 on
+    the GPU) -- against the composed oracle; and the dispatcher notices by itself that such windows cannot travel without their `ap`
+    block / as bare arrays (`lean` off) and returns the same bits as the in-process call."""
+    from realtime_yukarin_amd import dispatch
+    from realtime_yukarin_amd.voice_changer import VoiceChanger
+    from yukarin import AcousticFeature, Wave
+    from dispatch_hooks import emu_hook
+    n = 64
+    P1, P2 = _noncanonical_models(tmp_path, ('mc', 'f0'))
+    t1, t2 = torch_ref.TorchUNet(P1), torch_ref.TorchUNet(P2)
+    ac, sr = build_converters(tmp_path)
+    assert not ac.fusable() and ac.desc.in_ch == 10
+    wave, feat = make_window(n, 77)
+
+    def f_in():
+        f = AcousticFeature(**{k: v.copy() for k, v in feat.items()}); f.wave = Wave(wave=wave, sampling_rate=FS)
+        return f
+    vc = VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=60)
+    assert vc._fused_core() is None
+    out = vc.convert_from_acoustic_feature(f_in())
+    # the composed oracle with the concatenated input columns
+    eff = oef.separate_effective_mask(wave, FS, n, 60, 1024, FRAME_PERIOD)
+    assert 0 < eff.sum() < n
+    x = numpy.concatenate([feat['mc'], feat['f0']], axis=1)[eff]
+    mc = numpy.zeros((n, 9), numpy.float32); mc[eff] = torch_ref.stage1_convert_core(t1, x)
+    sp_mid = (omc.mc2sp(mc, omc.mcepalpha(FS), 1024) + 1e-16).astype(numpy.float32)
+    sp = torch_ref.stage2_convert(t2, sp_mid)
+    assert float(numpy.abs(out.mc - mc).max() / numpy.abs(mc).max()) < TOL and not out.mc[~eff].any()
+    assert float(numpy.abs(out.sp.astype(numpy.float64) / sp - 1).max()) < TOL
+    assert numpy.array_equal(out.ap[eff], feat['ap'][eff]) and not out.ap[~eff].any()
+    with dispatch.ChunkDispatcher(ac, sr, [0], threshold=60, comm='host', worker_hook=emu_hook, start_timeout=900) as d:
+        assert d.lean is False
+        d.submit(0, f_in(), discard=(7, 7), pick=(7, -7, ('f0', 'ap', 'sp', 'voiced', 'mc')))
+        d.submit(1, f_in())
+        (_, a), (_, b) = d.drain(timeout=900)
+    for k in ('f0', 'ap', 'sp', 'voiced', 'mc'):
+        assert numpy.array_equal(getattr(b, k), getattr(out, k)), k
+        assert numpy.array_equal(getattr(a, k), getattr(out, k)[7:-7]), k
+    vc.close(); ac.close(); sr.close()
