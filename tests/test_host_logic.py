@@ -99,3 +99,26 @@ def test_rendezvous_name_is_the_launchers_identity_not_an_mtime(tmp_path, monkey
     assert os.path.basename(p).startswith('comm_' + a + '_') and (os.stat(d).st_mode & 0o077) == 0 and d.startswith(str(tmp_path))
     monkeypatch.setenv('RY_COMM_NONCE', 'launch-42')
     assert 'comm_launch-42_' in rdist._rendezvous_path()
+
+
+def test_bench_line_stays_short_enough_for_the_drivers_tail():
+    """The driver keeps an 8 KB tail of bench.py's output; round 3's 14 KB line lost `device_ms_per_step_rank0` that way.  The printed line
+    is built by `bench.compact_line` from the long form: with every optional block present (taken from the committed round-4 details file) it
+    must stay under 6 KB and keep the headline, every bracket and the two required objects."""
+    import json
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    import bench
+    full = json.loads((root / 'profiles' / 'r04_d_bench_details.json').read_text())
+    line = bench.compact_line(full, 'gpurun_out/bench_details_1gpu.json')
+    text = json.dumps(line)
+    assert len(text) < 6144, len(text)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+              'config', 'roofline', 'cpu_baseline', 'brackets', 'spread', 'slow_brackets', 'device_ms_per_step_rank0', 'small_window'):
+        assert k in line, k
+    assert len(line['brackets']) == line['repeats'] == 7 and all(set(b) == {'wall_ms', 'enq_ms', 'dev_ms'} for b in line['brackets'])
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(line['roofline'])
+    assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(line['cpu_baseline'])
+    assert 'kernels' in full and 'kernels' not in line and 'note' not in json.dumps(line['small_window'])
