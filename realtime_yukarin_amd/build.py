@@ -45,33 +45,36 @@ def _compile_units(cc, flags, obj_dir: Path, suffix: str, extra_sources=()):
         return [str(o) for o in ex.map(one, jobs)]
 
 
-def build_product(force: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950 -> realtime_yukarin_amd/libry355.so (cross-compiles without a GPU)."""
-    if force or _stale(LIB, SOURCES):
+def build_product(force: bool = False, defs=(), suffix: str = '') -> Path:
+    """hipcc --offload-arch=gfx950 -> realtime_yukarin_amd/libry355.so (cross-compiles without a GPU).  `defs` / `suffix`: an experiment build
+    with extra -D switches next to the product (`libry355<suffix>.so`, e.g. for an A/B of a compile-time variant on the GPU box)."""
+    lib = LIB if not suffix else LIB.with_name('libry355%s.so' % suffix)
+    if force or _stale(lib, SOURCES):
         cc = _hipcc()
-        objs = _compile_units(cc, ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-x', 'hip'],
-                              ROOT / 'gpurun_out' / '_obj', '')
-        tmp = LIB.with_suffix('.so.tmp%d' % os.getpid())                   # link aside, then rename: a process that has the old library mapped keeps it
+        objs = _compile_units(cc, ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value'] + ['-D' + d for d in defs] + ['-x', 'hip'],
+                              ROOT / 'gpurun_out' / '_obj', suffix)
+        tmp = lib.with_suffix('.so.tmp%d' % os.getpid())                   # link aside, then rename: a process that has the old library mapped keeps it
         subprocess.run([cc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', str(tmp)], check=True, cwd=str(ROOT))
-        os.replace(str(tmp), str(LIB))
-    return LIB
+        os.replace(str(tmp), str(lib))
+    return lib
 
 
-def build_emu(force: bool = False) -> Path:
+def build_emu(force: bool = False, defs=(), suffix: str = '') -> Path:
     """Same sources as plain C++ on the fiber SIMT emulator (tests/emu) -- test infrastructure only."""
     deps = SOURCES + [EMU_DIR / 'ry_emu.h', EMU_DIR / 'ry_emu.cpp']
-    if force or _stale(EMU_LIB, deps):
+    emu_lib = EMU_LIB if not suffix else EMU_LIB.with_name('libry355_emu%s.so' % suffix)
+    if force or _stale(emu_lib, deps):
         cxx = '/opt/rocm/lib/llvm/bin/clang++'
         if not Path(cxx).exists():
             cxx = shutil.which('clang++') or shutil.which('g++')
         # plain -O2 on purpose: with AVX-512 enabled (-march=native on this host) ROCm's clang drops the tail of the fminf chain in
         # ry_pad_min_rows<16> (the remainder after the 8-wide gather is only run when a NaN was seen) -- found with the emulator tests
-        objs = _compile_units(cxx, ['-x', 'c++', '-DRY_HOST_EMU', '-O2', '-std=c++17', '-fPIC', '-pthread', '-Wno-psabi',
-                                    '-I' + str(EMU_DIR), '-I' + str(CSRC)], ROOT / 'gpurun_out' / '_obj', '_emu', [EMU_DIR / 'ry_emu.cpp'])
-        tmp = EMU_LIB.with_suffix('.so.tmp%d' % os.getpid())              # several test workers may build at once: link aside, then rename
+        objs = _compile_units(cxx, ['-x', 'c++', '-DRY_HOST_EMU', '-O2', '-std=c++17', '-fPIC', '-pthread', '-Wno-psabi'] + ['-D' + d for d in defs] +
+                              ['-I' + str(EMU_DIR), '-I' + str(CSRC)], ROOT / 'gpurun_out' / '_obj', '_emu' + suffix, [EMU_DIR / 'ry_emu.cpp'])
+        tmp = emu_lib.with_suffix('.so.tmp%d' % os.getpid())              # several test workers may build at once: link aside, then rename
         subprocess.run([cxx, '-shared', '-fPIC', '-pthread'] + objs + ['-o', str(tmp)], check=True, cwd=str(ROOT))
-        os.replace(str(tmp), str(EMU_LIB))
-    return EMU_LIB
+        os.replace(str(tmp), str(emu_lib))
+    return emu_lib
 
 
 if __name__ == '__main__':
