@@ -23,6 +23,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 RY_DEV f32x16 ry_mfma_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_4x4x1_16B_f32: SIXTEEN independent 4 x 4 x 1 outer products per instruction (8 cycles per SIMD, the same 64 FLOP / clk as the
+// 32 x 32 form).  Lane l belongs to block l >> 2 and supplies A_b[i = l & 3] and B_b[j = l & 3]; register r of lane l accumulates
+// D_b[i = r][j = l & 3] += A_b[r] * B_b[l & 3].  ry_c2d_os maps the blocks to sixteen K indices: a K-batched small-tile GEMM.
+RY_DEV f32x4 ry_mfma_4x4x1(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 ry_bf16x8 __attribute__((ext_vector_type(8)));

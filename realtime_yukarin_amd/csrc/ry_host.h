@@ -161,12 +161,14 @@ struct Layer {
     float* wig = nullptr;                // stage-2 implicit-GEMM blocks [phase][N/64][tap][Ctot/32][fragment order], see wig_inblock()
     float* wdir = nullptr;               // stage-2 direct [phase][tap][Ctot][N]
     float* wig16 = nullptr;              // stage-2 implicit-GEMM bf16 blocks [phase][N/64][tap][Ctot/64][fragment order], see wig16_inblock() (ry_net_set_dtype)
+    float* w2os = nullptr;               // stage-2 output-stationary kernel ry_c2d_os: [phase][N/4][tap][Ctot/64][lane][4], see relayout_c2d_os() (the weight-streaming layers only)
     float* wigx3 = nullptr;              // split-bf16 blocks [phase][N/64][tap][3 Ctot/64][fragment order]: K runs over [hi | hi | lo] per source, see build_wigx3()
     int cin() const { return cin_a + cin_b; }
 };
 
 enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4, PATH_IGEMM_BF16 = 5,
-       PATH_IGEMM_X3 = 6 };   // op-level selector only (ry_conv2d): runs as PATH_IGEMM_BF16 with LayerPlan::x3
+       PATH_IGEMM_X3 = 6,     // op-level selector only (ry_conv2d): runs as PATH_IGEMM_BF16 with LayerPlan::x3
+       PATH_OS2D = 7 };       // output-stationary weight-streaming layer (ry_c2d_os): one node, no slabs
 enum { TILE_128x128 = 1, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5, TILE_96x128 = 6 };   // (2 and 7 were the 256-row tiles of the register-staged kernel, removed in round 3)
 
 struct LayerPlan {
@@ -180,6 +182,7 @@ struct LayerPlan {
     // stage-2
     int path = 0, tile = 0;
     bool any_m_patch = false;                 // op-level calls (tests): take the input-patch variants whatever the row count
+    int os2_mt4 = 0, os2_nt4 = 0, os2_waves = 0, os2_depth = 0;   // PATH_OS2D: tile of 4 mt4 pixels x 4 nt4 channels per workgroup, waves that share the K axis, units in flight per wave
     int kg = 1;                               // K groups inside a workgroup (LDS-DMA implicit GEMM): 2 = split-K summed through the LDS
     float* out = nullptr;                     // NHWC activation, fp32
     unsigned short* out16 = nullptr;          // NHWC activation, bf16 copy for consumers on the bf16 path (bf16 / split-bf16 mode only)

@@ -46,6 +46,20 @@ RY_DEV int ry_fdiv(int x, int d, float inv_d) {
     return q;
 }
 
+// Keeps two values in separate registers: without it the compiler rewrites `c ? v[a] : v[b]` on a register array into a
+// select over an INDEX and then emulates the dynamic register index with a chain of A compare / v_cndmask pairs per access
+// (measured: the 31-shuffle reduction of 32 sums grew to ~5000 instructions and a layer from 8 to 26-65 us).
+RY_DEV void ry_keep2(float& a, float& b) {
+#ifndef RY_HOST_EMU
+    asm volatile("" : "+v"(a), "+v"(b));
+#endif
+}
+RY_DEV int ry_bitrev(int v, int bits) {            // reverse the low `bits` bits
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
 // four fp32 -> four bf16 (RNE), one 8-byte store
 RY_DEV void ry_st4_bf16(unsigned short* q, f32x4 v) {
     u16x4 h;
@@ -732,6 +746,195 @@ RY_KERNEL(256) void ry_splitk_reduce_wide(RyReduceParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// ry_c2d_os<MT4, NT4, WAVES, DEPTH> -- stage-2 layer, OUTPUT-STATIONARY form for the weight-streaming bottom of the U-Net (round 5).
+// A layer with a handful of output pixels (encoder c6 / c7, decoder c0 / c1 at 300 frames: 12-48 pixels against 16.8-33.5 MB of filters)
+// is a stream of filters with a little arithmetic attached.  The implicit GEMM above can only fill the chip with it by cutting K over
+// hundreds of workgroups: two chunks each -- all prologue and epilogue -- then raw slabs and a reduce launch of equal length.  Here a
+// workgroup owns a tile of 4 MT4 pixels x 4 NT4 output channels over the WHOLE K axis (taps x input channels): no slabs, no reduce
+// node, one fixed summation order.  The arithmetic runs on v_mfma_f32_4x4x1_16B_f32 with its sixteen independent blocks mapped to
+// sixteen K positions: lane (block b, i) feeds pixel i / output channel i of K position b, so a 16-byte load per lane is 4 K steps for
+// a 4-pixel (4-channel) group and 64 input channels per wave-instruction -- a K-batched small-tile GEMM at the full fp32 matrix rate
+// whose tile can be as small as 4 x 4 (the 32 x 32 form needs 32 output channels per workgroup, i.e. 16 workgroups for 512 channels).
+//   K units of 64 input channels x one tap are dealt to the WAVES waves of the workgroup in contiguous runs; every wave streams its
+//   filters ([phase][N / 4][tap][C / 64][lane][4]: one contiguous KiB per (4 channels, unit), consecutive units consecutive) and its
+//   activations (NHWC, out-of-image taps read the zero pixel behind the buffer) straight into registers through a ring of DEPTH
+//   units in flight, no LDS, no barrier in the K loop;
+//   then: reduce-scatter over the sixteen blocks (lane bits 2-5: DPP inside a row of 16, ds_bpermute across), a fixed-order sum over
+//   the waves through the LDS, folded BN + activation, dense store.
+// The host guarantees (launch_c2d_os): C1, C2 multiples of 64, N a multiple of 4 NT4, units % WAVES == 0, (units / WAVES) % DEPTH == 0,
+// sources followed by a zeroed pixel.
+// ---------------------------------------------------------------------------------------------
+struct RyC2dOsParams {
+    const float* src1;
+    const float* src2;          // second source of a skip concat (channels C1 .. C1 + C2), or null
+    const float* wt;            // [phase][N / 4][tap][(C1 + C2) / 64][lane = 4 * ((c % 64) / 4) + n % 4][c % 4]
+    const float* scale;
+    const float* shift;
+    float* out;                 // NHWC, or null when only the bf16 copy is wanted
+    unsigned short* out16;      // optional bf16 copy for consumers on the bf16 pipe (null in fp32 mode)
+    int x3;                     // out16 format: 0 = [pixel][N] bf16, 1 = split-bf16 [pixel][hi (N) | lo (N)]
+    int C1, C2;
+    int B, Hi, Wi, Ho, Wo;
+    int Mh, Mw, M;              // row grid per image (conv: output pixels, sub-pixel deconv: input pixels), rows in all = B * Mh * Mw
+    int stride, pad, ostride;   // as RyConvGeom
+    int ntaps, nphases;
+    int N;
+    int act;
+    float slope;
+    int mtiles, ntiles;         // tiles of 4 MT4 rows x 4 NT4 channels; 1-D grid, XCD-ordered: the M-tiles of one filter slice run on one XCD
+    unsigned zp1, zp2;          // byte offset of the zeroed pixel behind each source
+    int kw, dil;                // convolution: taps per kernel row, dilation (tap (ky, kx) reads input offset (ky, kx) * dil); the sub-pixel deconvolution
+                                // (ostride == 2) has 4 phases (py, px) of 2 x 2 taps (ty, tx) reading input offset py ? 1 - ty : -ty (likewise x)
+    float inv_Mimg, inv_Mw, inv_mtiles, inv_ntiles, inv_cpt, inv_kw;
+};
+
+// one step of the reduce-scatter over the K blocks: lanes with bit MASK set keep the upper half of the sums
+template <int NV, int MASK>
+RY_DEV void ry_rs_step(const float (&v)[NV], float (&h)[NV / 2], int lane) {
+    const bool up = (lane & MASK) != 0;
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) {
+        float lo = v[i], hi = v[i + NV / 2];
+        ry_keep2(lo, hi);
+        const float recv = ry_shfl_xor_c<MASK>(up ? lo : hi);
+        h[i] = (up ? hi : lo) + recv;
+    }
+}
+
+template <int MT4, int NT4, int WAVES, int DEPTH>
+RY_KERNEL(64 * WAVES, 2) void ry_c2d_os(RyC2dOsParams p) {
+    constexpr int MT = 4 * MT4, NT = 4 * NT4;
+    constexpr int V = MT4 * NT4 * 4, VP = (V + 15) / 16 * 16, L = VP / 16;      // partial sums per lane, padded for the 16-way scatter
+    static_assert(DEPTH * (MT4 + NT4) <= 56, "loads in flight per wave stay below the vmcnt range");
+    __shared__ float red[WAVES * VP * 4];
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = ry_uniform(tid >> 6);
+    const int blk = lane >> 2, sub = lane & 3;
+    const int total = p.nphases * p.ntiles * p.mtiles;
+    const int per_xcd = (total + 7) >> 3;
+    const int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);      // XCD b % 8 owns a contiguous run of (slice, M-tile) pairs
+    if (lid >= total) return;
+    const int sl = ry_fdiv(lid, p.mtiles, p.inv_mtiles), mt = lid - sl * p.mtiles;
+    const int phase = ry_fdiv(sl, p.ntiles, p.inv_ntiles), nt = sl - phase * p.ntiles;
+    const int m0 = mt * MT, n0 = nt * NT;
+    const int Mimg = p.Mh * p.Mw;
+
+    // Byte offset of the input pixel of (source, tap, row of the tile), or of the source's zero pixel when the tap falls outside the image
+    // or the row outside the batch: a table in the LDS, filled once.  The K loop then reads MT4 entries whenever its tap or source changes
+    // -- LDS reads and lgkmcnt, nothing that touches the vector-memory counter the ring of loads in flight is timed by.
+    __shared__ unsigned otab[2 * 16 * MT];
+    const int cpt1 = p.C1 >> 6, cpt = (p.C1 + p.C2) >> 6;
+    {
+        const int per_src = p.ntaps * MT;
+        for (int e = tid; e < 2 * per_src; e += 64 * WAVES) {
+            const int src = e >= per_src ? 1 : 0, e1 = e - src * per_src;
+            const int tap = ry_fdiv(e1, MT, 1.0f / MT), rl = e1 - tap * MT;
+            const int r = m0 + rl;
+            const int b = ry_fdiv(r, Mimg, p.inv_Mimg), rem = r - b * Mimg;
+            const int y = ry_fdiv(rem, p.Mw, p.inv_Mw), x = rem - y * p.Mw;
+            int dy, dx;
+            if (p.ostride == 2) { const int ty = tap >> 1, tx = tap & 1; dy = (phase >> 1) ? 1 - ty : -ty; dx = (phase & 1) ? 1 - tx : -tx; }
+            else { const int ky = ry_fdiv(tap, p.kw, p.inv_kw), kx = tap - ky * p.kw; dy = ky * p.dil; dx = kx * p.dil; }
+            const int iy = y * p.stride - p.pad + dy, ix = x * p.stride - p.pad + dx;
+            const bool ok = r < p.M && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const unsigned pix = (unsigned)((b * p.Hi + iy) * p.Wi + ix);
+            otab[e] = ok ? pix * (unsigned)((src ? p.C2 : p.C1) * 4) : (src ? p.zp2 : p.zp1);
+        }
+    }
+    __syncthreads();
+
+    const int U = p.ntaps * cpt, nu = U / WAVES;
+    const int u0 = wave * nu;
+    // filters of (phase, channel group n0 / 4 + h), unit u: one KiB at ((phase * N / 4 + n0 / 4 + h) * U + u) * 256 floats
+    const float* wq = p.wt + ((size_t)(phase * (p.N >> 2) + (n0 >> 2)) * (size_t)U + (size_t)u0) * 256 + lane * 4;
+    const size_t wh = (size_t)U * 256;
+
+    // issue pointer: (tap, chunk) of the next unit to request; the per-lane byte offsets of the MT4 pixels change with the tap and with the source
+    int i_tap = ry_fdiv(u0, cpt, p.inv_cpt), i_chunk = u0 - i_tap * cpt;
+    bool fresh = true;
+    unsigned pb[MT4];
+    const float* sbase = p.src1;
+    auto set_tap = [&]() {
+        const bool first = i_chunk < cpt1;
+        sbase = first ? p.src1 : p.src2 - (size_t)cpt1 * 64;            // + chunk * 64 floats below
+        const unsigned* ot = otab + ((first ? 0 : p.ntaps) + i_tap) * MT + sub;
+#pragma unroll
+        for (int g = 0; g < MT4; ++g) pb[g] = ot[4 * g] + (unsigned)blk * 16u;
+    };
+
+    f32x4 xa[DEPTH][MT4], wb[DEPTH][NT4];
+    f32x4 acc[MT4][NT4];
+#pragma unroll
+    for (int g = 0; g < MT4; ++g)
+#pragma unroll
+        for (int h = 0; h < NT4; ++h) acc[g][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int d) {
+        if (fresh || i_chunk == 0 || i_chunk == cpt1) { set_tap(); fresh = false; }      // wave-uniform
+        const char* sb = reinterpret_cast<const char*>(sbase + i_chunk * 64);
+#pragma unroll
+        for (int h = 0; h < NT4; ++h) wb[d][h] = ry_ld4(wq + (size_t)h * wh);
+#pragma unroll
+        for (int g = 0; g < MT4; ++g) xa[d][g] = *reinterpret_cast<const f32x4*>(sb + pb[g]);
+        wq += 256;
+        if (++i_chunk == cpt) { i_chunk = 0; ++i_tap; }
+    };
+    auto consume = [&](int d) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < MT4; ++g)
+#pragma unroll
+                for (int h = 0; h < NT4; ++h) acc[g][h] = ry_mfma_4x4x1(xa[d][g][t], wb[d][h][t], acc[g][h]);
+    };
+
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(d);
+    for (int it = DEPTH; it < nu; it += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) { consume(d); issue(d); }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) consume(d);
+
+    // ---- sum over the sixteen K blocks (reduce-scatter: lane bits 2..5), then over the waves (LDS, fixed order) ----
+    float v16[VP];
+#pragma unroll
+    for (int q = 0; q < VP; ++q) v16[q] = q < V ? acc[(q >> 2) / NT4][(q >> 2) % NT4][q & 3] : 0.f;      // q = (g * NT4 + h) * 4 + r
+    float v8[VP / 2], v4[VP / 4], v2[VP / 8], v1[L];
+    ry_rs_step<VP, 4>(v16, v8, lane);
+    ry_rs_step<VP / 2, 8>(v8, v4, lane);
+    ry_rs_step<VP / 4, 16>(v4, v2, lane);
+    ry_rs_step<VP / 8, 32>(v2, v1, lane);
+    const int q0 = ry_bitrev(blk, 4) * L;                     // this lane now holds the sums q0 .. q0 + L - 1 of column `sub`
+#pragma unroll
+    for (int u = 0; u < L; ++u) red[(wave * VP + q0 + u) * 4 + sub] = v1[u];
+    __syncthreads();
+    const int pdy = p.ostride == 2 ? phase >> 1 : 0, pdx = p.ostride == 2 ? phase & 1 : 0;
+    for (int idx = tid; idx < MT * NT; idx += 64 * WAVES) {
+        const int pxl = idx / NT, c = idx - pxl * NT;
+        const int q = ((pxl >> 2) * NT4 + (c >> 2)) * 4 + (pxl & 3), j = c & 3;
+        float s = red[q * 4 + j];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) s += red[(w * VP + q) * 4 + j];
+        const int r = m0 + pxl;
+        if (r < p.M) {
+            const int b = ry_fdiv(r, Mimg, p.inv_Mimg), rem = r - b * Mimg;
+            const int y = ry_fdiv(rem, p.Mw, p.inv_Mw), x = rem - y * p.Mw;
+            const size_t opix = ((size_t)b * p.Ho + y * p.ostride + pdy) * p.Wo + x * p.ostride + pdx;
+            const int n = n0 + c;
+            const float o = ry_act(fmaf(s, p.scale[n], p.shift[n]), p.act, p.slope);
+            if (p.out) p.out[opix * p.N + n] = o;
+            if (p.out16) {
+                const unsigned short hi = ry_f2bf(o);
+                if (p.x3) { p.out16[opix * (size_t)(2 * p.N) + n] = hi; p.out16[opix * (size_t)(2 * p.N) + p.N + n] = ry_f2bf(o - ry_bf2f(hi)); }
+                else p.out16[opix * p.N + n] = hi;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Generic direct convolution (VALU): one thread per (output pixel, output channel), channel fastest.
 // ---------------------------------------------------------------------------------------------
 struct RyDirectParams {
@@ -1290,14 +1493,6 @@ struct RyC1dOsParams {
     unsigned long long* dbg;    // diagnostics (-DRY_S1_STAMPS builds): per-workgroup s_memtime stamps at the phase boundaries, else null
 };
 
-// Keeps two values in separate registers: without it the compiler rewrites `c ? v[a] : v[b]` on a register array into a
-// select over an INDEX and then emulates the dynamic register index with a chain of A compare / v_cndmask pairs per access
-// (measured: the 31-shuffle reduction of 32 sums grew to ~5000 instructions and a layer from 8 to 26-65 us).
-RY_DEV void ry_keep2(float& a, float& b) {
-#ifndef RY_HOST_EMU
-    asm volatile("" : "+v"(a), "+v"(b));
-#endif
-}
 
 // Reduce-scatter over the 64 lanes of a wave: every lane brings N partial sums, the step with mask m halves them (lanes with bit m
 // set keep the upper half), masks 1, 2, 4, 8, 16, 32 in that order -- the steps that move the most values are the in-row DPP ones.
@@ -1330,11 +1525,6 @@ struct RyReduceScatter64<1, MASK> {
         return r;
     }
 };
-RY_DEV int ry_bitrev(int v, int bits) {            // reverse the low `bits` bits
-    int r = 0;
-    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
-    return r;
-}
 
 // USRC: every wave reads ONE source (no second source, or the first one ends on a multiple of 64 channels -- the U-Net's case): the
 // source, its row pitch and the row offsets are then wave-uniform and live in SGPRs, and a load costs one VALU add instead of a

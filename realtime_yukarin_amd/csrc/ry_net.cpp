@@ -203,10 +203,36 @@ static bool igemm_eligible(const Layer& l) {
     return l.cin_a % 32 == 0 && l.cin_b % 32 == 0 && l.cout % 64 == 0 && l.cin() > 0;
 }
 
+// ry_c2d_os filters: [phase][N/4][tap][C/64] blocks of 4 output channels x 64 input channels, one KiB each in the order the lanes load it:
+// lane = 4 * ((c % 64) / 4) + n % 4 holds the four consecutive input channels c % 4 = 0..3 of its output channel -- K position
+// 4 * (lane / 4) + t of the block for the t-th v_mfma_f32_4x4x1_16B_f32 of the unit.  Consecutive (tap, chunk) units of one channel
+// group are consecutive KiB: a wave streams its run of the K axis as one contiguous range.
+static bool c2d_os_eligible(const Layer& l) {
+    return l.cin_a % 64 == 0 && l.cin_b % 64 == 0 && l.cout % 4 == 0 && l.cin() > 0 && l.cin_a <= 2048 && l.cin_b <= 2048;    // (a source's zero pixel is ZTAIL floats)
+}
+
+static void relayout_c2d_os(const Layer& l, const float* W, std::vector<float>& out) {
+    const TapTable t = make_taps(l);
+    const int C = l.cin(), N = l.cout, cpt = C / 64;
+    out.resize((size_t)t.nphases * N * t.ntaps * C);
+    for (int ph = 0; ph < t.nphases; ++ph)
+        for (int n = 0; n < N; ++n)
+            for (int tt = 0; tt < t.ntaps; ++tt)
+                for (int c = 0; c < C; ++c) {
+                    const size_t blk = (((size_t)ph * (N / 4) + n / 4) * t.ntaps + tt) * cpt + c / 64;
+                    out[blk * 256 + (size_t)((((c % 64) >> 2) * 4 + (n & 3)) * 4 + (c & 3))] = w2d_at(l, W, n, c, t.ky[ph][tt], t.kx[ph][tt]);
+                }
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-layer launch plans
 // ------------------------------------------------------------------------------------------------
-static int prepare_layer(ry_ctx* ctx, Arena& arena, Layer& l, int ndim, float eps, const float* W, const float* b, const float* bn) {
+// Filters above this size (floats) get the ry_c2d_os layout next to the implicit-GEMM one when a predictor is created: the layers whose time
+// is the stream of their filters (SYN-64: encoder c4 .. c7, decoder c0 .. c3, 16.8 - 33.5 MB each).  Whether a plan uses it depends on the
+// window (build_plan: few enough output pixels).
+static size_t g_os2_min_filter = (size_t)1 << 21;      // RY_OS2_MINW (floats; tests lower it so that small predictors take the path)
+
+static int prepare_layer(ry_ctx* ctx, Arena& arena, Layer& l, int ndim, float eps, const float* W, const float* b, const float* bn, bool want_os2 = false) {
     std::vector<float> sc, sh, w;
     fold_scale_shift(l, b, bn, eps, sc, sh);
     // scale/shift padded to a multiple of 4 floats (16-byte epilogue loads)
@@ -222,6 +248,9 @@ static int prepare_layer(ry_ctx* ctx, Arena& arena, Layer& l, int ndim, float ep
     } else {
         if (l.k * l.k > 16) return fail(RY_EINVAL, "%s: 2-D kernels larger than 4x4 are not supported", l.name);
         if (igemm_eligible(l)) { relayout_igemm(l, W, w); RY_TRY(upload(arena, ctx, w, &l.wig)); }
+        if (c2d_os_eligible(l) && (want_os2 || (l.wig && (size_t)l.cin() * l.cout * l.k * l.k >= g_os2_min_filter))) {
+            relayout_c2d_os(l, W, w); RY_TRY(upload(arena, ctx, w, &l.w2os));
+        }
         relayout_direct(l, W, w);
         RY_TRY(upload(arena, ctx, w, &l.wdir));
     }
@@ -230,7 +259,7 @@ static int prepare_layer(ry_ctx* ctx, Arena& arena, Layer& l, int ndim, float ep
 
 // Activation buffers that an implicit-GEMM layer may read end in ZTAIL zeroed floats: the LDS-DMA kernel fetches its padding
 // from there (RyConvGeom::zoff1 / zoff2); nothing ever writes them.
-static const size_t ZTAIL = 64;
+static const size_t ZTAIL = 2048;     // (round 5: a whole zeroed PIXEL of up to 2048 channels -- ry_c2d_os fetches out-of-image taps from it at any channel offset)
 static int alloc_ztail(ry_ctx* ctx, Arena& arena, float** p, size_t nfloats) {
     RY_TRY(arena.alloc(p, nfloats + ZTAIL));
     RT_TRY(rt::dmemset(*p + nfloats, 0, ZTAIL * sizeof(float), ctx->stream));
@@ -407,7 +436,99 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
     if (*splits * *kg > nk) { *kg = 1; if (*splits > nk) *splits = nk; }
 }
 
+// ---- stage-2 output-stationary layers (ry_c2d_os) ----
+// (MT4, NT4, WAVES, DEPTH): tile of 4 MT4 rows x 4 NT4 output channels per workgroup, WAVES waves that deal the K units among them, DEPTH
+// units in flight per wave.  Every instantiation keeps accumulators + ring inside 256 registers (two workgroups of 4 waves per CU).
+#define RY_OS2_CONFIGS(X)                                                                                              \
+    X(1, 1, 4, 8) X(1, 1, 4, 4) X(1, 1, 8, 4) X(1, 1, 8, 2) X(2, 1, 4, 8) X(2, 1, 4, 4) X(2, 1, 8, 4) X(2, 1, 8, 2)     \
+    X(3, 1, 4, 8) X(3, 1, 4, 4) X(3, 1, 8, 4) X(3, 1, 8, 2) X(4, 1, 4, 8) X(4, 1, 4, 4) X(4, 1, 8, 4) X(4, 1, 8, 2)     \
+    X(6, 1, 4, 4) X(6, 1, 8, 4) X(6, 1, 8, 2)                                                                           \
+    X(1, 2, 4, 8) X(1, 2, 4, 4) X(1, 2, 8, 4) X(1, 2, 8, 2) X(2, 2, 4, 8) X(2, 2, 4, 4) X(2, 2, 8, 4) X(2, 2, 8, 2)     \
+    X(3, 2, 4, 8) X(3, 2, 4, 4) X(3, 2, 8, 4) X(3, 2, 8, 2) X(4, 2, 4, 4) X(4, 2, 8, 4) X(4, 2, 8, 2)                   \
+    X(6, 2, 4, 4) X(6, 2, 8, 4) X(6, 2, 8, 2)                                                                           \
+    X(1, 4, 4, 8) X(1, 4, 4, 4) X(1, 4, 8, 4) X(1, 4, 8, 2) X(2, 4, 4, 4) X(2, 4, 8, 4) X(2, 4, 8, 2)                   \
+    X(3, 4, 4, 4) X(3, 4, 8, 4) X(3, 4, 8, 2) X(4, 4, 4, 4) X(4, 4, 8, 4) X(4, 4, 8, 2) X(6, 4, 4, 2) X(6, 4, 8, 2)
+
+static bool os2_has_config(int mt4, int nt4, int waves, int depth) {
+#define X(A, B, C, D) if (mt4 == A && nt4 == B && waves == C && depth == D) return true;
+    RY_OS2_CONFIGS(X)
+#undef X
+    return false;
+}
+
+static int g_os2_maxm = 64;            // RY_OS2_MAXM: a layer with at most this many rows per phase (batch x pixels) and the ry_c2d_os filter layout runs output-stationary (0: never)
+static int g_os2_force[16][4];         // RY_OS2="layer:mt4:nt4:waves:depth,...": tuning aid, fixes the slice of single layers ("layer:0" keeps that layer on the implicit GEMM)
+static bool g_os2_forced[16];
+
+// Slice of one layer.  Per-CU operand traffic is K x (rows + channels) of the tile per workgroup, so the tile should be as square as the
+// accumulator budget allows -- but the chip has 256 CUs to fill and the filters want to be streamed by all of them.
+static bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int* waves, int* depth) {
+    static const int MTS[5] = {1, 2, 3, 4, 6};
+    if (*waves == 0) *waves = 4;
+    if (U % *waves != 0) return false;
+    const int nu = U / *waves;
+    if (*mt4 == 0) {
+        int best = 0; long best_rows = 1L << 40;
+        for (int i = 0; i < 5; ++i) {                                   // least padded rows, then the larger tile
+            const long tiles = (M + 4 * MTS[i] - 1) / (4 * MTS[i]), rows = tiles * 4 * MTS[i];
+            if (rows < best_rows || (rows == best_rows && MTS[i] <= 3)) { best_rows = rows; best = MTS[i]; }
+        }
+        *mt4 = best;
+    }
+    const long mtiles = (M + 4 * *mt4 - 1) / (4 * *mt4);
+    if (*nt4 == 0) {
+        *nt4 = 1;
+        for (int c : {4, 2}) {
+            if (N % (4 * c) != 0 || *mt4 * c > 24) continue;
+            if (mtiles * (N / (4 * c)) * nphases >= 256) { *nt4 = c; break; }
+        }
+    }
+    if (N % (4 * *nt4) != 0) return false;
+    if (*depth == 0) {
+        for (int d : {8, 4, 2}) if (nu % d == 0 && os2_has_config(*mt4, *nt4, *waves, d)) { *depth = d; break; }
+        if (*depth == 0) return false;
+    }
+    return nu % *depth == 0 && os2_has_config(*mt4, *nt4, *waves, *depth);
+}
+
+static int launch_c2d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int B, const float* s1, int C1, const float* s2, int C2, float slope) {
+    const TapTable t = make_taps(l);
+    RyC2dOsParams p;
+    memset(&p, 0, sizeof p);
+    p.src1 = s1; p.src2 = s2; p.wt = l.w2os; p.scale = l.scale; p.shift = l.shift;
+    p.out = lp.w32 ? lp.out : nullptr; p.out16 = lp.w16 ? lp.out16 : nullptr; p.x3 = lp.o16x3 ? 1 : 0;
+    p.C1 = C1; p.C2 = C2; p.B = B; p.Hi = lp.Hi; p.Wi = lp.Wi; p.Ho = lp.Ho; p.Wo = lp.Wo;
+    if (l.deconv) { p.Mh = lp.Hi; p.Mw = lp.Wi; p.stride = 1; p.pad = 0; p.ostride = 2; }
+    else { p.Mh = lp.Ho; p.Mw = lp.Wo; p.stride = l.stride; p.pad = l.pad; p.ostride = 1; }
+    p.M = B * p.Mh * p.Mw;
+    p.ntaps = t.ntaps; p.nphases = t.nphases; p.N = l.cout; p.act = l.act; p.slope = slope;
+    const int MT = 4 * lp.os2_mt4, NT = 4 * lp.os2_nt4;
+    p.mtiles = (p.M + MT - 1) / MT; p.ntiles = l.cout / NT;
+    const int cpt = (C1 + C2) / 64, U = t.ntaps * cpt;
+    if (!l.w2os || C1 % 64 || C2 % 64 || l.cout % NT || U % lp.os2_waves || (U / lp.os2_waves) % lp.os2_depth || (size_t)C1 > ZTAIL || (size_t)C2 > ZTAIL)
+        return fail(RY_ESTATE, "%s: not a shape for the output-stationary kernel (slice %dx%d, %d waves, depth %d)", l.name, lp.os2_mt4, lp.os2_nt4, lp.os2_waves, lp.os2_depth);
+    if (p.M >= (1 << 24) || (long long)p.mtiles * p.ntiles * p.nphases >= (1 << 24)) return fail(RY_EINVAL, "%s: more than 2^24 rows or tiles in one launch", l.name);
+    p.zp1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C1 * 4); p.zp2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C2 * 4);
+    p.inv_Mimg = 1.f / (float)(p.Mh * p.Mw); p.inv_Mw = 1.f / p.Mw; p.inv_mtiles = 1.f / p.mtiles; p.inv_ntiles = 1.f / p.ntiles; p.inv_cpt = 1.f / cpt;
+    p.kw = l.deconv ? 2 : l.k; p.dil = l.deconv ? 1 : l.dil; p.inv_kw = 1.f / p.kw;
+    const int total = p.mtiles * p.ntiles * p.nphases;
+    dim3 grid((unsigned)(((total + 7) / 8) * 8));
+    char nm[48];
+    snprintf(nm, sizeof nm, "ry_c2d_os<%d,%d,%d,%d>", lp.os2_mt4, lp.os2_nt4, lp.os2_waves, lp.os2_depth);      // as rocprofv3 prints it
+    RY_TRY(Lc.begin(nm, l.name, lp.flops, lp.bytes, grid));
+    bool done = false;
+#define X(A, B_, C, D)                                                                                          \
+    if (!done && lp.os2_mt4 == A && lp.os2_nt4 == B_ && lp.os2_waves == C && lp.os2_depth == D) {               \
+        RY_LAUNCH((ry_c2d_os<A, B_, C, D>), grid, 64 * C, Lc.stream, p); done = true;                           \
+    }
+    RY_OS2_CONFIGS(X)
+#undef X
+    if (!done) return fail(RY_EINVAL, "%s: no ry_c2d_os instantiation <%d,%d,%d,%d>", l.name, lp.os2_mt4, lp.os2_nt4, lp.os2_waves, lp.os2_depth);
+    return Lc.end();
+}
+
 static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int B, const float* s1, int C1, const float* s2, int C2, float slope) {
+    if (lp.path == PATH_OS2D) return launch_c2d_os(Lc, l, lp, B, s1, C1, s2, C2, slope);
     RyConvGeom g;
     fill_geom(g, l, lp, B, s1, C1, s2, C2);
     const int M = B * g.Mh * g.Mw;
@@ -779,7 +900,7 @@ static int build_plan(ry_net* net, Plan& P) {
                 for (int src : {l.src_a, l.src_b}) {
                     if (src < 0) continue;
                     const LayerPlan& sp = P.lp[src];
-                    if (sp.path != PATH_FIRST && sp.path != PATH_IGEMM && sp.path != PATH_IGEMM_BF16) want16 = false;   // that producer cannot write a bf16 copy
+                    if (sp.path != PATH_FIRST && sp.path != PATH_IGEMM && sp.path != PATH_IGEMM_BF16 && sp.path != PATH_OS2D) want16 = false;   // that producer cannot write a bf16 copy
                 }
                 if (l.src_a < 0) want16 = false;
                 if (want16) {
@@ -787,6 +908,18 @@ static int build_plan(ry_net* net, Plan& P) {
                     choose_igemm(l, M, t.nphases, t.ntaps * ((x3 ? 3 : 1) * l.cin() / 64), &lp.tile, &lp.splits, &lp.kg, x3 ? 2 : 1);
                 } else {
                     choose_igemm(l, M, t.nphases, nk, &lp.tile, &lp.splits, &lp.kg);
+                }
+                // the weight-streaming layers with few rows: output-stationary, one node, no slabs (ry_c2d_os) -- exact fp32 layers only
+                if (lp.path == PATH_IGEMM && l.w2os && !(g_os2_forced[i] && g_os2_force[i][0] == 0)) {
+                    int c[4] = {0, 0, 0, 0};
+                    if (g_os2_forced[i]) for (int q = 0; q < 4; ++q) c[q] = g_os2_force[i][q];
+                    const int U = t.ntaps * (l.cin() / 64);
+                    if ((g_os2_forced[i] || M <= g_os2_maxm) && choose_os2(M, l.cout, t.nphases, U, &c[0], &c[1], &c[2], &c[3])) {
+                        lp.path = PATH_OS2D; lp.splits = 1; lp.kg = 1;
+                        lp.os2_mt4 = c[0]; lp.os2_nt4 = c[1]; lp.os2_waves = c[2]; lp.os2_depth = c[3];
+                    } else if (g_os2_forced[i]) {
+                        return fail(RY_EINVAL, "RY_OS2: no output-stationary slice %d:%d:%d:%d for %s", c[0], c[1], c[2], c[3], l.name);
+                    }
                 }
                 if (lp.splits > 1) RY_TRY(P.arena.alloc(&lp.slabs, out_elems * lp.splits));
             } else {
@@ -1160,6 +1293,21 @@ int ry_device_count(void) {
 // the launch plans), so that one process can sweep plans (scripts/gpu_x3_plansweep.py, scripts/gpu_r3_lanesweep.py)
 static int read_plan_env() {
     memset(g_force, 0, sizeof(g_force));
+    memset(g_os2_force, 0, sizeof(g_os2_force)); memset(g_os2_forced, 0, sizeof(g_os2_forced));
+    g_os2_maxm = 64; g_os2_min_filter = (size_t)1 << 21;
+    if (const char* e = getenv("RY_OS2_MAXM")) g_os2_maxm = atoi(e);
+    if (const char* e = getenv("RY_OS2_MINW")) g_os2_min_filter = (size_t)atoll(e);
+    if (const char* e = getenv("RY_OS2")) {
+        for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
+            int i = -1, a = 0, b = 0, c = 0, d = 0;
+            const int got = sscanf(q, "%d:%d:%d:%d:%d", &i, &a, &b, &c, &d);
+            if (got >= 2 && i >= 0 && i < 16 && a >= 0 && b >= 0 && c >= 0 && d >= 0) {
+                g_os2_forced[i] = true; g_os2_force[i][0] = a; g_os2_force[i][1] = got >= 3 ? b : 0; g_os2_force[i][2] = got >= 4 ? c : 0; g_os2_force[i][3] = got >= 5 ? d : 0;
+            } else {
+                return fail(RY_EINVAL, "RY_OS2: expected layer:mt4[:nt4[:waves[:depth]]][,...]");
+            }
+        }
+    }
     if (const char* e = getenv("RY_PLAN")) {
         for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
             int i = -1, t = 0, sp = 0, kg = 0;
@@ -1655,7 +1803,7 @@ int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin
     l.deconv = transposed != 0; l.bn = bn != nullptr; l.k = k; l.stride = stride; l.pad = pad; l.dil = dilate;
     l.cin_a = Cin; l.cout = Cout; l.act = act;
     Arena arena;
-    RY_TRY(prepare_layer(ctx, arena, l, 2, 2e-5f, Wt, bias, bn));
+    RY_TRY(prepare_layer(ctx, arena, l, 2, 2e-5f, Wt, bias, bn, path == PATH_OS2D));
     LayerPlan lp;
     lp.Hi = H; lp.Wi = Wd;
     lp.Ho = transposed ? 2 * H : (H + 2 * pad - dilate * (k - 1) - 1) / stride + 1;
@@ -1668,6 +1816,16 @@ int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin
     if ((path == PATH_IGEMM_BF16 || path == PATH_IGEMM_X3) && !(l.wig && Cin % 64 == 0)) return fail(RY_EINVAL, "bf16 implicit-GEMM path needs Cin %% 64 == 0 and Cout %% 64 == 0");
     lp.path = path ? path : (l.wig ? PATH_IGEMM : PATH_DIRECT);
     if (path == PATH_IGEMM_X3) { lp.path = PATH_IGEMM_BF16; lp.x3 = true; }
+    if (path == PATH_OS2D) {                 // `tile` = mt4 + 16 nt4 + 256 waves + 4096 depth (zeros: the planner's choice)
+        if (!l.w2os) return fail(RY_EINVAL, "output-stationary path needs Cin %% 64 == 0 and Cout %% 4 == 0");
+        const TapTable t = make_taps(l);
+        const int M = B * (transposed ? H * Wd : lp.Ho * lp.Wo);
+        int c[4] = {tile & 15, (tile >> 4) & 15, (tile >> 8) & 15, (tile >> 12) & 15};
+        if (!choose_os2(M, Cout, t.nphases, t.ntaps * (Cin / 64), &c[0], &c[1], &c[2], &c[3]))
+            return fail(RY_EINVAL, "no output-stationary slice %d:%d:%d:%d for this shape", c[0], c[1], c[2], c[3]);
+        lp.os2_mt4 = c[0]; lp.os2_nt4 = c[1]; lp.os2_waves = c[2]; lp.os2_depth = c[3];
+        tile = 0;
+    }
     const size_t out_elems = (size_t)B * lp.Ho * lp.Wo * Cout;
     lp.splits = 1;
     lp.last_rows = lp.Ho; lp.last_cols = lp.Wo; lp.last_exp = 0;
@@ -1743,6 +1901,23 @@ int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin
         RT_TRY(rt::h2d(dx, x16.data(), x16.size() * sizeof(unsigned short), ctx->stream));
         RT_TRY(rt::stream_sync(ctx->stream));
         RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Cin, nullptr, 0, 0.2f));
+    } else if (lp.path == PATH_OS2D && Cin % 128 == 0) {
+        // exercise the un-materialised skip concat: the channels are handed over as two half-width sources, each followed by its zero pixel
+        const int Ch = Cin / 2;
+        const size_t npix = (size_t)B * H * Wd;
+        std::vector<float> ha(npix * Ch), hb(npix * Ch);
+        for (size_t q = 0; q < npix; ++q) {
+            memcpy(&ha[q * Ch], x + q * Cin, Ch * sizeof(float));
+            memcpy(&hb[q * Ch], x + q * Cin + Ch, Ch * sizeof(float));
+        }
+        float* dx2 = nullptr;
+        RY_TRY(alloc_ztail(ctx, arena, &dx2, npix * Ch));
+        RT_TRY(rt::dmemset(dx + npix * Ch, 0, ZTAIL * sizeof(float), ctx->stream));      // the first half ends inside dx: its zero pixel right behind it
+        RT_TRY(rt::h2d(dx, ha.data(), npix * Ch * sizeof(float), ctx->stream));
+        RT_TRY(rt::h2d(dx2, hb.data(), npix * Ch * sizeof(float), ctx->stream));
+        RT_TRY(rt::stream_sync(ctx->stream));
+        l.cin_a = Ch; l.cin_b = Ch;
+        RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Ch, dx2, Ch, 0.2f));
     } else {
         RT_TRY(rt::h2d(dx, x, (size_t)B * H * Wd * Cin * sizeof(float), ctx->stream));
         RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Cin, nullptr, 0, 0.2f));

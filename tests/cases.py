@@ -72,6 +72,34 @@ CONV2D_CASES = [
 ]
 
 
+# ry_c2d_os, the output-stationary weight-streaming kernel on the K-batched v_mfma_f32_4x4x1_16B_f32 (round 5): tile = (mt4, nt4, waves, depth);
+# Cin % 128 == 0 cases are handed over as two half-width sources (the un-materialised skip concat)
+CONV2D_OS_CASES = [
+    (1, 6, 8, 64, 16, 4, 2, 1, False, 'lrelu', 'os', (3, 1, 4, 4), 0),     # 3x4 = 12 output pixels (encoder c7 at 300 frames), image borders on every side
+    (1, 12, 16, 128, 32, 4, 2, 1, False, 'lrelu', 'os', (3, 2, 4, 8), 0),  # 48 pixels = four 12-pixel tiles x four 8-channel tiles, two sources, 8 units in flight
+    (1, 3, 4, 256, 16, 4, 2, 1, True, 'relu', 'os', (3, 1, 4, 4), 0),      # sub-pixel deconvolution: 4 phases x 12 input pixels (decoder c0), one tap per wave
+    (2, 3, 4, 256, 24, 4, 2, 1, True, None, 'os', (2, 2, 8, 2), 0),        # batch 2, eight waves, three 8-pixel tiles, three 8-channel tiles
+    (1, 10, 8, 64, 8, 4, 2, 1, False, 'relu', 'os', (4, 2, 4, 4), 0),      # 20 pixels on 16-pixel tiles: a ragged last tile
+    (1, 5, 7, 512, 16, 1, 1, 0, False, 'relu', 'os', (6, 4, 4, 2), 0),     # 'same' 1x1 layer (extensive_layers < 8): 35 pixels on 24-pixel tiles, 96 sums per lane
+    (1, 4, 8, 64, 64, 4, 2, 1, False, 'lrelu', 'os', None, 0),             # the planner's slice
+    (1, 2, 4, 128, 128, 4, 2, 1, False, 'lrelu', 'os', (1, 1, 8, 4), 0),   # deepest encoder layer at 100 frames: 1x2 pixels on a 4-pixel tile
+    (1, 1, 4, 256, 64, 4, 2, 1, True, 'relu', 'os', (1, 4, 4, 4), 0),      # deepest decoder layer at 100 frames: 4 pixels, 16-channel tiles
+    (1, 6, 6, 128, 8, 4, 2, 1, False, None, 'os', (1, 2, 4, 8), 0),        # 9 pixels on 4-pixel tiles, 32 units: the ring wraps
+]
+
+
+def os_identity_rows(ctx):
+    """1x1 'conv' = plain GEMM with one-hot rows on the output-stationary path: pixel i selects input channel 65 i mod 1024, so every K block,
+    every K step of a unit and several units are hit.  -> (y [16][16], W rows expected)"""
+    Cin, Cout = 1024, 16
+    x = numpy.zeros((1, 4, 4, Cin), 'f4')
+    for i in range(16):
+        x[0, i // 4, i % 4, 65 * i % Cin] = 1.0
+    W = (numpy.arange(Cout * Cin, dtype='f4').reshape(Cout, Cin, 1, 1) % 251) / 251.0
+    y = ctx.conv2d(x, W, None, None, stride=1, pad=0, path='os', tile=(4, 4, 4, 4))
+    return y.reshape(16, Cout), numpy.stack([W[:, 65 * i % Cin, 0, 0] for i in range(16)])      # y[pixel i][n] = W[n][65 i]
+
+
 # 2-D dilated convolution (north_star operator coverage: "1-D/2-D dilated conv"): B, H, W, Cin, Cout, k, stride, pad, dilate, act, path, tile, splits
 CONV2D_DILATED_CASES = [
     (1, 12, 16, 32, 128, 3, 1, 2, 2, 'lrelu', 'igemm', '32x128', 0),       # 'same' 3x3 with dilation 2 on the MFMA path

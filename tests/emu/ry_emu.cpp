@@ -210,6 +210,19 @@ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     return d;
 }
 
+// Emulated v_mfma_f32_4x4x1_16B_f32: sixteen independent 4 x 4 x 1 blocks; lane l is in block l >> 2 and supplies A_b[i = l & 3] and
+// B_b[j = l & 3]; register r of lane l holds D_b[i = r][j = l & 3] (the general MFMA rule: lanes run over the columns, registers over the rows).
+f32x4 mfma_4x4x1(float a, float b, f32x4 c) {
+    const int me = S->cur, w = me >> 6, l = me & 63;
+    S->wa[w][l] = a;
+    S->wb[w][l] = b;
+    sync_wave();
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) d[r] = fmaf(S->wa[w][(l & ~3) + r], S->wb[w][l], d[r]);
+    sync_wave();
+    return d;
+}
+
 unsigned short f2bf(float f) {                      // round to nearest even, like v_cvt_pk_bf16_f32
     uint32_t u; memcpy(&u, &f, 4);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN

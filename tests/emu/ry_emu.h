@@ -30,6 +30,7 @@ void sync_block();
 void wave_sync();
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
 f32x16 mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c);
+f32x4 mfma_4x4x1(float a, float b, f32x4 c);
 unsigned short f2bf(float f);
 float shfl_xor(float v, int mask);
 float shfl(float v, int src);
@@ -48,6 +49,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 
 RY_DEV f32x16 ry_mfma_32x32x2(float a, float b, f32x16 c) { return ry_emu::mfma_32x32x2(a, b, c); }
 RY_DEV f32x16 ry_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) { return ry_emu::mfma_32x32x16_bf16(a, b, c); }
+RY_DEV f32x4 ry_mfma_4x4x1(float a, float b, f32x4 c) { return ry_emu::mfma_4x4x1(a, b, c); }
 RY_DEV unsigned short ry_f2bf(float f) { return ry_emu::f2bf(f); }
 RY_DEV void ry_glds16(const float* gsrc_lane, float* lds_wave_base) {          // emulated global_load_lds_dwordx4
     memcpy(lds_wave_base + 4 * (threadIdx.x & 63u), gsrc_lane, 16);

@@ -54,6 +54,50 @@ def test_conv2d_x3_gpu(gpu_ctx, case):
     assert rel_max(y, r) < 2e-5
 
 
+@pytest.mark.parametrize('case', cases.CONV2D_OS_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_os_gpu(gpu_ctx, case):
+    """ry_c2d_os (round 5): the output-stationary weight-streaming kernel on v_mfma_f32_4x4x1_16B_f32, K batched over the sixteen blocks."""
+    y, r = cases.run_conv2d(gpu_ctx, numpy.random.default_rng(21), case, bn_params)
+    assert rel_max(y, r) < cases.TOL
+
+
+OS_FULL_SIZE = [          # the weight-streaming bottom of SYN-64 at the 300-frame window, planner's slice (B, H, W, Cin, Cout, k, s, p, transposed, act, path, tile, splits)
+    (1, 6, 8, 512, 512, 4, 2, 1, False, 'lrelu', 'os', None, 0),          # encoder c7: 12 pixels, 16.8 MB of filters
+    (1, 12, 16, 512, 512, 4, 2, 1, False, 'lrelu', 'os', None, 0),        # encoder c6: 48 pixels
+    (1, 3, 4, 512, 512, 4, 2, 1, True, 'relu', 'os', None, 0),            # decoder c0
+    (1, 6, 8, 1024, 512, 4, 2, 1, True, 'relu', 'os', None, 0),           # decoder c1: two sources of 512 channels, 33.5 MB
+]
+
+
+@pytest.mark.parametrize('case', OS_FULL_SIZE, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_os_full_size_gpu(gpu_ctx, case):
+    """BASELINE layer sizes: against the implicit-GEMM path of the same operator (other summation order only: 1e-5) and, where the
+    numpy oracle finishes in seconds, against the oracle; run twice: deterministic."""
+    B, H, W_, Cin, Cout, k, s, p, tr, act, path, tile, splits = case
+    rng = numpy.random.default_rng(31)
+    x = rng.normal(size=(B, H, W_, Cin)).astype('f4')
+    Wt = rng.normal(0, 0.02, size=(Cin, Cout, k, k) if tr else (Cout, Cin, k, k)).astype('f4')
+    b = rng.normal(0, 0.1, Cout).astype('f4')
+    bn = bn_params(rng, Cout)
+    y = gpu_ctx.conv2d(x, Wt, b, bn, stride=s, pad=p, transposed=tr, act=act, path='os', tile=tile)
+    y2 = gpu_ctx.conv2d(x, Wt, b, bn, stride=s, pad=p, transposed=tr, act=act, path='os', tile=tile)
+    yi = gpu_ctx.conv2d(x, Wt, b, bn, stride=s, pad=p, transposed=tr, act=act, path='igemm')
+    assert numpy.array_equal(y, y2)
+    assert rel_max(y, yi) < 1e-5
+    if H * W_ <= 12:
+        xn = x.transpose(0, 3, 1, 2)
+        r = cases.ops.deconv_nd(xn, Wt, b, stride=s, pad=p) if tr else cases.ops.conv_nd(xn, Wt, b, stride=s, pad=p)
+        r = cases.ops.apply_act(cases.ops.batch_norm_inference(r, *bn), act).transpose(0, 2, 3, 1)
+        assert rel_max(y, r) < cases.TOL
+
+
+def test_mfma_4x4x1_block_map_is_transpose_detecting(gpu_ctx):
+    """Asymmetric 1x1 'conv' = plain GEMM with identity rows on the output-stationary path: catches a swapped row / column map of the sixteen
+    4 x 4 blocks of v_mfma_f32_4x4x1_16B_f32 (registers = rows = pixels, lanes = columns = output channels) and a wrong K position of a block."""
+    y, ref = cases.os_identity_rows(gpu_ctx)
+    assert numpy.array_equal(y, ref)
+
+
 X3_FULL_SIZE = [
     (1, 48, 64, 1024, 256, 4, 2, 1, True, 'relu', None, 0),        # decoder c4 of SYN-64 at the 300-frame window (planner's tile / splits)
     (1, 96, 128, 256, 512, 4, 2, 1, False, 'relu', None, 0),       # encoder c3 at the same window

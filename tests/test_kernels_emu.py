@@ -26,6 +26,18 @@ def test_conv2d_emu(emu_ctx, case):
     assert rel_max(y, r) < cases.TOL
 
 
+@pytest.mark.parametrize('case', cases.CONV2D_OS_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_os_emu(emu_ctx, case):
+    """the output-stationary weight-streaming kernel (ry_c2d_os): emulated 4x4x1 block map, K runs per wave, reduce-scatter over the blocks"""
+    y, r = cases.run_conv2d(emu_ctx, numpy.random.default_rng(21), case, bn_params)
+    assert rel_max(y, r) < cases.TOL
+
+
+def test_conv2d_os_identity_rows_emu(emu_ctx):
+    y, ref = cases.os_identity_rows(emu_ctx)
+    assert numpy.array_equal(y, ref)
+
+
 @pytest.mark.parametrize('case', cases.CONV2D_DILATED_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
 def test_conv2d_dilated_emu(emu_ctx, case):
     y, r = cases.run_conv2d_dilated(emu_ctx, numpy.random.default_rng(19), case, bn_params)
@@ -180,6 +192,60 @@ def test_stage2_x3_pipeline_emu(emu_ctx, monkeypatch):
     assert c3.shape == (11, 17) and not numpy.array_equal(c3, c32)
     assert float(numpy.abs(numpy.log(c3) - numpy.log(c32)).max() / numpy.abs(numpy.log(c32)).max()) < 2e-5
     net.close()
+
+
+def test_stage2_output_stationary_layers_emu(emu_ctx, monkeypatch):
+    """Round 5: layers with few rows per phase and the ry_c2d_os filter layout run output-stationary (PATH_OS2D: one node, no slabs) inside the
+    predictor -- k4 s2 convolutions, sub-pixel deconvolutions over a two-source skip concat -- next to implicit-GEMM neighbours, in the
+    convert wrapper with the dead-row crop / a discard (bit-identical kept rows), and as producers of split-bf16 copies in 'bf16x3' mode."""
+    import ctypes
+    reread = lambda: emu_ctx.lib.check(emu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    d = NetDesc(2, 1, 1, 64, 3)
+    P = synthetic_params(d, 451, bias_std=0.05)
+    x = numpy.random.default_rng(71).normal(size=(1, 16, 16)).astype('f4')
+    ref = cases.oracle_forward(d, P, x)
+    sp = numpy.exp(numpy.random.default_rng(72).normal(-6.0, 1.5, (11, 17))).astype('f4')
+    try:
+        monkeypatch.setenv('RY_OS2_MINW', '1'); reread()          # every eligible layer gets the layout (the product keeps it for filters >= 8 MB)
+        net = engine.Net(emu_ctx, d, flatten_params(d, P), width=16)
+        y = net.forward(x)
+        assert rel_max(y, ref) < cases.TOL
+        os_layers = [q['layer'] for q in net.profile(1, 16, 1) if q['name'].startswith('ry_c2d_os<')]
+        assert {'encoder/c1', 'encoder/c2', 'decoder/c5', 'decoder/c6'} <= set(os_layers), os_layers
+        assert not any(q['layer'] in os_layers for q in net.profile(1, 16, 1) if q['name'].startswith('ry_splitk_reduce'))
+        monkeypatch.setenv('RY_OS2_MAXM', '0'); reread(); net.set_dtype('f32')        # the same predictor on the implicit GEMM: other summation order only
+        assert not [q for q in net.profile(1, 16, 1) if q['name'].startswith('ry_c2d_os<')]
+        y_ig = net.forward(x)
+        assert rel_max(y, y_ig) < 1e-5 and rel_max(y_ig, ref) < cases.TOL
+        monkeypatch.setenv('RY_OS2', '14:0,13:1:2:8:2'); monkeypatch.delenv('RY_OS2_MAXM'); reread(); net.set_dtype('f32')   # forced per layer: decoder c6 off, decoder c5 on another slice
+        names = {q['layer']: q['name'] for q in net.profile(1, 16, 1)}
+        assert names['decoder/c5'] == 'ry_c2d_os<1,2,8,2>' and not names['decoder/c6'].startswith('ry_c2d_os'), names
+        assert rel_max(net.forward(x), ref) < cases.TOL
+        monkeypatch.delenv('RY_OS2'); reread(); net.set_dtype('f32')
+        assert numpy.array_equal(net.forward(x), y)
+        # convert wrapper: dead-row crop and a discard hint around output-stationary layers (they run whole and stop the row-range chain)
+        monkeypatch.setenv('RY_S2_CROP', '0'); reread()
+        whole = net.convert(sp)
+        monkeypatch.setenv('RY_S2_CROP', '2'); reread()
+        cropped = net.convert(sp)
+        assert numpy.array_equal(whole, cropped)
+        assert float(numpy.abs(cropped / unet.stage2_convert(sp, P, 3) - 1).max()) < cases.TOL
+        part = net.convert(sp, discard=(4, 3))
+        assert numpy.array_equal(part[4:8], whole[4:8]) and not part[:4].any() and not part[8:].any()
+        # split-bf16 mode: the output-stationary layers stay exact fp32 and write the [hi | lo] copies their bf16 consumers read
+        monkeypatch.setenv('RY_X3_MINM', '64')
+        net.set_dtype('bf16x3')
+        st = net.profile(1, 16, 1)
+        names = {q['layer']: q['name'] for q in st if not q['name'].startswith('ry_splitk')}
+        assert names['decoder/c5'].startswith('ry_c2d_os<') and names['decoder/c6'].startswith('ry_igemm_ldsdma<') and names['decoder/c6'][:-1].split(',')[5] == 'true', names
+        assert rel_max(net.forward(x), ref) < 2e-5
+        net.set_dtype('f32')
+        assert numpy.array_equal(net.forward(x), y)
+        net.close()
+    finally:
+        for k in ('RY_OS2_MINW', 'RY_OS2_MAXM', 'RY_OS2', 'RY_S2_CROP', 'RY_X3_MINM'):
+            monkeypatch.delenv(k, raising=False)
+        reread()
 
 
 def test_stage2_dead_row_crop_emu(emu_ctx, monkeypatch):
