@@ -230,6 +230,12 @@ int ry_debug_plan_igemm(int M, int Cout, int nphases, int nk, int* tile, int* sp
 /* the same for the bf16 (mode 1) / split-bf16 (mode 2) kernels (nk in 64-channel chunks; non-zero tile / splits / kgroups on entry are kept) */
 int ry_debug_plan_igemm_bf16(int mode, int M, int Cout, int nphases, int nk, int* tile, int* splits, int* kgroups, double* est_us);
 
+/* diagnostics: the slice the planner picks for an output-stationary layer (ry_c2d_os, round 5) with M rows per phase (batch x pixels), Cout
+ * output channels, `nphases` phases and K = 64 * units: tile rows / 4, tile channels / 4, waves per workgroup, units in flight per wave, and the
+ * slice cost (x units: what is compared with RY_OS2_MAXCOST to decide between this kernel and the implicit GEMM).  Non-zero values on entry
+ * are kept.  Returns RY_EINVAL when no slice fits the shape.  No device work. */
+int ry_debug_plan_os2(int M, int Cout, int nphases, int units, int* mt4, int* nt4, int* waves, int* depth, double* cost);
+
 #ifdef __cplusplus
 }
 #endif

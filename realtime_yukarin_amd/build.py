@@ -48,6 +48,8 @@ def _compile_units(cc, flags, obj_dir: Path, suffix: str, extra_sources=()):
 def build_product(force: bool = False, defs=(), suffix: str = '') -> Path:
     """hipcc --offload-arch=gfx950 -> realtime_yukarin_amd/libry355.so (cross-compiles without a GPU).  `defs` / `suffix`: an experiment build
     with extra -D switches next to the product (`libry355<suffix>.so`, e.g. for an A/B of a compile-time variant on the GPU box)."""
+    if defs and not suffix:
+        raise ValueError('an experiment build (extra -D switches) needs a suffix: it must never replace the product library')
     lib = LIB if not suffix else LIB.with_name('libry355%s.so' % suffix)
     if force or _stale(lib, SOURCES):
         cc = _hipcc()
@@ -62,6 +64,8 @@ def build_product(force: bool = False, defs=(), suffix: str = '') -> Path:
 def build_emu(force: bool = False, defs=(), suffix: str = '') -> Path:
     """Same sources as plain C++ on the fiber SIMT emulator (tests/emu) -- test infrastructure only."""
     deps = SOURCES + [EMU_DIR / 'ry_emu.h', EMU_DIR / 'ry_emu.cpp']
+    if defs and not suffix:
+        raise ValueError('an experiment build (extra -D switches) needs a suffix: it must never replace the test emulator library')
     emu_lib = EMU_LIB if not suffix else EMU_LIB.with_name('libry355_emu%s.so' % suffix)
     if force or _stale(emu_lib, deps):
         cxx = '/opt/rocm/lib/llvm/bin/clang++'

@@ -59,6 +59,11 @@ RY_DEV void ry_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Workgroup barrier for data exchanged through the LDS only: waits for this wave's LDS operations, not for its vector-memory loads --
+// __syncthreads() carries a fence that drains vmcnt, i.e. every global load in flight (ry_c2d_os requests its first filters before the barrier).
+RY_DEV void ry_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 // the instruction scheduler does not move anything across this point
 RY_DEV void ry_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 RY_DEV float ry_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }

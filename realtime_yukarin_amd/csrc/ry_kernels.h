@@ -761,8 +761,8 @@ RY_KERNEL(256) void ry_splitk_reduce_wide(RyReduceParams p) {
 //   units in flight, no LDS, no barrier in the K loop;
 //   then: reduce-scatter over the sixteen blocks (lane bits 2-5: DPP inside a row of 16, ds_bpermute across), a fixed-order sum over
 //   the waves through the LDS, folded BN + activation, dense store.
-// The host guarantees (launch_c2d_os): C1, C2 multiples of 64, N a multiple of 4 NT4, units % WAVES == 0, (units / WAVES) % DEPTH == 0,
-// sources followed by a zeroed pixel.
+// The host guarantees (launch_c2d_os): C1, C2 multiples of 256 (a round of four units never straddles a source), N a multiple of 4 NT4,
+// units % (4 WAVES) == 0, sources followed by a zeroed pixel.
 // ---------------------------------------------------------------------------------------------
 struct RyC2dOsParams {
     const float* src1;
@@ -783,6 +783,8 @@ struct RyC2dOsParams {
     float slope;
     int mtiles, ntiles;         // tiles of 4 MT4 rows x 4 NT4 channels; 1-D grid, XCD-ordered: the M-tiles of one filter slice run on one XCD
     unsigned zp1, zp2;          // byte offset of the zeroed pixel behind each source
+    int dbg;                    // diagnostics (RY_OS2_DBG, WRONG results, timing only): 1 no pixel loads, 2 no filter loads, 4 no MFMAs, 8 no K loop at all,
+                                // 16 no offset table, 32 no reduction / stores
     int kw, dil;                // convolution: taps per kernel row, dilation (tap (ky, kx) reads input offset (ky, kx) * dil); the sub-pixel deconvolution
                                 // (ostride == 2) has 4 phases (py, px) of 2 x 2 taps (ty, tx) reading input offset py ? 1 - ty : -ty (likewise x)
     float inv_Mimg, inv_Mw, inv_mtiles, inv_ntiles, inv_cpt, inv_kw;
@@ -802,7 +804,7 @@ RY_DEV void ry_rs_step(const float (&v)[NV], float (&h)[NV / 2], int lane) {
 }
 
 template <int MT4, int NT4, int WAVES, int DEPTH>
-RY_KERNEL(64 * WAVES, 2) void ry_c2d_os(RyC2dOsParams p) {
+RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
     constexpr int MT = 4 * MT4, NT = 4 * NT4;
     constexpr int V = MT4 * NT4 * 4, VP = (V + 15) / 16 * 16, L = VP / 16;      // partial sums per lane, padded for the 16-way scatter
     static_assert(DEPTH * (MT4 + NT4) <= 56, "loads in flight per wave stay below the vmcnt range");
@@ -819,12 +821,24 @@ RY_KERNEL(64 * WAVES, 2) void ry_c2d_os(RyC2dOsParams p) {
     const int m0 = mt * MT, n0 = nt * NT;
     const int Mimg = p.Mh * p.Mw;
 
-    // Byte offset of the input pixel of (source, tap, row of the tile), or of the source's zero pixel when the tap falls outside the image
-    // or the row outside the batch: a table in the LDS, filled once.  The K loop then reads MT4 entries whenever its tap or source changes
-    // -- LDS reads and lgkmcnt, nothing that touches the vector-memory counter the ring of loads in flight is timed by.
-    __shared__ unsigned otab[2 * 16 * MT];
+#ifdef RY_OS2_DBG_BUILD                        // diagnostic build only (scripts/gpu_r5_os_ablate.py): the product carries no ablation branches in its K loop
+    const int dbg = p.dbg;
+#else
+    constexpr int dbg = 0;
+#endif
+    constexpr int RND = 4;                     // units per round: a round never straddles a tap or a source (the host checks C1 / 64, C2 / 64, units per wave)
+    static_assert(DEPTH == 2 || DEPTH == 4, "two or four units in flight");
     const int cpt1 = p.C1 >> 6, cpt = (p.C1 + p.C2) >> 6;
-    {
+    const int U = p.ntaps * cpt, nu = U / WAVES, nr = nu / RND;
+    const int u0 = wave * nu;
+    // filters of (phase, channel group n0 / 4 + h), unit u: one KiB at ((phase * N / 4 + n0 / 4 + h) * U + u) * 256 floats
+    const float* const wq0 = p.wt + ((size_t)(phase * (p.N >> 2) + (n0 >> 2)) * (size_t)U + (size_t)u0) * 256 + lane * 4;
+    const size_t wh = (size_t)U * 256;
+
+    // Byte offset of the input pixel of (source, tap, row of the tile), or of the source's zero pixel when the tap falls outside the image
+    // or the row outside the batch: a table in the LDS, filled once; the K loop reads MT4 entries when its tap or source changes.
+    __shared__ unsigned otab[2 * 16 * MT];
+    if (!(dbg & 16)) {
         const int per_src = p.ntaps * MT;
         for (int e = tid; e < 2 * per_src; e += 64 * WAVES) {
             const int src = e >= per_src ? 1 : 0, e1 = e - src * per_src;
@@ -841,25 +855,33 @@ RY_KERNEL(64 * WAVES, 2) void ry_c2d_os(RyC2dOsParams p) {
             otab[e] = ok ? pix * (unsigned)((src ? p.C2 : p.C1) * 4) : (src ? p.zp2 : p.zp1);
         }
     }
-    __syncthreads();
+    ry_lds_barrier();
 
-    const int U = p.ntaps * cpt, nu = U / WAVES;
-    const int u0 = wave * nu;
-    // filters of (phase, channel group n0 / 4 + h), unit u: one KiB at ((phase * N / 4 + n0 / 4 + h) * U + u) * 256 floats
-    const float* wq = p.wt + ((size_t)(phase * (p.N >> 2) + (n0 >> 2)) * (size_t)U + (size_t)u0) * 256 + lane * 4;
-    const size_t wh = (size_t)U * 256;
-
-    // issue pointer: (tap, chunk) of the next unit to request; the per-lane byte offsets of the MT4 pixels change with the tap and with the source
-    int i_tap = ry_fdiv(u0, cpt, p.inv_cpt), i_chunk = u0 - i_tap * cpt;
-    bool fresh = true;
+    // state of the round being REQUESTED (wave-uniform): position in the run, its tap and first chunk, where its filters and pixels start
+    // (every wave walks its run from the head: a rotated start -- waves spread over the offsets of their filter regions -- and non-temporal
+    // filter loads were measured as nulls, profiles/r05_b_*)
+    int r_rel = 0, r_tap = ry_fdiv(u0, cpt, p.inv_cpt), r_chunk = u0 - r_tap * cpt;
+    int r_key = -1;
     unsigned pb[MT4];
-    const float* sbase = p.src1;
-    auto set_tap = [&]() {
-        const bool first = i_chunk < cpt1;
-        sbase = first ? p.src1 : p.src2 - (size_t)cpt1 * 64;            // + chunk * 64 floats below
-        const unsigned* ot = otab + ((first ? 0 : p.ntaps) + i_tap) * MT + sub;
+    const float* xs = p.src1;
+    const float* wr = wq0;
+    auto round_setup = [&]() {
+        const bool first = r_chunk < cpt1;
+        const int key = 2 * r_tap + (first ? 0 : 1);
+        if (key != r_key) {                                         // another tap or the other source: this lane's pixel offsets
+            r_key = key;
+            const unsigned* ot = otab + ((first ? 0 : p.ntaps) + r_tap) * MT + sub;
 #pragma unroll
-        for (int g = 0; g < MT4; ++g) pb[g] = ot[4 * g] + (unsigned)blk * 16u;
+            for (int g = 0; g < MT4; ++g) pb[g] = ot[4 * g] + (unsigned)blk * 16u;
+        }
+        xs = (first ? p.src1 : p.src2 - (size_t)cpt1 * 64) + r_chunk * 64;
+        wr = wq0 + (size_t)r_rel * (RND * 256);
+    };
+    auto round_next = [&]() {
+        r_chunk += RND;
+        if (r_chunk == cpt) { r_chunk = 0; ++r_tap; }
+        ++r_rel;
+        round_setup();
     };
 
     f32x4 xa[DEPTH][MT4], wb[DEPTH][NT4];
@@ -869,17 +891,19 @@ RY_KERNEL(64 * WAVES, 2) void ry_c2d_os(RyC2dOsParams p) {
 #pragma unroll
         for (int h = 0; h < NT4; ++h) acc[g][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto issue = [&](int d) {
-        if (fresh || i_chunk == 0 || i_chunk == cpt1) { set_tap(); fresh = false; }      // wave-uniform
-        const char* sb = reinterpret_cast<const char*>(sbase + i_chunk * 64);
+    auto issue = [&](int d, int j) {                                // unit j of the round being requested -> slot d
+        if (!(dbg & 2)) {
 #pragma unroll
-        for (int h = 0; h < NT4; ++h) wb[d][h] = ry_ld4(wq + (size_t)h * wh);
+            for (int h = 0; h < NT4; ++h) wb[d][h] = ry_ld4(wr + j * 256 + (size_t)h * wh);
+        }
+        if (!(dbg & 1)) {
+            const char* sb = reinterpret_cast<const char*>(xs + j * 64);
 #pragma unroll
-        for (int g = 0; g < MT4; ++g) xa[d][g] = *reinterpret_cast<const f32x4*>(sb + pb[g]);
-        wq += 256;
-        if (++i_chunk == cpt) { i_chunk = 0; ++i_tap; }
+            for (int g = 0; g < MT4; ++g) xa[d][g] = *reinterpret_cast<const f32x4*>(sb + pb[g]);
+        }
     };
     auto consume = [&](int d) {
+        if (dbg & 4) return;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -888,14 +912,27 @@ RY_KERNEL(64 * WAVES, 2) void ry_c2d_os(RyC2dOsParams p) {
                 for (int h = 0; h < NT4; ++h) acc[g][h] = ry_mfma_4x4x1(xa[d][g][t], wb[d][h][t], acc[g][h]);
     };
 
+    // Ring of DEPTH units: while unit j of a round is multiplied, unit j + DEPTH is requested -- the last DEPTH requests of a round already
+    // belong to the next one, so the round state moves on at j = RND - DEPTH.  The last round requests nothing beyond the run.
+    if (!(dbg & 8)) {
+        round_setup();
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) issue(d);
-    for (int it = DEPTH; it < nu; it += DEPTH) {
+        for (int d = 0; d < DEPTH; ++d) issue(d, d);
+        for (int i = 1; i < nr; ++i) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) { consume(d); issue(d); }
+            for (int j = 0; j < RND; ++j) {
+                if (j == RND - DEPTH) round_next();
+                consume(j % DEPTH);
+                issue(j % DEPTH, (j + DEPTH) % RND);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RND; ++j) {
+            consume(j % DEPTH);
+            if (j + DEPTH < RND) issue(j % DEPTH, j + DEPTH);
+        }
     }
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) consume(d);
+    if (dbg & 32) return;
 
     // ---- sum over the sixteen K blocks (reduce-scatter: lane bits 2..5), then over the waves (LDS, fixed order) ----
     float v16[VP];

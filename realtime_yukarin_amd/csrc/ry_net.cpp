@@ -208,7 +208,7 @@ static bool igemm_eligible(const Layer& l) {
 // 4 * (lane / 4) + t of the block for the t-th v_mfma_f32_4x4x1_16B_f32 of the unit.  Consecutive (tap, chunk) units of one channel
 // group are consecutive KiB: a wave streams its run of the K axis as one contiguous range.
 static bool c2d_os_eligible(const Layer& l) {
-    return l.cin_a % 64 == 0 && l.cin_b % 64 == 0 && l.cout % 4 == 0 && l.cin() > 0 && l.cin_a <= 2048 && l.cin_b <= 2048;    // (a source's zero pixel is ZTAIL floats)
+    return l.cin_a % 256 == 0 && l.cin_b % 256 == 0 && l.cout % 4 == 0 && l.cin() > 0 && l.cin_a <= 2048 && l.cin_b <= 2048;    // (rounds of four 64-channel units inside one source; a source's zero pixel is ZTAIL floats)
 }
 
 static void relayout_c2d_os(const Layer& l, const float* W, std::vector<float>& out) {
@@ -437,17 +437,17 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
 }
 
 // ---- stage-2 output-stationary layers (ry_c2d_os) ----
-// (MT4, NT4, WAVES, DEPTH): tile of 4 MT4 rows x 4 NT4 output channels per workgroup, WAVES waves that deal the K units among them, DEPTH
-// units in flight per wave.  Every instantiation keeps accumulators + ring inside 256 registers (two workgroups of 4 waves per CU).
+// (MT4, NT4, WAVES, DEPTH): tile of 4 MT4 rows x 4 NT4 output channels per workgroup, WAVES waves that deal the K units among them in rounds
+// of four, DEPTH units in flight per wave.  Sixteen-wave workgroups have 128 registers per lane: small tiles only.
 #define RY_OS2_CONFIGS(X)                                                                                              \
-    X(1, 1, 4, 8) X(1, 1, 4, 4) X(1, 1, 8, 4) X(1, 1, 8, 2) X(2, 1, 4, 8) X(2, 1, 4, 4) X(2, 1, 8, 4) X(2, 1, 8, 2)     \
-    X(3, 1, 4, 8) X(3, 1, 4, 4) X(3, 1, 8, 4) X(3, 1, 8, 2) X(4, 1, 4, 8) X(4, 1, 4, 4) X(4, 1, 8, 4) X(4, 1, 8, 2)     \
-    X(6, 1, 4, 4) X(6, 1, 8, 4) X(6, 1, 8, 2)                                                                           \
-    X(1, 2, 4, 8) X(1, 2, 4, 4) X(1, 2, 8, 4) X(1, 2, 8, 2) X(2, 2, 4, 8) X(2, 2, 4, 4) X(2, 2, 8, 4) X(2, 2, 8, 2)     \
-    X(3, 2, 4, 8) X(3, 2, 4, 4) X(3, 2, 8, 4) X(3, 2, 8, 2) X(4, 2, 4, 4) X(4, 2, 8, 4) X(4, 2, 8, 2)                   \
-    X(6, 2, 4, 4) X(6, 2, 8, 4) X(6, 2, 8, 2)                                                                           \
-    X(1, 4, 4, 8) X(1, 4, 4, 4) X(1, 4, 8, 4) X(1, 4, 8, 2) X(2, 4, 4, 4) X(2, 4, 8, 4) X(2, 4, 8, 2)                   \
-    X(3, 4, 4, 4) X(3, 4, 8, 4) X(3, 4, 8, 2) X(4, 4, 4, 4) X(4, 4, 8, 4) X(4, 4, 8, 2) X(6, 4, 4, 2) X(6, 4, 8, 2)
+    X(1, 1, 4, 4) X(1, 1, 8, 4) X(1, 1, 8, 2) X(1, 1, 16, 2) X(2, 1, 4, 4) X(2, 1, 8, 4) X(2, 1, 8, 2) X(2, 1, 16, 2)     \
+    X(3, 1, 4, 4) X(3, 1, 8, 4) X(3, 1, 8, 2) X(3, 1, 16, 2) X(4, 1, 4, 4) X(4, 1, 8, 4) X(4, 1, 8, 2) X(4, 1, 16, 2)     \
+    X(6, 1, 4, 4) X(6, 1, 8, 4) X(6, 1, 8, 2)                                                             \
+    X(1, 2, 4, 4) X(1, 2, 8, 4) X(1, 2, 8, 2) X(1, 2, 16, 2) X(2, 2, 4, 4) X(2, 2, 8, 4) X(2, 2, 8, 2) X(2, 2, 16, 2)     \
+    X(3, 2, 4, 4) X(3, 2, 8, 4) X(3, 2, 8, 2) X(3, 2, 16, 2) X(4, 2, 4, 4) X(4, 2, 8, 4) X(4, 2, 8, 2) X(4, 2, 16, 2)     \
+    X(6, 2, 4, 4) X(6, 2, 8, 4) X(6, 2, 8, 2)                                                                             \
+    X(1, 4, 4, 4) X(1, 4, 8, 4) X(1, 4, 8, 2) X(1, 4, 16, 2) X(2, 4, 4, 4) X(2, 4, 8, 4) X(2, 4, 8, 2) X(2, 4, 16, 2)     \
+    X(3, 4, 4, 4) X(3, 4, 8, 4) X(3, 4, 8, 2) X(4, 4, 4, 4) X(4, 4, 8, 2) X(6, 4, 4, 2)
 
 static bool os2_has_config(int mt4, int nt4, int waves, int depth) {
 #define X(A, B, C, D) if (mt4 == A && nt4 == B && waves == C && depth == D) return true;
@@ -456,39 +456,45 @@ static bool os2_has_config(int mt4, int nt4, int waves, int depth) {
     return false;
 }
 
-static int g_os2_maxm = 64;            // RY_OS2_MAXM: a layer with at most this many rows per phase (batch x pixels) and the ry_c2d_os filter layout runs output-stationary (0: never)
+static int g_os2_dbg = 0;              // RY_OS2_DBG: ablation bits of ry_c2d_os, honoured by -DRY_OS2_DBG_BUILD builds only (diagnostics, WRONG results): 1 no pixel loads, 2 no filter loads, 4 no MFMAs, 8 no K loop, 16 no offset table, 32 no reduction / stores
+static int g_os2_maxcost = 4608;       // RY_OS2_MAXCOST: a layer with the ry_c2d_os filter layout runs output-stationary when slice cost x K units stays below this (0: never).
+                                       // Fitted: encoder c6 / decoder c1 at 300 frames (4096) win by 2-4 us, encoder c5 at 300 frames (10240) and decoder c2 at 100 frames (8192) lose by 8-11
 static int g_os2_force[16][4];         // RY_OS2="layer:mt4:nt4:waves:depth,...": tuning aid, fixes the slice of single layers ("layer:0" keeps that layer on the implicit GEMM)
 static bool g_os2_forced[16];
 
-// Slice of one layer.  Per-CU operand traffic is K x (rows + channels) of the tile per workgroup, so the tile should be as square as the
-// accumulator budget allows -- but the chip has 256 CUs to fill and the filters want to be streamed by all of them.
-static bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int* waves, int* depth) {
-    static const int MTS[5] = {1, 2, 3, 4, 6};
-    if (*waves == 0) *waves = 4;
-    if (U % *waves != 0) return false;
-    const int nu = U / *waves;
-    if (*mt4 == 0) {
-        int best = 0; long best_rows = 1L << 40;
-        for (int i = 0; i < 5; ++i) {                                   // least padded rows, then the larger tile
-            const long tiles = (M + 4 * MTS[i] - 1) / (4 * MTS[i]), rows = tiles * 4 * MTS[i];
-            if (rows < best_rows || (rows == best_rows && MTS[i] <= 3)) { best_rows = rows; best = MTS[i]; }
+// Slice of one layer, by a cost fitted to the slice sweeps on the MI355X (profiles/r05_e_os_sweep_n{300,100}.txt): a workgroup pulls K x (rows +
+// channels) of its tile through its CU's L1, the pixel rows at about half the rate of the filter rows (a wave-load of pixels is four
+// 256-byte pieces of four different pixels, a wave-load of filters one contiguous KiB), and the launch takes as many rounds as there are
+// workgroups per CU.  cost = max(1, workgroups / 256) x (2 rows + channels) of the tile; the sweeps rank the slices of every bottom layer in this
+// order (encoder c7: 4 x 8 < 8 x 4 < 4 x 4 < 12 x 4; decoder c1: 24 x 16 < 12 x 16 < 8 x 16 < 16 x 16).  `cost_out` x K units is what the
+// caller compares with the implicit GEMM (g_os2_maxcost).
+static bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int* waves, int* depth, double* cost_out = nullptr) {
+    static const int MTS[5] = {1, 2, 3, 4, 6}, NTS[3] = {1, 2, 4};
+    double best = 1e30; int bm = 0, bn = 0, bw = 0, bd = 0;
+    for (int mi = 0; mi < 5; ++mi)
+        for (int ni = 0; ni < 3; ++ni) {
+            const int m = MTS[mi], n = NTS[ni];
+            if ((*mt4 != 0 && *mt4 != m) || (*nt4 != 0 && *nt4 != n) || N % (4 * n) != 0) continue;
+            // waves x units in flight: large tiles run four waves with four units in flight, small ones eight waves with two (more waves hide more of
+            // the chain request -> landing -> MFMA at one or two workgroups per CU); whatever the run of K units feeds with whole rounds of four
+            int w = 0, d = 0;
+            static const int WD[4][2] = {{8, 2}, {4, 4}, {16, 2}, {8, 4}}, WD_BIG[4][2] = {{4, 4}, {8, 2}, {4, 2}, {8, 4}};
+            for (int k = 0; k < 4 && w == 0; ++k) {
+                const int cw = (m * n >= 12 ? WD_BIG : WD)[k][0], cd = (m * n >= 12 ? WD_BIG : WD)[k][1];
+                if ((*waves != 0 && *waves != cw) || (*depth != 0 && *depth != cd) || U % (4 * cw) != 0 || !os2_has_config(m, n, cw, cd)) continue;
+                w = cw; d = cd;
+            }
+            if (w == 0 && (*waves != 0 || *depth != 0))                  // a forced pair outside the preference lists
+                if (U % (4 * *waves) == 0 && os2_has_config(m, n, *waves, *depth)) { w = *waves; d = *depth; }
+            if (w == 0) continue;
+            const double wgs = (double)((M + 4 * m - 1) / (4 * m)) * (N / (4 * n)) * nphases;
+            const double cost = (wgs > 256.0 ? wgs / 256.0 : 1.0) * (8.0 * m + 4.0 * n) * ((double)((M + 4 * m - 1) / (4 * m)) * 4 * m / M);   // padded rows are loaded too
+            if (cost < best - 1e-9) { best = cost; bm = m; bn = n; bw = w; bd = d; }
         }
-        *mt4 = best;
-    }
-    const long mtiles = (M + 4 * *mt4 - 1) / (4 * *mt4);
-    if (*nt4 == 0) {
-        *nt4 = 1;
-        for (int c : {4, 2}) {
-            if (N % (4 * c) != 0 || *mt4 * c > 24) continue;
-            if (mtiles * (N / (4 * c)) * nphases >= 256) { *nt4 = c; break; }
-        }
-    }
-    if (N % (4 * *nt4) != 0) return false;
-    if (*depth == 0) {
-        for (int d : {8, 4, 2}) if (nu % d == 0 && os2_has_config(*mt4, *nt4, *waves, d)) { *depth = d; break; }
-        if (*depth == 0) return false;
-    }
-    return nu % *depth == 0 && os2_has_config(*mt4, *nt4, *waves, *depth);
+    if (bm == 0) return false;
+    *mt4 = bm; *nt4 = bn; *waves = bw; *depth = bd;
+    if (cost_out) *cost_out = best;
+    return true;
 }
 
 static int launch_c2d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int B, const float* s1, int C1, const float* s2, int C2, float slope) {
@@ -505,12 +511,13 @@ static int launch_c2d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     const int MT = 4 * lp.os2_mt4, NT = 4 * lp.os2_nt4;
     p.mtiles = (p.M + MT - 1) / MT; p.ntiles = l.cout / NT;
     const int cpt = (C1 + C2) / 64, U = t.ntaps * cpt;
-    if (!l.w2os || C1 % 64 || C2 % 64 || l.cout % NT || U % lp.os2_waves || (U / lp.os2_waves) % lp.os2_depth || (size_t)C1 > ZTAIL || (size_t)C2 > ZTAIL)
+    if (!l.w2os || C1 % 256 || C2 % 256 || l.cout % NT || U % (4 * lp.os2_waves) || (size_t)C1 > ZTAIL || (size_t)C2 > ZTAIL)
         return fail(RY_ESTATE, "%s: not a shape for the output-stationary kernel (slice %dx%d, %d waves, depth %d)", l.name, lp.os2_mt4, lp.os2_nt4, lp.os2_waves, lp.os2_depth);
     if (p.M >= (1 << 24) || (long long)p.mtiles * p.ntiles * p.nphases >= (1 << 24)) return fail(RY_EINVAL, "%s: more than 2^24 rows or tiles in one launch", l.name);
     p.zp1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C1 * 4); p.zp2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C2 * 4);
     p.inv_Mimg = 1.f / (float)(p.Mh * p.Mw); p.inv_Mw = 1.f / p.Mw; p.inv_mtiles = 1.f / p.mtiles; p.inv_ntiles = 1.f / p.ntiles; p.inv_cpt = 1.f / cpt;
     p.kw = l.deconv ? 2 : l.k; p.dil = l.deconv ? 1 : l.dil; p.inv_kw = 1.f / p.kw;
+    p.dbg = g_os2_dbg;
     const int total = p.mtiles * p.ntiles * p.nphases;
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
     char nm[48];
@@ -914,7 +921,8 @@ static int build_plan(ry_net* net, Plan& P) {
                     int c[4] = {0, 0, 0, 0};
                     if (g_os2_forced[i]) for (int q = 0; q < 4; ++q) c[q] = g_os2_force[i][q];
                     const int U = t.ntaps * (l.cin() / 64);
-                    if ((g_os2_forced[i] || M <= g_os2_maxm) && choose_os2(M, l.cout, t.nphases, U, &c[0], &c[1], &c[2], &c[3])) {
+                    double cost = 0.0;
+                    if (choose_os2(M, l.cout, t.nphases, U, &c[0], &c[1], &c[2], &c[3], &cost) && (g_os2_forced[i] || cost * U <= (double)g_os2_maxcost)) {
                         lp.path = PATH_OS2D; lp.splits = 1; lp.kg = 1;
                         lp.os2_mt4 = c[0]; lp.os2_nt4 = c[1]; lp.os2_waves = c[2]; lp.os2_depth = c[3];
                     } else if (g_os2_forced[i]) {
@@ -1294,9 +1302,11 @@ int ry_device_count(void) {
 static int read_plan_env() {
     memset(g_force, 0, sizeof(g_force));
     memset(g_os2_force, 0, sizeof(g_os2_force)); memset(g_os2_forced, 0, sizeof(g_os2_forced));
-    g_os2_maxm = 64; g_os2_min_filter = (size_t)1 << 21;
-    if (const char* e = getenv("RY_OS2_MAXM")) g_os2_maxm = atoi(e);
+    g_os2_maxcost = 4608; g_os2_min_filter = (size_t)1 << 21;
+    if (const char* e = getenv("RY_OS2_MAXCOST")) g_os2_maxcost = atoi(e);
     if (const char* e = getenv("RY_OS2_MINW")) g_os2_min_filter = (size_t)atoll(e);
+    g_os2_dbg = 0;
+    if (const char* e = getenv("RY_OS2_DBG")) g_os2_dbg = atoi(e);
     if (const char* e = getenv("RY_OS2")) {
         for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
             int i = -1, a = 0, b = 0, c = 0, d = 0;
@@ -1734,6 +1744,16 @@ int ry_debug_plan_igemm_bf16(int mode, int M, int Cout, int nphases, int nk, int
     return RY_OK;
 }
 
+// diagnostics: the output-stationary slice the planner picks for one layer shape (choose_os2)
+int ry_debug_plan_os2(int M, int Cout, int nphases, int units, int* mt4, int* nt4, int* waves, int* depth, double* cost) {
+    if (!mt4 || !nt4 || !waves || !depth) return fail(RY_EINVAL, "null argument");
+    if (M < 1 || Cout < 4 || Cout % 4 != 0 || nphases < 1 || units < 1) return fail(RY_EINVAL, "not an output-stationary layer shape");
+    RY_TRY(read_env_switches());
+    if (!choose_os2(M, Cout, nphases, units, mt4, nt4, waves, depth, cost))
+        return fail(RY_EINVAL, "no output-stationary slice for %d rows x %d channels x %d units", M, Cout, units);
+    return RY_OK;
+}
+
 // ---- single operators -------------------------------------------------------------------------
 int ry_conv1d(ry_ctx* ctx, const float* x, int B, int L, int Cin, const float* W, const float* bias, const float* bn,
               int Cout, int k, int stride, int pad, int dilate, int transposed, int act, int splits, float* y) {
@@ -1816,11 +1836,11 @@ int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin
     if ((path == PATH_IGEMM_BF16 || path == PATH_IGEMM_X3) && !(l.wig && Cin % 64 == 0)) return fail(RY_EINVAL, "bf16 implicit-GEMM path needs Cin %% 64 == 0 and Cout %% 64 == 0");
     lp.path = path ? path : (l.wig ? PATH_IGEMM : PATH_DIRECT);
     if (path == PATH_IGEMM_X3) { lp.path = PATH_IGEMM_BF16; lp.x3 = true; }
-    if (path == PATH_OS2D) {                 // `tile` = mt4 + 16 nt4 + 256 waves + 4096 depth (zeros: the planner's choice)
-        if (!l.w2os) return fail(RY_EINVAL, "output-stationary path needs Cin %% 64 == 0 and Cout %% 4 == 0");
+    if (path == PATH_OS2D) {                 // `tile` = mt4 + 16 nt4 + 256 waves + 8192 depth (zeros: the planner's choice)
+        if (!l.w2os) return fail(RY_EINVAL, "output-stationary path needs Cin %% 256 == 0 and Cout %% 4 == 0");
         const TapTable t = make_taps(l);
         const int M = B * (transposed ? H * Wd : lp.Ho * lp.Wo);
-        int c[4] = {tile & 15, (tile >> 4) & 15, (tile >> 8) & 15, (tile >> 12) & 15};
+        int c[4] = {tile & 15, (tile >> 4) & 15, (tile >> 8) & 31, (tile >> 13) & 15};
         if (!choose_os2(M, Cout, t.nphases, t.ntaps * (Cin / 64), &c[0], &c[1], &c[2], &c[3]))
             return fail(RY_EINVAL, "no output-stationary slice %d:%d:%d:%d for this shape", c[0], c[1], c[2], c[3]);
         lp.os2_mt4 = c[0]; lp.os2_nt4 = c[1]; lp.os2_waves = c[2]; lp.os2_depth = c[3];
@@ -1901,7 +1921,7 @@ int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin
         RT_TRY(rt::h2d(dx, x16.data(), x16.size() * sizeof(unsigned short), ctx->stream));
         RT_TRY(rt::stream_sync(ctx->stream));
         RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Cin, nullptr, 0, 0.2f));
-    } else if (lp.path == PATH_OS2D && Cin % 128 == 0) {
+    } else if (lp.path == PATH_OS2D && Cin % 512 == 0) {
         // exercise the un-materialised skip concat: the channels are handed over as two half-width sources, each followed by its zero pixel
         const int Ch = Cin / 2;
         const size_t npix = (size_t)B * H * Wd;

@@ -108,7 +108,7 @@ class Context(object):
         pth = {'auto': 0, 'igemm': 1, 'direct': 2, 'first': 3, 'last': 4, 'igemm_bf16': 5, 'igemm_x3': 6, 'os': 7}[path]
         if path == 'os':         # output-stationary weight-streaming kernel: tile = (mt4, nt4, waves, depth), zeros / None = the planner's choice
             c = tuple(tile or ()) + (0, 0, 0, 0)
-            tcode = int(c[0]) + 16 * int(c[1]) + 256 * int(c[2]) + 4096 * int(c[3])
+            tcode = int(c[0]) + 16 * int(c[1]) + 256 * int(c[2]) + 8192 * int(c[3])
         else:
             tcode = _lib.TILES[tile]
         self.lib.check(self.lib.dll.ry_conv2d_dilated(self.handle, _lib._fptr(x), B, H, Wd, Cin, _lib._fptr(W), _lib._fptr(bv), _lib._fptr(bnv),

@@ -25,10 +25,10 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 OUT = sys.argv[2] if len(sys.argv) > 2 else str(ROOT / 'gpurun_out' / ('r5_os_sweep_n%d.txt' % N))
 REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 NAMES = ['encoder/c%d' % i for i in range(8)] + ['decoder/c%d' % i for i in range(8)]
-LAYERS = tuple(int(v) for v in os.environ.get('SWEEP_LAYERS', '7,8,6,9,5,10').split(','))
+LAYERS = tuple(int(v) for v in os.environ.get('SWEEP_LAYERS', '7,8,6,9,5,10').split(',') if v.strip().isdigit())      # 'none': only the planner's picks against the implicit GEMM
 EMU = bool(os.environ.get('SWEEP_EMU'))                             # flow check on the CPU emulator (numbers mean nothing)
 
-CONFIGS = [(m, n, w, d) for n in (1, 2, 4) for m in (1, 2, 3, 4, 6) for (w, d) in ((4, 8), (4, 4), (8, 4), (8, 2))]
+CONFIGS = [(m, n, w, d) for n in (1, 2, 4) for m in (1, 2, 3, 4, 6) for (w, d) in ((4, 4), (8, 4), (8, 2), (16, 2))]
 
 (d1, P1), (d2, P2) = synth.model_params('SYN-8' if EMU else 'SYN-64')
 if EMU:
@@ -59,7 +59,7 @@ def say(s):
 
 def setup(os2, maxm):
     os.environ['RY_OS2'] = os2
-    os.environ['RY_OS2_MAXM'] = str(maxm)
+    os.environ['RY_OS2_MAXCOST'] = str(maxm)
     if not os2:
         del os.environ['RY_OS2']
     n2.set_dtype('f32')
@@ -127,7 +127,7 @@ base = layer_us()
 y0 = result()
 f0 = forward_alone()
 bot0 = sum(base[NAMES[l]][0] for l in (5, 6, 7, 8, 9, 10))
-say('# implicit GEMM + reduce (RY_OS2_MAXM=0): stage-2 forward alone %.4f ms (graph replay); bottom six %.1f us' % (f0, bot0))
+say('# implicit GEMM + reduce (RY_OS2_MAXCOST=0): stage-2 forward alone %.4f ms (graph replay); bottom six %.1f us' % (f0, bot0))
 for l in (5, 6, 7, 8, 9, 10):
     say('#   %-11s %7.2f us   %s' % (NAMES[l], base[NAMES[l]][0], ' + '.join(base[NAMES[l]][1])))
 best = {}
@@ -163,8 +163,8 @@ say('# with the winners: stage-2 forward alone %.4f ms (was %.4f); bottom six %.
     % (f1, f0, sum(lu[NAMES[l]][0] for l in (5, 6, 7, 8, 9, 10)), bot0, err, numpy.array_equal(result(), y1)))
 for l in (5, 6, 7, 8, 9, 10):
     say('#   %-11s %7.2f us   %s' % (NAMES[l], lu[NAMES[l]][0], ' + '.join(lu[NAMES[l]][1])))
-# the default planner (RY_OS2 unset, RY_OS2_MAXM default)
-os.environ.pop('RY_OS2', None); os.environ.pop('RY_OS2_MAXM', None); n2.set_dtype('f32')
+# the default planner (RY_OS2 unset, RY_OS2_MAXCOST default)
+os.environ.pop('RY_OS2', None); os.environ.pop('RY_OS2_MAXCOST', None); n2.set_dtype('f32')
 lu = layer_us()
 f2 = forward_alone()
 say('# planner defaults: stage-2 forward alone %.4f ms; bottom six %.1f us' % (f2, sum(lu[NAMES[l]][0] for l in (5, 6, 7, 8, 9, 10))))
@@ -174,7 +174,7 @@ for l in (5, 6, 7, 8, 9, 10):
 for rnd in range(1 if EMU else 2):
     setup('', 0); a = two_lane()
     setup(cfg, 0); b = two_lane()
-    os.environ.pop('RY_OS2', None); os.environ.pop('RY_OS2_MAXM', None); n2.set_dtype('f32'); c = two_lane()
+    os.environ.pop('RY_OS2', None); os.environ.pop('RY_OS2_MAXCOST', None); n2.set_dtype('f32'); c = two_lane()
     say('# two-lane step, ms per window: implicit GEMM %.4f   winners %.4f   planner defaults %.4f' % (a, b, c))
 Path(OUT).parent.mkdir(parents=True, exist_ok=True)
 Path(OUT).write_text(''.join(lines))

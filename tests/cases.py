@@ -75,16 +75,17 @@ CONV2D_CASES = [
 # ry_c2d_os, the output-stationary weight-streaming kernel on the K-batched v_mfma_f32_4x4x1_16B_f32 (round 5): tile = (mt4, nt4, waves, depth);
 # Cin % 128 == 0 cases are handed over as two half-width sources (the un-materialised skip concat)
 CONV2D_OS_CASES = [
-    (1, 6, 8, 64, 16, 4, 2, 1, False, 'lrelu', 'os', (3, 1, 4, 4), 0),     # 3x4 = 12 output pixels (encoder c7 at 300 frames), image borders on every side
-    (1, 12, 16, 128, 32, 4, 2, 1, False, 'lrelu', 'os', (3, 2, 4, 8), 0),  # 48 pixels = four 12-pixel tiles x four 8-channel tiles, two sources, 8 units in flight
-    (1, 3, 4, 256, 16, 4, 2, 1, True, 'relu', 'os', (3, 1, 4, 4), 0),      # sub-pixel deconvolution: 4 phases x 12 input pixels (decoder c0), one tap per wave
-    (2, 3, 4, 256, 24, 4, 2, 1, True, None, 'os', (2, 2, 8, 2), 0),        # batch 2, eight waves, three 8-pixel tiles, three 8-channel tiles
-    (1, 10, 8, 64, 8, 4, 2, 1, False, 'relu', 'os', (4, 2, 4, 4), 0),      # 20 pixels on 16-pixel tiles: a ragged last tile
-    (1, 5, 7, 512, 16, 1, 1, 0, False, 'relu', 'os', (6, 4, 4, 2), 0),     # 'same' 1x1 layer (extensive_layers < 8): 35 pixels on 24-pixel tiles, 96 sums per lane
-    (1, 4, 8, 64, 64, 4, 2, 1, False, 'lrelu', 'os', None, 0),             # the planner's slice
-    (1, 2, 4, 128, 128, 4, 2, 1, False, 'lrelu', 'os', (1, 1, 8, 4), 0),   # deepest encoder layer at 100 frames: 1x2 pixels on a 4-pixel tile
+    (1, 6, 8, 256, 16, 4, 2, 1, False, 'lrelu', 'os', (3, 1, 4, 4), 0),    # 3x4 = 12 output pixels (encoder c7 at 300 frames), image borders on every side; 4 rounds per wave, rotated start
+    (1, 12, 16, 512, 32, 4, 2, 1, False, 'lrelu', 'os', (3, 2, 8, 4), 0),  # 48 pixels = four 12-pixel tiles x four 8-channel tiles, two sources of 256 channels, eight waves
+    (1, 3, 4, 256, 16, 4, 2, 1, True, 'relu', 'os', (3, 1, 4, 4), 0),      # sub-pixel deconvolution: 4 phases x 12 input pixels (decoder c0), one round per wave
+    (2, 3, 4, 512, 24, 4, 2, 1, True, None, 'os', (2, 2, 8, 2), 0),        # batch 2, two sources, eight waves, three 8-pixel tiles, three 8-channel tiles
+    (1, 10, 8, 256, 8, 4, 2, 1, False, 'relu', 'os', (4, 2, 4, 4), 0),     # 20 pixels on 16-pixel tiles: a ragged last tile
+    (1, 5, 7, 1024, 16, 1, 1, 0, False, 'relu', 'os', (6, 4, 4, 2), 0),    # 'same' 1x1 layer (extensive_layers < 8): 35 pixels on 24-pixel tiles, 96 sums per lane, two sources
+    (1, 4, 8, 256, 64, 4, 2, 1, False, 'lrelu', 'os', None, 0),            # the planner's slice
+    (1, 2, 4, 256, 128, 4, 2, 1, False, 'lrelu', 'os', (1, 1, 8, 4), 0),   # deepest encoder layer at 100 frames: 1x2 pixels on a 4-pixel tile
     (1, 1, 4, 256, 64, 4, 2, 1, True, 'relu', 'os', (1, 4, 4, 4), 0),      # deepest decoder layer at 100 frames: 4 pixels, 16-channel tiles
-    (1, 6, 6, 128, 8, 4, 2, 1, False, None, 'os', (1, 2, 4, 8), 0),        # 9 pixels on 4-pixel tiles, 32 units: the ring wraps
+    (1, 6, 6, 256, 8, 4, 2, 1, False, None, 'os', (1, 2, 16, 2), 0),       # 9 pixels on 4-pixel tiles, sixteen waves of one round each
+    (1, 6, 8, 512, 8, 4, 2, 1, False, 'relu', 'os', (3, 2, 8, 2), 0),   # two units in flight, four rounds per wave, two sources
 ]
 
 

@@ -117,6 +117,29 @@ def test_stage2_planner_picks_legal_launches_bf16(lib, frames, mode):
     assert f(3, 100, 128, 1, 8, ctypes.byref(t), ctypes.byref(s), ctypes.byref(k), None) != 0
 
 
+def test_output_stationary_planner_follows_the_measured_ranking(lib):
+    """choose_os2 (round 5): the slice cost fitted to the MI355X sweeps (profiles/r05_e_os_sweep_*) picks the measured winners of the bottom
+    layers of SYN-64 -- (rows per phase, channels, phases, K units) -> (tile rows / 4, tile channels / 4) -- and keeps encoder c5 at 300 frames
+    and decoder c2 at 100 frames (cost x units 10240 / 8192) on the implicit GEMM."""
+    f = lib.dll.ry_debug_plan_os2
+    picks = {}
+    for name, (M, N, nph, U) in dict(e7_300=(12, 512, 1, 128), e6_300=(48, 512, 1, 128), d0_300=(12, 512, 4, 32), d1_300=(48, 512, 4, 64), e5_300=(192, 512, 1, 128),
+                                     e7_100=(4, 512, 1, 128), e6_100=(16, 512, 1, 128), e5_100=(64, 512, 1, 128), d0_100=(4, 512, 4, 32), d1_100=(16, 512, 4, 64),
+                                     d2_100=(64, 512, 4, 64)).items():
+        a, b, w, d, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        lib.check(f(M, N, nph, U, ctypes.byref(a), ctypes.byref(b), ctypes.byref(w), ctypes.byref(d), ctypes.byref(c)))
+        assert U % (4 * w.value) == 0 and d.value in (2, 4) and N % (4 * b.value) == 0
+        picks[name] = (a.value, b.value, c.value * U)
+    assert picks['e7_300'][:2] == (1, 2) and picks['e6_300'][:2] in ((2, 4), (3, 2)) and picks['d1_300'][:2] == (6, 4), picks
+    assert picks['e7_100'][:2] == (1, 1) and picks['e6_100'][:2] == (1, 2) and picks['e5_100'][:2] == (2, 4), picks
+    assert all(picks[k][2] <= 4608 for k in picks if k not in ('e5_300', 'd2_100')) and picks['e5_300'][2] > 4608 and picks['d2_100'][2] > 4608, picks
+    a, b, w, d = ctypes.c_int(3), ctypes.c_int(1), ctypes.c_int(8), ctypes.c_int(2)                  # a given slice is kept
+    lib.check(f(12, 512, 1, 128, ctypes.byref(a), ctypes.byref(b), ctypes.byref(w), ctypes.byref(d), None))
+    assert (a.value, b.value, w.value, d.value) == (3, 1, 8, 2)
+    a, b, w, d = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert f(12, 512, 1, 6, ctypes.byref(a), ctypes.byref(b), ctypes.byref(w), ctypes.byref(d), None) != 0      # 6 units: no whole rounds of four per wave
+
+
 def test_stage2_planner_rejects_non_igemm_shapes(lib):
     t, s, k = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.dll.ry_debug_plan_igemm(100, 48, 1, 8, ctypes.byref(t), ctypes.byref(s), ctypes.byref(k), None) != 0

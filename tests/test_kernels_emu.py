@@ -211,13 +211,13 @@ def test_stage2_output_stationary_layers_emu(emu_ctx, monkeypatch):
         y = net.forward(x)
         assert rel_max(y, ref) < cases.TOL
         os_layers = [q['layer'] for q in net.profile(1, 16, 1) if q['name'].startswith('ry_c2d_os<')]
-        assert {'encoder/c1', 'encoder/c2', 'decoder/c5', 'decoder/c6'} <= set(os_layers), os_layers
+        assert {'decoder/c1', 'decoder/c2', 'decoder/c3', 'decoder/c5'} <= set(os_layers), os_layers
         assert not any(q['layer'] in os_layers for q in net.profile(1, 16, 1) if q['name'].startswith('ry_splitk_reduce'))
-        monkeypatch.setenv('RY_OS2_MAXM', '0'); reread(); net.set_dtype('f32')        # the same predictor on the implicit GEMM: other summation order only
+        monkeypatch.setenv('RY_OS2_MAXCOST', '0'); reread(); net.set_dtype('f32')        # the same predictor on the implicit GEMM: other summation order only
         assert not [q for q in net.profile(1, 16, 1) if q['name'].startswith('ry_c2d_os<')]
         y_ig = net.forward(x)
         assert rel_max(y, y_ig) < 1e-5 and rel_max(y_ig, ref) < cases.TOL
-        monkeypatch.setenv('RY_OS2', '14:0,13:1:2:8:2'); monkeypatch.delenv('RY_OS2_MAXM'); reread(); net.set_dtype('f32')   # forced per layer: decoder c6 off, decoder c5 on another slice
+        monkeypatch.setenv('RY_OS2', '14:0,13:1:2:8:2'); monkeypatch.delenv('RY_OS2_MAXCOST'); reread(); net.set_dtype('f32')   # forced per layer: decoder c6 off, decoder c5 on another slice
         names = {q['layer']: q['name'] for q in net.profile(1, 16, 1)}
         assert names['decoder/c5'] == 'ry_c2d_os<1,2,8,2>' and not names['decoder/c6'].startswith('ry_c2d_os'), names
         assert rel_max(net.forward(x), ref) < cases.TOL
@@ -243,7 +243,7 @@ def test_stage2_output_stationary_layers_emu(emu_ctx, monkeypatch):
         assert numpy.array_equal(net.forward(x), y)
         net.close()
     finally:
-        for k in ('RY_OS2_MINW', 'RY_OS2_MAXM', 'RY_OS2', 'RY_S2_CROP', 'RY_X3_MINM'):
+        for k in ('RY_OS2_MINW', 'RY_OS2_MAXCOST', 'RY_OS2', 'RY_S2_CROP', 'RY_X3_MINM'):
             monkeypatch.delenv(k, raising=False)
         reread()
 
