@@ -203,6 +203,30 @@ def dispatcher_bench(args):
     return out
 
 
+def self_launch(n, argv):
+    """`python3 bench.py --gpus N` without a launcher: the same script under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free>` (one rank per GPU); the ranks' stdout / stderr are ours.  -> what rank 0 printed, parsed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(Path(__file__).resolve())] + argv
+    print('bench.py: --gpus %d without a launcher: starting %s' % (n, ' '.join(cmd[1:10])), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:                                   # hand the ranks' stdout through as it comes; remember the JSON line
+        sys.stdout.write(ln); sys.stdout.flush()
+        if ln.startswith('{'):
+            line = ln
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit(rc)
+    return json.loads(line) if line else None
+
+
 def main(argv=None):
     args = parse(argv)
     if args.dispatcher:
@@ -213,8 +237,10 @@ def main(argv=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 ... bench.py --gpus %d' % (args.gpus, args.gpus))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started plainly (`python3 bench.py --gpus N`, the form of the driver's 1-GPU command): launch the N ranks ourselves, exactly as
+        # the driver's multi-GPU form does, and hand their output through (rank 0 prints the one JSON line)
+        return self_launch(args.gpus, list(sys.argv[1:] if argv is None else argv))
     use_dist = world > 1 or args.force_dist
     emu = args.emulator
     model = args.model or ('SYN-8' if emu else 'SYN-64')
@@ -466,7 +492,7 @@ def main(argv=None):
                                  'stretch in the middle): stage 1 converts only the effective frames -- another padded length and launch plan, frame '
                                  'counts that change from window to window on every ring slot -- and combine_silent scatters them back; `value` still '
                                  'counts every frame handed to convert' % NW},
-        'comm': None if comm is None else comm.kind,
+        'comm': None if comm is None else comm.kind, 'comm_ranks': None if comm is None else comm.ranks_seen,
         'config': {'workload': 'BASELINE config #3: stage-1 + stage-2 SR forward, buffer_time 0.5 s + 2x0.5 s convert_extra_time '
                                '@16 kHz / 5 ms -> %d real frames (%d padded) per window, %d window(s) per GPU per step, %s random-init weights'
                                % (N, T, Wn, model),
@@ -804,7 +830,7 @@ def compact_line(out, details):
     discard measurements, the notes) is in the details file."""
     keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
             'device_ms_per_step_rank0', 'repeats', 'value_from', 'brackets', 'spread', 'slow_brackets', 'gc', 'x_realtime', 'x_realtime_per_gpu',
-            'effective_x_realtime', 'comm', 'config', 'graph_replay_ms')
+            'effective_x_realtime', 'comm', 'comm_ranks', 'config', 'graph_replay_ms')
     line = {k: out[k] for k in keep if k in out}
 
     def pick(src, keys):

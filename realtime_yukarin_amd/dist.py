@@ -93,6 +93,10 @@ class TorchComm(object):
     def broadcast_net(self, ctx, desc, params, width=512):
         return make_net(ctx, desc, broadcast_blob(desc, params, self.device), width=width)
 
+    @property
+    def ranks_seen(self) -> int:
+        return int(_dist().get_world_size())
+
     def barrier(self):
         _dist().barrier()
 
@@ -131,11 +135,42 @@ def _launcher_identity() -> str:
         return '%d-0' % ppid
 
 
+def _proc_start(pid: int) -> Optional[str]:
+    """start time of process `pid` in clock ticks since boot (/proc/<pid>/stat field 22), None when there is no such process"""
+    try:
+        with open('/proc/%d/stat' % pid, 'rb') as f:
+            return f.read().rsplit(b')', 1)[1].split()[19].decode()
+    except (OSError, IndexError):
+        return None
+
+
+def _id_record(idb: bytes) -> bytes:
+    """what rank 0 writes: the 128-byte RCCL id + 32 bytes naming the writer (its pid and start time)"""
+    tag = ('%d %s' % (os.getpid(), _proc_start(os.getpid()) or '0')).encode()
+    return bytes(idb) + tag.ljust(32, b' ')
+
+
+def _id_record_is_live(rec: bytes) -> bool:
+    """A record counts only while its WRITER is still that very process (same pid, same start time: not a recycled pid): the name of the
+    rendezvous file is unique per launcher, but one launcher may start its ranks twice (torchrun --max-restarts, a test process, a
+    long-lived shell), and a file that a crashed attempt left behind carries a dead RCCL id -- a rank that picked it up would sit in
+    ry_comm_init until the RCCL timeout (round-4 advisor).  The writer of a leftover is dead, so the readers skip it until the new
+    rank 0 has replaced it."""
+    if len(rec) != 160:
+        return False
+    try:
+        pid_s, start = rec[128:].decode().split()
+        return _proc_start(int(pid_s)) == start
+    except (ValueError, UnicodeDecodeError):
+        return False
+
+
 def _rendezvous_path() -> str:
-    """Where rank 0 leaves the 128-byte RCCL id for the other ranks of the same launch: a file in a directory only this user can write
-    (0700, ownership and mode checked), named after the launcher's identity (pid + start time: no other launch, past or concurrent, has
-    it), MASTER_PORT and the serial number of the communicator within the launch -- so a name is used once, and nothing older can be
-    mistaken for it.  RY_COMM_RENDEZVOUS names the file explicitly (the dispatcher passes a path inside a fresh private directory)."""
+    """Where rank 0 leaves the RCCL id for the other ranks of the same launch: a file in a directory only this user can write (0700,
+    ownership and mode checked), named after the launcher's identity (pid + start time: no other launcher, past or concurrent, has it), the
+    elastic restart count when torchrun sets one, MASTER_PORT and the serial number of the communicator within the launch; the record in it
+    names its writer, and a reader accepts it only while that writer is alive (_id_record_is_live).  RY_COMM_RENDEZVOUS names the file
+    explicitly (the dispatcher passes a path inside a fresh private directory)."""
     p = os.environ.get('RY_COMM_RENDEZVOUS')
     if p:
         return p
@@ -144,7 +179,9 @@ def _rendezvous_path() -> str:
     st = os.stat(d)
     if st.st_uid != os.getuid() or (st.st_mode & 0o077):
         raise _lib.Ry355Error('%s is not a private directory of this user: refusing to exchange the RCCL id through it' % d)
-    return os.path.join(d, 'comm_%s_%s_%d' % (_launcher_identity(), os.environ.get('MASTER_PORT', '0'), _comm_serial[0]))
+    attempt = '%s.%s' % (os.environ.get('TORCHELASTIC_RUN_ID', ''), os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'))
+    attempt = ''.join(c if c.isalnum() or c in '.-' else '_' for c in attempt)[:48]
+    return os.path.join(d, 'comm_%s_%s_%s_%d' % (_launcher_identity(), attempt, os.environ.get('MASTER_PORT', '0'), _comm_serial[0]))
 
 
 class NativeComm(object):
@@ -165,22 +202,24 @@ class NativeComm(object):
                         pass
                 fd = os.open(path + '.tmp', os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
                 with os.fdopen(fd, 'wb') as f:
-                    f.write(idb.raw)
+                    f.write(_id_record(idb.raw))
                 os.replace(path + '.tmp', path)
         else:
             t0 = time.time()
             while True:
                 try:
                     st = os.stat(path)
-                    if st.st_size == 128 and st.st_uid == os.getuid():    # rank 0 renames the complete file into place; the name belongs to this launch alone
-                        break
+                    if st.st_size == 160 and st.st_uid == os.getuid():    # rank 0 renames the complete record into place ...
+                        with open(path, 'rb') as f:
+                            rec = f.read(160)
+                        if _id_record_is_live(rec):                       # ... and is still the process that wrote it (not the leftover of a crashed attempt)
+                            break
                 except OSError:
                     pass
                 if time.time() - t0 > timeout:
                     raise _lib.Ry355Error('rank %d: no RCCL id of this launch at %s after %.0f s' % (self.rank, path, timeout))
                 time.sleep(0.01)
-            with open(path, 'rb') as f:
-                idb.raw = f.read(128)
+            idb.raw = rec[:128]
         h = ctypes.c_void_p()
         lib.check(lib.dll.ry_comm_init(ctx.handle, idb, self.rank, self.world, ctypes.byref(h)))
         self.handle = h
@@ -202,6 +241,11 @@ class NativeComm(object):
         net = engine.Net(ctx, desc, (ptr, n), width=width)
         ctx.dev_free(ptr)                                      # ry_net_create re-laid the filters out into its own buffers
         return net
+
+    @property
+    def ranks_seen(self) -> int:
+        """the rank count RCCL was initialised with and every collective since has completed on (ry_comm_init's barrier included)"""
+        return self.world
 
     def barrier(self):
         self.ctx.lib.check(self.ctx.lib.dll.ry_comm_barrier(self.handle))

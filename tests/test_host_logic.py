@@ -101,6 +101,33 @@ def test_rendezvous_name_is_the_launchers_identity_not_an_mtime(tmp_path, monkey
     assert 'comm_launch-42_' in rdist._rendezvous_path()
 
 
+def test_rendezvous_record_of_a_dead_writer_is_not_an_id(monkeypatch):
+    """Round-4 advisor: one launcher may start its ranks twice (torchrun --max-restarts, a test process); the file a crashed attempt left under
+    the launch's name carries a dead RCCL id.  The record now names its writer (pid + start time) and counts only while that very process is
+    alive; the elastic restart count is part of the name."""
+    import os
+    import subprocess
+    import sys
+    from realtime_yukarin_amd import dist as rdist
+    rec = rdist._id_record(b'\x07' * 128)
+    assert len(rec) == 160 and rec[:128] == b'\x07' * 128 and rdist._id_record_is_live(rec)
+    child = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(60)'])
+    try:
+        start = rdist._proc_start(child.pid)
+        other = b'\x07' * 128 + ('%d %s' % (child.pid, start)).encode().ljust(32, b' ')
+        assert rdist._id_record_is_live(other)                                       # a live writer
+        wrong = b'\x07' * 128 + ('%d %s' % (child.pid, str(int(start) + 1))).encode().ljust(32, b' ')
+        assert not rdist._id_record_is_live(wrong)                                   # the pid was recycled: another start time
+    finally:
+        child.kill(); child.wait()
+    assert not rdist._id_record_is_live(other)                                       # the writer is gone: a leftover
+    assert not rdist._id_record_is_live(b'\x07' * 128) and not rdist._id_record_is_live(b'\x07' * 128 + b'garbage'.ljust(32, b' '))
+    monkeypatch.delenv('RY_COMM_RENDEZVOUS', raising=False)
+    monkeypatch.setenv('TORCHELASTIC_RESTART_COUNT', '0'); a = rdist._rendezvous_path()
+    monkeypatch.setenv('TORCHELASTIC_RESTART_COUNT', '1'); b = rdist._rendezvous_path()
+    assert a != b
+
+
 def test_bench_line_stays_short_enough_for_the_drivers_tail():
     """The driver keeps an 8 KB tail of bench.py's output; round 3's 14 KB line lost `device_ms_per_step_rank0` that way.  The printed line
     is built by `bench.compact_line` from the long form: with every optional block present (taken from the committed round-4 details file) it
