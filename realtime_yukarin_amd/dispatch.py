@@ -197,6 +197,7 @@ class ChunkDispatcher(object):
         can_lean = bool(getattr(acoustic_converter, 'fusable', lambda: False)()) and hasattr(super_resolution, '_get_net')
         self.lean = can_lean if lean is None else (bool(lean) and (can_lean or null_workers))
         self._bins = None
+        self._ac_sizes = getattr(acoustic_converter, '_sizes', None) or (lambda: {})
         self._mp = get_context(mp_context)
         self._q_in = [transport.FeatureQueue(slots, slot_bytes, ctx=self._mp) for _ in self.devices]
         self._q_out = [transport.FeatureQueue(slots, slot_bytes, ctx=self._mp) for _ in self.devices]
@@ -282,8 +283,11 @@ class ChunkDispatcher(object):
         from .voice_changer import VoiceChanger
         from yukarin.acoustic_feature import AcousticFeature
         k0, sp, f0, voiced, mc, effective = payload
-        if self._bins is None:
-            self._bins = sp.shape[1]
+        if self._bins is None:                                          # width of a missing `ap` block: the INPUT rate's size (combine_silent's), not the spectrogram's
+            try:
+                self._bins = int(self._ac_sizes()['ap'])
+            except Exception:
+                self._bins = sp.shape[1]
         parts = dict(f0=f0, sp=sp, voiced=voiced, mc=mc)
         keys = FULL_KEYS if pick is None else tuple(pick[2])
         if 'ap' in keys:
@@ -351,16 +355,34 @@ class ChunkDispatcher(object):
         if self.closed:
             return
         self.closed = True
-        for q, p in zip(self._q_in, self._procs):
-            if p.is_alive():
+        # One deadline for all workers, and the return rings keep being emptied while we wait: a worker with a backlog drains it into its
+        # bounded return ring before it sees the stop item, and would otherwise block in `put` for ever once that ring is full (round-4
+        # advisor: G x 20 s on the error path).
+        deadline = time.time() + 20.0
+        unsent = [(q, p) for q, p in zip(self._q_in, self._procs) if p.is_alive()]
+
+        def drain():
+            while self._avail.acquire(False):
                 try:
-                    q.put(_STOP, True, 1.0)
+                    self._next_message()                     # thrown away: the stream is over
+                except Exception:
+                    return
+        while time.time() < deadline and (unsent or any(p.is_alive() for p in self._procs)):
+            drain()
+            for q, p in list(unsent):
+                if not p.is_alive():
+                    unsent.remove((q, p)); continue
+                try:
+                    q.put(_STOP, True, 0.02)
+                    unsent.remove((q, p))
                 except Exception:
                     pass
+            for p in self._procs:
+                p.join(timeout=0.02)
         for p in self._procs:
-            p.join(timeout=20)
             if p.is_alive():
                 p.terminate()                                # this exact child (never by pattern)
+                p.join(timeout=2)
         for q in self._q_in + self._q_out:
             q.close()
         shutil.rmtree(self._dir, ignore_errors=True)

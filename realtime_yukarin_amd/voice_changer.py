@@ -131,10 +131,9 @@ class VoiceChanger(object):
         `combine_silent` leaves zeros on the frames the silence gate cut (float32, as `AcousticFeature.silent` allocates it)."""
         n = last - first
         if not isinstance(ap_in, numpy.ndarray):
-            return numpy.zeros((n, bins), numpy.float32)
-        ap = numpy.asarray(ap_in[first:last], dtype=numpy.float32)
+            return numpy.zeros((n, bins), numpy.float32)            # (`bins` = the ap width of the INPUT rate: AcousticConverter._sizes()['ap'])
+        ap = numpy.array(ap_in[first:last], dtype=numpy.float32)      # always a fresh array: the result never aliases the submitted window (round-4 advisor)
         if effective is not None and not effective[first:last].all():
-            ap = numpy.array(ap, copy=True)
             ap[~effective[first:last]] = 0
         return ap
 

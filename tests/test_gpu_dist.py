@@ -76,8 +76,10 @@ def test_bench_at_the_drivers_own_command():
     line = [ln for ln in out.splitlines() if ln.startswith('{')][-1]
     d = json.loads(line)
     assert len(line) < 6144, len(line)
-    assert d['steps'] == 20 and d['warmup'] == 5 and d['value'] > 200000 and d['value_from'] == 'median bracket'
-    walls = sorted(b['wall_ms'] for b in d['brackets'])
-    assert d['slow_brackets'] == [] and walls[-1] < 1.10 * walls[0], d['brackets']
-    assert abs(d['device_ms_per_step_rank0'] - d['ms_per_step']) < 0.05 * d['ms_per_step']
-    assert d['cpu_baseline']['gpu_result_vs_this_baseline']['sp_max_rel'] < 1e-4 and d['roofline']['frac'] > 0.5
+    assert d['steps'] == 20 and d['warmup'] == 5 and d['value'] > 0 and d['value_from'] == 'median bracket' and len(d['brackets']) == 7
+    assert d['cpu_baseline']['gpu_result_vs_this_baseline']['sp_max_rel'] < 1e-4 and 0.0 < d['roofline']['frac'] < 1.0
+    if os.environ.get('RY_TEST_PERF'):            # absolute speed and timing agreement: an idle MI355X only (round-4 advisor: a co-tenant or another
+        walls = sorted(b['wall_ms'] for b in d['brackets'])      # clock state must not turn the correctness suite red) -- RY_TEST_PERF=1 opts in
+        assert d['value'] > 200000 and d['roofline']['frac'] > 0.5
+        assert d['slow_brackets'] == [] and walls[-1] < 1.10 * walls[0], d['brackets']
+        assert abs(d['device_ms_per_step_rank0'] - d['ms_per_step']) < 0.05 * d['ms_per_step']
