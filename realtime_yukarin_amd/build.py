@@ -61,8 +61,12 @@ def build_product(force: bool = False, defs=(), suffix: str = '') -> Path:
     return lib
 
 
-def build_emu(force: bool = False, defs=(), suffix: str = '') -> Path:
-    """Same sources as plain C++ on the fiber SIMT emulator (tests/emu) -- test infrastructure only."""
+def build_emu(force: bool = False, defs=(), suffix: str = '', sanitize: bool = False) -> Path:
+    """Same sources as plain C++ on the fiber SIMT emulator (tests/emu) -- test infrastructure only.
+    sanitize=True: AddressSanitizer + UndefinedBehaviorSanitizer over the host executor (ry_net.cpp / ry_vc.cpp: plans, LRU graph slots, pointer
+    arithmetic) and the kernels' index arithmetic -> tests/emu/libry355_emu_asan.so, run by scripts/asan_emu.sh."""
+    if sanitize:
+        suffix = suffix or '_asan'
     deps = SOURCES + [EMU_DIR / 'ry_emu.h', EMU_DIR / 'ry_emu.cpp']
     if defs and not suffix:
         raise ValueError('an experiment build (extra -D switches) needs a suffix: it must never replace the test emulator library')
@@ -73,10 +77,11 @@ def build_emu(force: bool = False, defs=(), suffix: str = '') -> Path:
             cxx = shutil.which('clang++') or shutil.which('g++')
         # plain -O2 on purpose: with AVX-512 enabled (-march=native on this host) ROCm's clang drops the tail of the fminf chain in
         # ry_pad_min_rows<16> (the remainder after the 8-wide gather is only run when a NaN was seen) -- found with the emulator tests
-        objs = _compile_units(cxx, ['-x', 'c++', '-DRY_HOST_EMU', '-O2', '-std=c++17', '-fPIC', '-pthread', '-Wno-psabi'] + ['-D' + d for d in defs] +
-                              ['-I' + str(EMU_DIR), '-I' + str(CSRC)], ROOT / 'gpurun_out' / '_obj', '_emu' + suffix, [EMU_DIR / 'ry_emu.cpp'])
+        san = ['-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-g', '-shared-libasan'] if sanitize else []
+        objs = _compile_units(cxx, ['-x', 'c++', '-DRY_HOST_EMU', '-O1' if sanitize else '-O2', '-std=c++17', '-fPIC', '-pthread', '-Wno-psabi'] + san +
+                              ['-D' + d for d in defs] + ['-I' + str(EMU_DIR), '-I' + str(CSRC)], ROOT / 'gpurun_out' / '_obj', '_emu' + suffix, [EMU_DIR / 'ry_emu.cpp'])
         tmp = emu_lib.with_suffix('.so.tmp%d' % os.getpid())              # several test workers may build at once: link aside, then rename
-        subprocess.run([cxx, '-shared', '-fPIC', '-pthread'] + objs + ['-o', str(tmp)], check=True, cwd=str(ROOT))
+        subprocess.run([cxx, '-shared', '-fPIC', '-pthread'] + san + objs + ['-o', str(tmp)], check=True, cwd=str(ROOT))
         os.replace(str(tmp), str(emu_lib))
     return emu_lib
 

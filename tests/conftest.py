@@ -18,7 +18,7 @@ def pytest_configure(config):
 def emu_ctx():
     """Context over the host-side SIMT emulator build of the kernel sources (CPU, test-only)."""
     from realtime_yukarin_amd import _lib, build, engine
-    lib = _lib.Ry355Lib(build.build_emu())
+    lib = _lib.Ry355Lib(os.environ.get('RY_EMU_LIB') or build.build_emu())      # RY_EMU_LIB: another build of the emulator library (scripts/asan_emu.sh: the sanitizer build)
     return engine.Context(0, lib)
 
 

@@ -128,6 +128,7 @@ def test_mfma_fragment_map_is_transpose_detecting(gpu_ctx):
 SMALL_NETS = [
     (1, 9, 9, 8, 8, 128, 1, 1), (1, 9, 9, 64, 8, 128, 1, 2), (1, 523, 9, 16, 8, 256, 1, 1), (1, 9, 9, 8, 3, 40, 1, 1),
     (2, 1, 1, 8, 8, 128, 128, 1), (2, 1, 1, 32, 8, 128, 128, 1),
+    (2, 1, 1, 32, 3, 24, 40, 2), (2, 1, 1, 16, 0, 10, 12, 2), (2, 1, 1, 64, 3, 16, 16, 1),      # round 5: 2-D predictors with extensive_layers 3 / 0 ('same' 1x1 layers, k1 end layers) on the GPU
 ]
 
 

@@ -74,6 +74,8 @@ NETS = [
     (1, 9, 9, 8, 3, 40, 1, 1),          # extensive_layers 3: 'same' layers
     (2, 1, 1, 8, 8, 128, 128, 1),       # all-direct path
     (2, 1, 1, 32, 8, 128, 128, 1),      # implicit-GEMM middle layers
+    (2, 1, 1, 32, 3, 24, 40, 2),        # 2-D, extensive_layers 3: two down / up layers, the rest 'same' 1x1 layers; batch 2, ragged sizes
+    (2, 1, 1, 16, 0, 10, 12, 2),        # 2-D, extensive_layers 0: every layer 1x1 (k1 end layers)
 ]
 
 

@@ -8,9 +8,10 @@ import numpy
 import pytest
 import torch
 
+from oracle import mc2sp as omc
 from oracle import torch_ref, trained_like
-from realtime_yukarin_amd import engine, synth
-from realtime_yukarin_amd.weights import flatten_params, validate_params
+from realtime_yukarin_amd import engine, sptk, synth
+from realtime_yukarin_amd.weights import flatten_params, synthetic_params, validate_params
 
 TOL = 1e-4
 
@@ -37,6 +38,10 @@ def run(ctx, name, n_frames, windows):
     n2 = engine.Net(ctx, d2, flatten_params(d2, P2), width=synth.FFT_BINS - 1)
     t1, t2 = torch_ref.TorchUNet(P1), torch_ref.TorchUNet(P2)
     t1d, t2d = torch_ref.TorchUNet(P1, dtype=torch.float64), torch_ref.TorchUNet(P2, dtype=torch.float64)
+    mtx = sptk.mc2sp_matrix(d1.out_ch - 1, sptk.mcepalpha(16000), 1024)
+    P1s = synthetic_params(d1, synth.SEED_STAGE1)
+    n1s = engine.Net(ctx, d1, flatten_params(d1, P1s))
+    t1sd = torch_ref.TorchUNet(P1s, dtype=torch.float64)
     try:
         for n in windows:                                             # other windows than the calibration one
             x = synth.stage1_input(n, seed=830 + n)[0]
@@ -54,8 +59,29 @@ def run(ctx, name, n_frames, windows):
                   % (name, n, e32, e64, float(numpy.abs(r / rd - 1).max()), float(numpy.log(rd).min()), float(numpy.log(rd).max())))
             assert e32 < TOL and e64 < TOL and numpy.isfinite(y).all()
             assert float(numpy.log(rd).max() - numpy.log(rd).min()) > 0.05             # the predictor did something
+            # round 5: the split-bf16 mode ('bf16x3': x w ~ x_hi w_hi + x_lo w_hi + x_hi w_lo) on THESE weights -- folded scales from 3e-4 to
+            # 4e2 are where a dropped lo * lo term or a mis-scaled split would show -- held to the same 1e-4 bar, stage 2 alone and through
+            # the chained window core (stage 1 -> combine_silent -> mc2sp -> stage 2)
+            n2.set_dtype('bf16x3')
+            y3 = n2.convert(sp).astype(numpy.float64)
+            e3 = float(numpy.abs(y3 / rd - 1).max())
+            print('%s stage-2 n=%d in split-bf16 mode: element-wise vs float64 oracle %.2e (differs from the fp32 path: %s)' % (name, n, e3, not numpy.array_equal(y3, y)))
+            assert e3 < TOL and numpy.isfinite(y3).all()
+            for mode in ('bf16x3', 'f32'):
+                n2.set_dtype(mode)
+                core = engine.VcCore(n1s, n2, mtx)                     # (stage 1 with the pix2pix-init weights: the trained-like stage-1 output is not a mel-cepstrum, exp() of it overflows)
+                eff = numpy.ones(n, bool); eff[n // 3:n // 3 + max(1, n // 10)] = False
+                mc, spw = core.convert(x[eff], eff)
+                core.close()
+                mc_ref = numpy.zeros((n, d1.out_ch), numpy.float64); mc_ref[eff] = torch_ref.stage1_convert_core(t1sd, x[eff].astype(numpy.float64))
+                mid = (omc.mc2sp(mc_ref, omc.mcepalpha(16000), 1024) + 1e-16).astype(numpy.float32)      # voice_changer.py:38-41: the cast before stage 2
+                sp_ref = torch_ref.stage2_convert(t2d, mid.astype(numpy.float64))
+                ec = float(numpy.abs(spw.astype(numpy.float64) / sp_ref - 1).max())
+                em = float(numpy.abs(mc - mc_ref).max() / numpy.abs(mc_ref).max())
+                print('%s chained core n=%d, stage 2 in %s mode: spectrogram element-wise vs float64 oracle %.2e, mc %.2e' % (name, n, mode, ec, em))
+                assert ec < TOL and em < TOL and not mc[~eff].any()
     finally:
-        n1.close(); n2.close()
+        n1.close(); n2.close(); n1s.close()
 
 
 def test_trained_like_statistics_emu(emu_ctx):
