@@ -1597,6 +1597,28 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
     // numpy.pad(mode='minimum'): the per-channel minimum over the real rows, taken here by the workgroups that reach that far
     const int src_rows = PADMIN ? p.n_real : p.Lin;
     const bool need_min = PADMIN && pos0 + NP > p.n_real;                            // wave-uniform
+    // [r5] The minimum is taken by the WHOLE workgroup at once: thread (channel c = tid % 64, row group tid / 64 of four) walks rows rg, rg + 4, ...
+    // of its channel with sixteen loads in flight, the four partial minima meet in the LDS.  (Round 2 had every lane of a wave walk all
+    // real rows of its channel eight at a time -- 38 dependent rounds at 300 frames, with 9 of 64 lanes at work: 16.4 us for the layer, a fifth of
+    // the stage-1 forward.)  The condition is workgroup-uniform: the last position group of the tile reaches the padding.
+    __shared__ float cmins[4 * 64];
+    if (PADMIN) {
+        const int r_last = (tile * PG + PG - 1) * TP - p.pad + NP;                   // one past the last input row any wave of this workgroup reads
+        if (r_last > p.n_real) {
+            const int c = lane, rg = wave;                                           // (the fused pad needs Ca <= 64, one lane set: build_plan)
+            const float* colc = p.sa + (size_t)b * (size_t)p.n_real * (size_t)p.Ca + (c < p.Ca ? c : 0);
+            float m = INFINITY;
+            for (int r = rg; r < p.n_real; r += 64) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = colc[(unsigned)((r + 4 * u < p.n_real ? r + 4 * u : rg) * p.Ca)];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) m = fminf(m, v[u]);
+            }
+            cmins[rg * 64 + c] = m;
+            __syncthreads();
+        }
+    }
 
     // the epilogue's scale / shift of the output this thread will store: requested now, with the operand loads, instead of as one more
     // dependent round trip behind the barrier
@@ -1639,15 +1661,7 @@ RY_KERNEL(256) void ry_c1d_os(RyC1dOsParams p) {
         }
         if (PADMIN) {
             cmin = INFINITY;
-            if (need_min) {
-                for (int r = 0; r < p.n_real; r += 8) {                              // eight independent loads in flight per round
-                    float v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = col[(unsigned)((r + u < p.n_real ? r + u : 0) * Cs) + (unsigned)ci];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) cmin = fminf(cmin, v[u]);
-                }
-            }
+            if (need_min) cmin = fminf(fminf(cmins[ci], cmins[64 + ci]), fminf(cmins[128 + ci], cmins[192 + ci]));
         }
     };
     // applied after the scheduling fence, so that no select sits between the loads (the scheduler otherwise waits for the first

@@ -260,8 +260,11 @@ static int prepare_layer(ry_ctx* ctx, Arena& arena, Layer& l, int ndim, float ep
 // Activation buffers that an implicit-GEMM layer may read end in ZTAIL zeroed floats: the LDS-DMA kernel fetches its padding
 // from there (RyConvGeom::zoff1 / zoff2); nothing ever writes them.
 static const size_t ZTAIL = 2048;     // (round 5: a whole zeroed PIXEL of up to 2048 channels -- ry_c2d_os fetches out-of-image taps from it at any channel offset)
+static int g_poison = 0;               // RY_POISON=1 (diagnostics): fresh activation buffers are filled with NaN patterns, so that a kernel that reads a row / pixel its producer
+                                       // never wrote shows up as NaN in the result instead of depending on what the allocator handed out
 static int alloc_ztail(ry_ctx* ctx, Arena& arena, float** p, size_t nfloats) {
     RY_TRY(arena.alloc(p, nfloats + ZTAIL));
+    if (g_poison) RT_TRY(rt::dmemset(*p, 0xFF, nfloats * sizeof(float), ctx->stream));
     RT_TRY(rt::dmemset(*p + nfloats, 0, ZTAIL * sizeof(float), ctx->stream));
     RT_TRY(rt::stream_sync(ctx->stream));
     return RY_OK;
@@ -1002,7 +1005,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
     const float slope = d.lrelu_slope;
     // the fused pad takes the column minimum inside the workgroups that reach the padding: one chain of n_frames / 8 load rounds, worth
     // it while the window is short (measured: 300 frames -3 us, 1000 frames +14 us against the separate ry_pad_min_rows node)
-    const bool padfuse_now = nd == 1 && P.s1_padfuse && P.n_frames <= 512;
+    const bool padfuse_now = nd == 1 && P.s1_padfuse && P.n_frames <= 2048;     // [r5] (the cooperative minimum: one round of loads per 1024 frames; was 512 with the per-lane walk)
     if (P.mode == 1 && !padfuse_now) {
         const int cols_in = nd == 1 ? d.in_ch : d.width + 1;
         const int cols_out = nd == 1 ? d.in_ch : d.width;
@@ -1305,7 +1308,8 @@ static int read_plan_env() {
     g_os2_maxcost = 4608; g_os2_min_filter = (size_t)1 << 21;
     if (const char* e = getenv("RY_OS2_MAXCOST")) g_os2_maxcost = atoi(e);
     if (const char* e = getenv("RY_OS2_MINW")) g_os2_min_filter = (size_t)atoll(e);
-    g_os2_dbg = 0;
+    g_os2_dbg = 0; g_poison = 0;
+    if (const char* e = getenv("RY_POISON")) g_poison = atoi(e);
     if (const char* e = getenv("RY_OS2_DBG")) g_os2_dbg = atoi(e);
     if (const char* e = getenv("RY_OS2")) {
         for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {

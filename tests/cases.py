@@ -234,3 +234,25 @@ def oracle_forward(desc, P, x):
     if desc.ndim == 1:
         return unet.unet_forward(x.transpose(0, 2, 1), P, desc.extensive_layers).transpose(0, 2, 1)
     return unet.unet_forward(x[:, numpy.newaxis], P, desc.extensive_layers)[:, 0]
+
+
+def poisoned_converts(ctx, net, sizes, monkeypatch, modes=('f32', 'bf16', 'bf16x3')):
+    """RY_POISON=1 (round 5): every fresh stage-2 activation buffer -- fp32 and bf16 copies -- is filled with NaN patterns, so a kernel that reads a
+    row / pixel / channel its producer did not write in THIS forward (dead-row crop, row ranges of a discard, skipped fp32 copies of the bf16
+    modes) turns the result into NaN instead of depending on what the allocator handed out.  -> [(n, mode, NaNs, NaNs in the kept rows of a discard)]"""
+    import ctypes
+    reread = lambda: ctx.lib.check(ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    out = []
+    try:
+        monkeypatch.setenv('RY_POISON', '1'); reread()
+        for n, sp in sizes:
+            for mode in modes:
+                net.set_dtype(mode)                                   # drops the plans: the next convert builds poisoned buffers
+                a = net.convert(sp)
+                k = max(1, n // 3)
+                b = net.convert(sp, discard=(k, k)) if n > 2 * k + 1 else a
+                out.append((n, mode, int(numpy.isnan(a).sum()), int(numpy.isnan(b[k:n - k]).sum()) if n > 2 * k + 1 else 0))
+    finally:
+        monkeypatch.delenv('RY_POISON', raising=False); reread()
+        net.set_dtype('f32')
+    return out

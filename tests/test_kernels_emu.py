@@ -250,6 +250,15 @@ def test_stage2_output_stationary_layers_emu(emu_ctx, monkeypatch):
         reread()
 
 
+def test_no_kernel_reads_what_its_producer_did_not_write_emu(emu_ctx, monkeypatch):
+    d = NetDesc(2, 1, 1, 64, 3)
+    net = engine.Net(emu_ctx, d, flatten_params(d, synthetic_params(d, 471, bias_std=0.05)), width=16)
+    sizes = [(n, numpy.exp(numpy.random.default_rng(90 + n).normal(-6.0, 1.5, (n, 17))).astype('f4')) for n in (11, 23)]
+    res = cases.poisoned_converts(emu_ctx, net, sizes, monkeypatch)
+    assert all(r[2] == 0 and r[3] == 0 for r in res), res
+    net.close()
+
+
 def test_stage2_dead_row_crop_emu(emu_ctx, monkeypatch):
     """The convert wrapper keeps n_frames rows of a window padded to a multiple of 128: decoder layers may skip the rows that only
     feed the discarded padding (LayerPlan::crop_hi).  Same arithmetic on the rows that are kept: results are bit-identical to the
