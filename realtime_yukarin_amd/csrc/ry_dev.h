@@ -64,6 +64,14 @@ RY_DEV void ry_wave_sync() {
 RY_DEV void ry_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// A wave reads LDS bytes that its OWN earlier global_load_lds wrote, with AFTER younger vector-memory instructions of this wave allowed to be still
+// in flight: an explicit s_waitcnt, and nothing moves across it.  The compiler's own timing of such reads is not to be relied on -- hipcc 7.2 waited for
+// the DMA of the first KiB of a ring slot and read the second KiB, requested after that wait, with no wait at all (round 5, ry_c2d_os<2,2,8,2,true>:
+// NaNs in rows 4-7 of every tile on the MI355X, profiles/r05_n_xl.txt).  (The emulator runs the lanes one after the other: all of them past the copy first.)
+// every LDS read of this wave has delivered its registers; nothing moves across (what follows may overwrite the LDS bytes just read, by DMA)
+RY_DEV void ry_lds_reads_returned() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int AFTER>
+RY_DEV void ry_own_dma_landed() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER) : "memory"); }
 // the instruction scheduler does not move anything across this point
 RY_DEV void ry_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 RY_DEV float ry_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }

@@ -803,7 +803,12 @@ RY_DEV void ry_rs_step(const float (&v)[NV], float (&h)[NV / 2], int lane) {
     }
 }
 
-template <int MT4, int NT4, int WAVES, int DEPTH>
+// XL = true: the pixels travel global -> LDS by DMA and from there into the MFMA operand registers.  A wave-load of pixels straight into registers has to
+// follow the lane order of the instruction -- lane (block b, i) = pixel i, channels 4 b .. 4 b + 3: consecutive lanes read DIFFERENT pixels, 16 bytes each --
+// and measured at about half the rate of the filter stream (contiguous KiB).  By DMA, lane 16 i + q of a wave-instruction fetches quad q ^ 4 i of pixel i
+// (sixteen consecutive lanes = one contiguous 256-byte piece) and the data lands lane-linear in a wave-private ring slot; lane (b, i) then reads position
+// 16 i + (b ^ 4 i) with one ds_read_b128: the XOR on the source side makes the sixteen lanes of every read group hit sixteen different bank quads.
+template <int MT4, int NT4, int WAVES, int DEPTH, bool XL>
 RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
     constexpr int MT = 4 * MT4, NT = 4 * NT4;
     constexpr int V = MT4 * NT4 * 4, VP = (V + 15) / 16 * 16, L = VP / 16;      // partial sums per lane, padded for the 16-way scatter
@@ -865,14 +870,20 @@ RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
     unsigned pb[MT4];
     const float* xs = p.src1;
     const float* wr = wq0;
+    // XL: wave-private ring slots of MT4 KiB each; this lane's DMA role (pixel lane / 16, quad (lane % 16) ^ 4 (lane / 16)) and its read position
+    // (DEPTH slots, refilled in place: the reads of a slot have RETURNED -- explicit lgkmcnt(0) in consume -- before the DMA that overwrites it is issued)
+    __shared__ __attribute__((aligned(16))) float xs0[XL ? WAVES * MT4 * 256 : 4], xs1[XL ? WAVES * MT4 * 256 : 4];
+    __shared__ __attribute__((aligned(16))) float xs2[XL && DEPTH == 4 ? WAVES * MT4 * 256 : 4], xs3[XL && DEPTH == 4 ? WAVES * MT4 * 256 : 4];
+    const int dpx = lane >> 4, dq = (lane & 15) ^ (4 * dpx);
+    const int rpos = (sub * 16 + (blk ^ (4 * sub))) * 4;            // floats into a group's KiB
     auto round_setup = [&]() {
         const bool first = r_chunk < cpt1;
         const int key = 2 * r_tap + (first ? 0 : 1);
         if (key != r_key) {                                         // another tap or the other source: this lane's pixel offsets
             r_key = key;
-            const unsigned* ot = otab + ((first ? 0 : p.ntaps) + r_tap) * MT + sub;
+            const unsigned* ot = otab + ((first ? 0 : p.ntaps) + r_tap) * MT + (XL ? dpx : sub);
 #pragma unroll
-            for (int g = 0; g < MT4; ++g) pb[g] = ot[4 * g] + (unsigned)blk * 16u;
+            for (int g = 0; g < MT4; ++g) pb[g] = ot[4 * g] + (unsigned)(XL ? dq : blk) * 16u;
         }
         xs = (first ? p.src1 : p.src2 - (size_t)cpt1 * 64) + r_chunk * 64;
         wr = wq0 + (size_t)r_rel * (RND * 256);
@@ -884,7 +895,7 @@ RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
         round_setup();
     };
 
-    f32x4 xa[DEPTH][MT4], wb[DEPTH][NT4];
+    f32x4 xa[XL ? 1 : DEPTH][MT4], wb[DEPTH][NT4];
     f32x4 acc[MT4][NT4];
 #pragma unroll
     for (int g = 0; g < MT4; ++g)
@@ -897,19 +908,36 @@ RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
             for (int h = 0; h < NT4; ++h) wb[d][h] = ry_ld4(wr + j * 256 + (size_t)h * wh);
         }
         if (!(dbg & 1)) {
-            const char* sb = reinterpret_cast<const char*>(xs + j * 64);
+            if (XL) {
+                float* const slot = (d == 0 ? xs0 : d == 1 ? xs1 : d == 2 ? xs2 : xs3) + wave * (MT4 * 256);
 #pragma unroll
-            for (int g = 0; g < MT4; ++g) xa[d][g] = *reinterpret_cast<const f32x4*>(sb + pb[g]);
+                for (int g = 0; g < MT4; ++g) ry_glds16_off(xs + j * 64, pb[g], slot + g * 256);
+            } else {
+                const char* sb = reinterpret_cast<const char*>(xs + j * 64);
+#pragma unroll
+                for (int g = 0; g < MT4; ++g) xa[d][g] = *reinterpret_cast<const f32x4*>(sb + pb[g]);
+            }
         }
     };
-    auto consume = [&](int d) {
+    auto consume = [&](int d, int j, int after) {                   // unit j of the round being multiplied, in slot d; `after` younger units are in flight
+        if (XL) {
+            const float* const slot = (d == 0 ? xs0 : d == 1 ? xs1 : d == 2 ? xs2 : xs3) + wave * (MT4 * 256) + rpos;
+            if (after >= 3) ry_own_dma_landed<3 * (MT4 + NT4)>();
+            else if (after == 2) ry_own_dma_landed<2 * (MT4 + NT4)>();
+            else if (after == 1) ry_own_dma_landed<MT4 + NT4>();
+            else ry_own_dma_landed<0>();
+#pragma unroll
+            for (int g = 0; g < MT4; ++g) xa[0][g] = ry_ld4(slot + g * 256);
+            ry_lds_reads_returned();
+        }
+        const int xd = XL ? 0 : d;
         if (dbg & 4) return;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int g = 0; g < MT4; ++g)
 #pragma unroll
-                for (int h = 0; h < NT4; ++h) acc[g][h] = ry_mfma_4x4x1(xa[d][g][t], wb[d][h][t], acc[g][h]);
+                for (int h = 0; h < NT4; ++h) acc[g][h] = ry_mfma_4x4x1(xa[xd][g][t], wb[d][h][t], acc[g][h]);
     };
 
     // Ring of DEPTH units: while unit j of a round is multiplied, unit j + DEPTH is requested -- the last DEPTH requests of a round already
@@ -922,13 +950,13 @@ RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
 #pragma unroll
             for (int j = 0; j < RND; ++j) {
                 if (j == RND - DEPTH) round_next();
-                consume(j % DEPTH);
+                consume(j % DEPTH, j, DEPTH - 1);
                 issue(j % DEPTH, (j + DEPTH) % RND);
             }
         }
 #pragma unroll
         for (int j = 0; j < RND; ++j) {
-            consume(j % DEPTH);
+            consume(j % DEPTH, j, RND - 1 - j < DEPTH - 1 ? RND - 1 - j : DEPTH - 1);
             if (j + DEPTH < RND) issue(j % DEPTH, j + DEPTH);
         }
     }

@@ -445,10 +445,10 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
 #define RY_OS2_CONFIGS(X)                                                                                              \
     X(1, 1, 4, 4) X(1, 1, 8, 4) X(1, 1, 8, 2) X(1, 1, 16, 2) X(2, 1, 4, 4) X(2, 1, 8, 4) X(2, 1, 8, 2) X(2, 1, 16, 2)     \
     X(3, 1, 4, 4) X(3, 1, 8, 4) X(3, 1, 8, 2) X(3, 1, 16, 2) X(4, 1, 4, 4) X(4, 1, 8, 4) X(4, 1, 8, 2) X(4, 1, 16, 2)     \
-    X(6, 1, 4, 4) X(6, 1, 8, 4) X(6, 1, 8, 2)                                                             \
+    X(6, 1, 4, 4) X(6, 1, 8, 2)                                                             \
     X(1, 2, 4, 4) X(1, 2, 8, 4) X(1, 2, 8, 2) X(1, 2, 16, 2) X(2, 2, 4, 4) X(2, 2, 8, 4) X(2, 2, 8, 2) X(2, 2, 16, 2)     \
     X(3, 2, 4, 4) X(3, 2, 8, 4) X(3, 2, 8, 2) X(3, 2, 16, 2) X(4, 2, 4, 4) X(4, 2, 8, 4) X(4, 2, 8, 2) X(4, 2, 16, 2)     \
-    X(6, 2, 4, 4) X(6, 2, 8, 4) X(6, 2, 8, 2)                                                                             \
+    X(6, 2, 4, 4) X(6, 2, 8, 2)                                                                             \
     X(1, 4, 4, 4) X(1, 4, 8, 4) X(1, 4, 8, 2) X(1, 4, 16, 2) X(2, 4, 4, 4) X(2, 4, 8, 4) X(2, 4, 8, 2) X(2, 4, 16, 2)     \
     X(3, 4, 4, 4) X(3, 4, 8, 4) X(3, 4, 8, 2) X(4, 4, 4, 4) X(4, 4, 8, 2) X(6, 4, 4, 2)
 
@@ -459,6 +459,10 @@ static bool os2_has_config(int mt4, int nt4, int waves, int depth) {
     return false;
 }
 
+static int g_os2_xl = 1;               // RY_OS2_XL=0: ry_c2d_os loads its pixels straight into registers (A/B of the LDS-DMA pixel path)
+// The LDS-DMA pixel path keeps one KiB per (wave, four tile rows, unit in flight): slices with two units in flight and at most 64 KiB of ring
+// (what the other window lane's kernels leave free on a CU).
+static constexpr bool os2_xl_ok(int mt4, int waves, int depth) { return depth == 2 && mt4 * waves <= 32; }
 static int g_os2_dbg = 0;              // RY_OS2_DBG: ablation bits of ry_c2d_os, honoured by -DRY_OS2_DBG_BUILD builds only (diagnostics, WRONG results): 1 no pixel loads, 2 no filter loads, 4 no MFMAs, 8 no K loop, 16 no offset table, 32 no reduction / stores
 static int g_os2_maxcost = 4608;       // RY_OS2_MAXCOST: a layer with the ry_c2d_os filter layout runs output-stationary when slice cost x K units stays below this (0: never).
                                        // Fitted: encoder c6 / decoder c1 at 300 frames (4096) win by 2-4 us, encoder c5 at 300 frames (10240) and decoder c2 at 100 frames (8192) lose by 8-11
@@ -468,7 +472,7 @@ static bool g_os2_forced[16];
 // Slice of one layer, by a cost fitted to the slice sweeps on the MI355X (profiles/r05_e_os_sweep_n{300,100}.txt): a workgroup pulls K x (rows +
 // channels) of its tile through its CU's L1, the pixel rows at about half the rate of the filter rows (a wave-load of pixels is four
 // 256-byte pieces of four different pixels, a wave-load of filters one contiguous KiB), and the launch takes as many rounds as there are
-// workgroups per CU.  cost = max(1, workgroups / 256) x (2 rows + channels) of the tile; the sweeps rank the slices of every bottom layer in this
+// workgroups per CU.  cost = max(1, workgroups / 256) x (2 rows + channels) of the tile (1.5 rows where the pixels travel by DMA); the sweeps rank the slices of every bottom layer in this
 // order (encoder c7: 4 x 8 < 8 x 4 < 4 x 4 < 12 x 4; decoder c1: 24 x 16 < 12 x 16 < 8 x 16 < 16 x 16).  `cost_out` x K units is what the
 // caller compares with the implicit GEMM (g_os2_maxcost).
 static bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int* waves, int* depth, double* cost_out = nullptr) {
@@ -482,8 +486,9 @@ static bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int
             // the chain request -> landing -> MFMA at one or two workgroups per CU); whatever the run of K units feeds with whole rounds of four
             int w = 0, d = 0;
             static const int WD[4][2] = {{8, 2}, {4, 4}, {16, 2}, {8, 4}}, WD_BIG[4][2] = {{4, 4}, {8, 2}, {4, 2}, {8, 4}};
+            const bool big = m * n >= 12 && !(g_os2_xl && os2_xl_ok(m, 8, 2));        // (a large tile whose pixels go through the LDS keeps eight waves)
             for (int k = 0; k < 4 && w == 0; ++k) {
-                const int cw = (m * n >= 12 ? WD_BIG : WD)[k][0], cd = (m * n >= 12 ? WD_BIG : WD)[k][1];
+                const int cw = (big ? WD_BIG : WD)[k][0], cd = (big ? WD_BIG : WD)[k][1];
                 if ((*waves != 0 && *waves != cw) || (*depth != 0 && *depth != cd) || U % (4 * cw) != 0 || !os2_has_config(m, n, cw, cd)) continue;
                 w = cw; d = cd;
             }
@@ -491,7 +496,8 @@ static bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int
                 if (U % (4 * *waves) == 0 && os2_has_config(m, n, *waves, *depth)) { w = *waves; d = *depth; }
             if (w == 0) continue;
             const double wgs = (double)((M + 4 * m - 1) / (4 * m)) * (N / (4 * n)) * nphases;
-            const double cost = (wgs > 256.0 ? wgs / 256.0 : 1.0) * (8.0 * m + 4.0 * n) * ((double)((M + 4 * m - 1) / (4 * m)) * 4 * m / M);   // padded rows are loaded too
+            const double px = g_os2_xl && os2_xl_ok(m, w, d) ? 6.0 : 8.0;      // pixel rows by DMA through the LDS: contiguous 256-byte pieces (encoder c6: 12 x 8 ahead of 8 x 16)
+            const double cost = (wgs > 256.0 ? wgs / 256.0 : 1.0) * (px * m + 4.0 * n) * ((double)((M + 4 * m - 1) / (4 * m)) * 4 * m / M);   // padded rows are loaded too
             if (cost < best - 1e-9) { best = cost; bm = m; bn = n; bw = w; bd = d; }
         }
     if (bm == 0) return false;
@@ -524,12 +530,15 @@ static int launch_c2d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     const int total = p.mtiles * p.ntiles * p.nphases;
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
     char nm[48];
-    snprintf(nm, sizeof nm, "ry_c2d_os<%d,%d,%d,%d>", lp.os2_mt4, lp.os2_nt4, lp.os2_waves, lp.os2_depth);      // as rocprofv3 prints it
+    const bool xl = g_os2_xl && os2_xl_ok(lp.os2_mt4, lp.os2_waves, lp.os2_depth);
+    snprintf(nm, sizeof nm, "ry_c2d_os<%d,%d,%d,%d,%s>", lp.os2_mt4, lp.os2_nt4, lp.os2_waves, lp.os2_depth, xl ? "true" : "false");      // as rocprofv3 prints it
     RY_TRY(Lc.begin(nm, l.name, lp.flops, lp.bytes, grid));
     bool done = false;
 #define X(A, B_, C, D)                                                                                          \
     if (!done && lp.os2_mt4 == A && lp.os2_nt4 == B_ && lp.os2_waves == C && lp.os2_depth == D) {               \
-        RY_LAUNCH((ry_c2d_os<A, B_, C, D>), grid, 64 * C, Lc.stream, p); done = true;                           \
+        if (xl) RY_LAUNCH((ry_c2d_os<A, B_, C, D, os2_xl_ok(A, C, D)>), grid, 64 * C, Lc.stream, p);            \
+        else RY_LAUNCH((ry_c2d_os<A, B_, C, D, false>), grid, 64 * C, Lc.stream, p);                            \
+        done = true;                                                                                            \
     }
     RY_OS2_CONFIGS(X)
 #undef X
@@ -1308,7 +1317,8 @@ static int read_plan_env() {
     g_os2_maxcost = 4608; g_os2_min_filter = (size_t)1 << 21;
     if (const char* e = getenv("RY_OS2_MAXCOST")) g_os2_maxcost = atoi(e);
     if (const char* e = getenv("RY_OS2_MINW")) g_os2_min_filter = (size_t)atoll(e);
-    g_os2_dbg = 0; g_poison = 0;
+    g_os2_dbg = 0; g_poison = 0; g_os2_xl = 1;
+    if (const char* e = getenv("RY_OS2_XL")) g_os2_xl = atoi(e);
     if (const char* e = getenv("RY_POISON")) g_poison = atoi(e);
     if (const char* e = getenv("RY_OS2_DBG")) g_os2_dbg = atoi(e);
     if (const char* e = getenv("RY_OS2")) {

@@ -101,6 +101,36 @@ def os_identity_rows(ctx):
     return y.reshape(16, Cout), numpy.stack([W[:, 65 * i % Cin, 0, 0] for i in range(16)])      # y[pixel i][n] = W[n][65 i]
 
 
+def os_every_slice(ctx, one_round=False):
+    """Every instantiated slice of ry_c2d_os (tile rows / 4, tile channels / 4, waves, units in flight) on one layer against the implicit GEMM of the
+    same operator: a decoder-c1-like sub-pixel deconvolution (48 rows per phase, 64 K units), or with one_round a 1 x 1 layer of 2048 channels whose
+    waves run the prologue and the last round only (the pixel value carries its row and its 64-channel chunk: a KiB of a ring slot read before its DMA
+    landed shows as a wrong chunk).  -> [(slice, relative error)] of the slices that exist for the shape"""
+    rng = numpy.random.default_rng(31)
+    if one_round:
+        H, W_, Cin, Cout = 3, 8, 2048, 64
+        x = ((numpy.arange(H * W_).reshape(H, W_, 1) + 1) + 1000.0 * (numpy.arange(Cin) // 64)[None, None, :]).astype('f4')[None]
+        Wt = numpy.ones((Cout, Cin, 1, 1), 'f4')
+        kw = dict(stride=1, pad=0, act=None)
+    else:
+        H, W_, Cin, Cout = 6, 8, 1024, 64
+        x = rng.normal(size=(1, H, W_, Cin)).astype('f4')
+        Wt = rng.normal(0, 0.02, size=(Cin, Cout, 4, 4)).astype('f4')
+        kw = dict(stride=2, pad=1, transposed=True, act=None)
+    yi = ctx.conv2d(x, Wt, None, None, path='igemm', **kw)
+    out = []
+    for n in (1, 2, 4):
+        for m in (1, 2, 3, 4, 6):
+            for (w, d) in ((4, 4), (8, 4), (8, 2), (16, 2), (4, 2)):
+                try:
+                    y = ctx.conv2d(x, Wt, None, None, path='os', tile=(m, n, w, d), **kw)
+                except RuntimeError as e:
+                    assert 'no output-stationary slice' in str(e), e
+                    continue
+                out.append(((m, n, w, d), float(numpy.abs(y - yi).max() / numpy.abs(yi).max())))
+    return out
+
+
 # 2-D dilated convolution (north_star operator coverage: "1-D/2-D dilated conv"): B, H, W, Cin, Cout, k, stride, pad, dilate, act, path, tile, splits
 CONV2D_DILATED_CASES = [
     (1, 12, 16, 32, 128, 3, 1, 2, 2, 'lrelu', 'igemm', '32x128', 0),       # 'same' 3x3 with dilation 2 on the MFMA path

@@ -60,6 +60,8 @@ RY_DEV void ry_glds16_off(const float* base_uniform, unsigned byte_off_lane, flo
 RY_DEV int ry_uniform(int v) { return v; }
 RY_DEV void ry_wave_sync() { ry_emu::wave_sync(); }
 RY_DEV void ry_lds_barrier() { ry_emu::sync_block(); }
+template <int AFTER> RY_DEV void ry_own_dma_landed() { ry_emu::wave_sync(); }
+RY_DEV void ry_lds_reads_returned() { ry_emu::wave_sync(); }
 RY_DEV void ry_sched_fence() {}
 RY_DEV float ry_mul_rn(float a, float b) { volatile float r = a * b; return r; }     // volatile: no contraction with a following add
 RY_DEV float ry_add_rn(float a, float b) { volatile float r = a + b; return r; }

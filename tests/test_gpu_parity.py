@@ -61,6 +61,16 @@ def test_conv2d_os_gpu(gpu_ctx, case):
     assert rel_max(y, r) < cases.TOL
 
 
+@pytest.mark.parametrize('one_round', [False, True], ids=['deconv-64-units', 'one-round'])
+def test_conv2d_os_every_slice_gpu(gpu_ctx, one_round):
+    """every instantiated slice of ry_c2d_os, with and without the LDS-DMA pixel path, against the implicit GEMM (round 5: the compiler's own
+    timing of LDS-DMA reads let six slices read a ring slot early on the hardware only; the kernel waits explicitly since)"""
+    res = cases.os_every_slice(gpu_ctx, one_round)
+    assert len(res) >= (20 if one_round else 40), res
+    bad = [r for r in res if not r[1] < 1e-5]
+    assert not bad, bad
+
+
 OS_FULL_SIZE = [          # the weight-streaming bottom of SYN-64 at the 300-frame window, planner's slice (B, H, W, Cin, Cout, k, s, p, transposed, act, path, tile, splits)
     (1, 6, 8, 512, 512, 4, 2, 1, False, 'lrelu', 'os', None, 0),          # encoder c7: 12 pixels, 16.8 MB of filters
     (1, 12, 16, 512, 512, 4, 2, 1, False, 'lrelu', 'os', None, 0),        # encoder c6: 48 pixels

@@ -33,6 +33,11 @@ def test_conv2d_os_emu(emu_ctx, case):
     assert rel_max(y, r) < cases.TOL
 
 
+def test_conv2d_os_every_slice_emu(emu_ctx):
+    res = cases.os_every_slice(emu_ctx, one_round=True)
+    assert len(res) >= 20 and all(e < 1e-5 for _, e in res), res
+
+
 def test_conv2d_os_identity_rows_emu(emu_ctx):
     y, ref = cases.os_identity_rows(emu_ctx)
     assert numpy.array_equal(y, ref)
@@ -221,7 +226,7 @@ def test_stage2_output_stationary_layers_emu(emu_ctx, monkeypatch):
         assert rel_max(y, y_ig) < 1e-5 and rel_max(y_ig, ref) < cases.TOL
         monkeypatch.setenv('RY_OS2', '14:0,13:1:2:8:2'); monkeypatch.delenv('RY_OS2_MAXCOST'); reread(); net.set_dtype('f32')   # forced per layer: decoder c6 off, decoder c5 on another slice
         names = {q['layer']: q['name'] for q in net.profile(1, 16, 1)}
-        assert names['decoder/c5'] == 'ry_c2d_os<1,2,8,2>' and not names['decoder/c6'].startswith('ry_c2d_os'), names
+        assert names['decoder/c5'].startswith('ry_c2d_os<1,2,8,2,') and not names['decoder/c6'].startswith('ry_c2d_os'), names
         assert rel_max(net.forward(x), ref) < cases.TOL
         monkeypatch.delenv('RY_OS2'); reread(); net.set_dtype('f32')
         assert numpy.array_equal(net.forward(x), y)
