@@ -190,6 +190,7 @@ struct LayerPlan {
     bool x3 = false;                          // PATH_IGEMM_BF16 in split-bf16 form: sources are [pixel][hi | lo], K = [hi | lo | hi] x filters [hi | hi | lo]
     bool o16x3 = false;                       // format of the out16 copy this layer writes: plain bf16 or split [hi | lo]
     float* slabs = nullptr;
+    int hole_lo = 0, hole_n = 0;              // > 0 (set per enqueue): output rows hole_lo .. hole_lo + hole_n - 1 equal row hole_lo - 1 (padding behind the real frames): not computed, copied
     int crop_hi = 0;                          // > 0 (set per enqueue, one window): the layer runs on the first crop_hi input rows only -- the rows behind them feed nothing but
                                               // output rows the convert wrapper throws away (dead padding rows, see enqueue_forward)
     int crop_lo = 0;                          // ... starting at this input row (> 0 when the caller discards the leading frames of the window too)

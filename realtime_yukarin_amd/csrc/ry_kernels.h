@@ -125,6 +125,8 @@ struct RyIgemmParams {
     int xcd_gs, xcd_gs_shift, xcd_nsg, xcd_mtg;   // LDS-DMA kernel: XCD grouping (gs slice groups of xcd_nsg slices x 8/gs M-tile groups of xcd_mtg tiles); 0 = contiguous runs
     float inv_xcd_nsg, inv_nsl; // reciprocals of xcd_nsg and of the slice count splits * ntiles * nphases
     int kq, krem;               // K chunks per split: split s takes kq + (s < krem) chunks starting at s * kq + min(s, krem)
+    int hole_ty, hole_nt;       // 2-D M-tiles: tile rows hole_ty .. hole_ty + hole_nt - 1 of every image are not computed (`trows` counts the computed ones): rows of the
+                                // padding that equal the row above them, filled in by ry_rep_rows (hole_nt = 0: none)
     int tw;                     // > 0: an M-tile is a 2-D block of (BM/tw) x tw rows of the Mh x Mw grid (compact input footprint:
                                 //      overlapping taps hit L2); 0: BM consecutive rows in raster order
     int dbg_flags;              // diagnostics of ry_igemm_ldsdma (wrong results): 4 skip the output stores, 8 skip the K loop, 128 skip the loads in the K loop
@@ -273,7 +275,8 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
             const int trow = ry_fdiv(mt, p.tcols, p.inv_tcols);              // tile row counted over the whole batch
             const int tx = mt - trow * p.tcols;
             b = ry_fdiv(trow, p.trows, p.inv_trows);
-            const int ty = trow - b * p.trows;
+            const int tyc = trow - b * p.trows;
+            const int ty = tyc + (tyc >= p.hole_ty ? p.hole_nt : 0);
             ry = ty * p.th + (r >> p.tw_shift); rx = tx * p.tw + (r & (p.tw - 1));
             live = b < g.B;
         } else if (live) {
@@ -302,7 +305,8 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
         const int trow = ry_fdiv(mt, p.tcols, p.inv_tcols);
         const int tx = mt - trow * p.tcols;
         const int bimg = ry_fdiv(trow, p.trows, p.inv_trows);
-        const int ty = trow - bimg * p.trows;
+        const int tyc = trow - bimg * p.trows;
+        const int ty = tyc + (tyc >= p.hole_ty ? p.hole_nt : 0);
         // input pixel of patch (0, 0): deconvolution: taps reach one pixel up / left of the phase; convolution: the parity-(1, 1)
         // pixel 2 * (first output row / column of the tile)
         const int oy0 = PATCH == 1 ? ty * (BM / 16) + pdy - 1 : 2 * ty * (BM / 16);
@@ -1804,6 +1808,17 @@ struct RyPadRowsParams {
     long long in_bstride, out_bstride;
     int minv_bstride;
 };
+
+// ry_rep_rows -- rows dst0 .. dst0 + nrows - 1 of every image := row src of the same image (NHWC rows of row_f4 16-byte pieces).  The convert wrapper
+// pads a window with copies of ONE row (the column minima), so behind the real frames every encoder layer computes rows that are equal bit for
+// bit; the implicit GEMM leaves the tile rows inside that stretch out (RyIgemmParams::hole_ty) and this copy fills them in.
+struct RyRepRowsParams { float* base; long long img_f4; int row_f4, src, dst0, nrows; };
+RY_KERNEL(256) void ry_rep_rows(RyRepRowsParams p) {     // grid: (pieces of a row / 256, rows to fill, images)
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= p.row_f4) return;
+    f32x4* img = reinterpret_cast<f32x4*>(p.base) + (size_t)blockIdx.z * (size_t)p.img_f4;
+    img[(size_t)(p.dst0 + (int)blockIdx.y) * p.row_f4 + i] = img[(size_t)p.src * p.row_f4 + i];
+}
 
 // ry_pad_min_rows -- ry_colmin + ry_pad_rows in one launch (one graph node less on the convert path): a workgroup owns 16
 // columns (16 row groups x 16 columns), takes their minimum over the real rows, then writes the padded / logged block.

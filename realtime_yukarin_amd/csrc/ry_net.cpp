@@ -307,6 +307,7 @@ static void tile_dims(int tile, int* bm, int* bn) {
 
 // Process-wide switches (INTEGRATION.md section 6 lists every one).  Round 3 removed the A/B switches of closed experiments (register-staged
 // kernel, 256-row tiles, burst loads, raster tiles, two-graph cut + stagger, stage-1 tuning aids, ...): their measurements are in DESIGN.md.
+static int g_s2_hole = 1;     // RY_S2_HOLE=0: the encoder computes the identical padding rows behind the real frames instead of copying them (A/B, bit-identity tests)
 static int g_s2_crop = 2;     // RY_S2_CROP=0: every decoder layer of the convert wrapper computes all padded rows (A/B of the dead-row crop, used by the bit-identity tests); 1: only grids of more than one workgroup per CU
 static int g_igemm_dbg = 0;   // RY_IGEMM_DBG: ablation bits (diagnostics; WRONG results): ry_igemm_ldsdma 4 no stores, 8 no K loop, 128 no loads in the K loop;
                               // stage-2 forward: 16 no split-K reduce launches, 32 no encoder c5 .. decoder c2 (scripts/gpu_r3_ablate.sh)
@@ -568,6 +569,14 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         p.tw = 0;
         for (int tw = 16; tw >= 4; tw >>= 1)           // 2-D M-tiles when the row grid divides evenly, else BM consecutive rows in raster order
             if (bm % tw == 0 && g.Mw % tw == 0 && g.Mh % (bm / tw) == 0) { p.tw = tw; break; }
+        p.hole_ty = 1 << 30; p.hole_nt = 0;
+        if (lp.hole_n > 0) {                            // whole tile rows inside the stretch of identical padding rows are left out (ry_rep_rows fills them in)
+            const int th = p.tw > 0 ? bm / p.tw : 0;
+            if (p.tw == 0 || l.deconv || lp.splits != 1 || lp.crop_hi > 0 || lp.hole_lo % th || lp.hole_n % th || lp.hole_lo + lp.hole_n > g.Mh)
+                return fail(RY_ESTATE, "%s: rows %d..%d cannot be left out of this launch", l.name, lp.hole_lo, lp.hole_lo + lp.hole_n - 1);
+            p.hole_ty = lp.hole_lo / th; p.hole_nt = lp.hole_n / th;
+            p.mtiles -= B * p.hole_nt * (g.Mw / p.tw);
+        }
         int patch = 0;
         {   // prologue helpers of the LDS-DMA kernel (ry_fdiv reciprocals; operands stay below 2^24, checked here)
             const int ck = bf16 ? 64 : 32, cpt = (C1 + C2) / ck, nkc = g.ntaps * cpt;
@@ -594,7 +603,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
             p.tw_shift = 0; p.th = 1; p.tcols = 1; p.trows = 1; p.inv_tcols = 1.f; p.inv_trows = 1.f;
             if (p.tw > 0) {
                 while ((1 << p.tw_shift) < p.tw) ++p.tw_shift;
-                p.th = bm / p.tw; p.tcols = g.Mw / p.tw; p.trows = g.Mh / p.th;
+                p.th = bm / p.tw; p.tcols = g.Mw / p.tw; p.trows = g.Mh / p.th - p.hole_nt;
                 p.inv_tcols = 1.f / p.tcols; p.inv_trows = 1.f / p.trows;
             }
             // sub-pixel deconvolution on 16-pixel-wide 2-D tiles: the patch variant of the kernel (K units = whole channel chunks)
@@ -647,6 +656,18 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         }
 #undef RY_IGEMM_LAUNCH
         RY_TRY(Lc.end());
+        for (int copy = 0; copy < 2 && p.hole_nt > 0; ++copy) {            // the fp32 output and / or the bf16 copy ([pixel][N] or split [pixel][hi | lo])
+            if (copy == 0 ? !lp.w32 : !lp.w16) continue;
+            const int px_bytes = copy == 0 ? 4 * l.cout : (lp.o16x3 ? 4 : 2) * l.cout;
+            RyRepRowsParams q;
+            q.base = copy == 0 ? lp.out : reinterpret_cast<float*>(lp.out16);
+            q.row_f4 = lp.Wo * px_bytes / 16; q.img_f4 = (long long)lp.Ho * q.row_f4;
+            q.src = lp.hole_lo - 1; q.dst0 = lp.hole_lo; q.nrows = lp.hole_n;
+            dim3 rg((unsigned)((q.row_f4 + 255) / 256), (unsigned)lp.hole_n, (unsigned)B);
+            RY_TRY(Lc.begin("ry_rep_rows", l.name, 0, (double)B * lp.hole_n * lp.Wo * px_bytes, rg));
+            RY_LAUNCH(ry_rep_rows, rg, 256, Lc.stream, q);
+            RY_TRY(Lc.end());
+        }
         if (lp.splits > 1 && !(g_igemm_dbg & 16)) {
             RyReduceParams r;
             const size_t ro = B == 1 ? oo : 0;                                    // one window: only the rows this launch wrote
@@ -1074,6 +1095,31 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
             else { need0 = 0; need1 = lp.Hi; }                      // this layer runs whole: it reads every row of its producer
         }
     }
+    // Stage 2, convert wrapper: rows n_frames .. T - 1 of the padded window are copies of ONE row (the column minima, ry_pad_min_rows), so down the
+    // encoder every layer has a stretch of output rows that are equal bit for bit (same operands, same order): identical input rows [a, b] give
+    // identical output rows [ceil((a + pad) / stride), floor((b - (k - 1) dil + pad) / stride)] -- at 300 of 384 frames 40 of 192 rows of encoder c1,
+    // 19 of 96 of c2.  The implicit GEMM leaves the whole tile rows inside the stretch out of its grid and ry_rep_rows copies the row above them:
+    // the MFMA time of those tiles goes to the window on the other lane (RY_S2_HOLE=0 computes them; results are bit-identical either way).
+    int hole_lo[16], hole_n[16];
+    for (int i = 0; i < 16; ++i) hole_lo[i] = hole_n[i] = 0;
+    if (nd == 2 && P.mode == 1 && g_s2_hole && P.n_frames < P.T - 2) {
+        int a = P.n_frames, b = P.T - 1;
+        for (int i = 0; i < 8; ++i) {
+            const Layer& l = net->layers[i];
+            const LayerPlan& lp = P.lp[i];
+            if (l.deconv || l.src_b >= 0 || l.src_a != i - 1) break;
+            const int top = b - (l.k - 1) * l.dil + l.pad;
+            if (top < 0) break;
+            a = (a + l.pad + l.stride - 1) / l.stride; b = top / l.stride;
+            if (b >= lp.Ho) b = lp.Ho - 1;
+            if (b - a < 1) break;
+            if ((lp.path != PATH_IGEMM && lp.path != PATH_IGEMM_BF16) || lp.splits != 1 || crop[i] > 0 || (lp.Wo * l.cout) % 8) continue;
+            int bm, bn; tile_dims(lp.tile, &bm, &bn);
+            if (bm % 16 || lp.Wo % 16 || lp.Ho % (bm / 16)) continue;
+            const int th = bm / 16, r0 = (a + 1 + th - 1) / th * th, r1 = (b + 1) / th * th;      // rows [r0, r1) are whole tile rows and copies of row r0 - 1 >= a
+            if (r1 - r0 >= th) { hole_lo[i] = r0; hole_n[i] = r1 - r0; }
+        }
+    }
     for (int i = lo; i < hi; ++i) {
         const Layer& l = net->layers[i];
         const LayerPlan& lp = P.lp[i];
@@ -1094,6 +1140,7 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
             LayerPlan lq = lp;
             if (i == 15 && (P.mode == 0 || lp.path == PATH_LAST)) lq.out = P.cur_out;   // last layer writes the caller's block
             if (i == 15 && P.mode == 1 && lp.path == PATH_LAST) { lq.last_rows = k1 - k0; lq.last_row0 = k0; lq.last_out_rows = P.n_frames; lq.flops = lp.flops * (k1 - k0) / lp.Ho; }
+            if (hole_n[i] > 0) { lq.hole_lo = hole_lo[i]; lq.hole_n = hole_n[i]; lq.flops = lp.flops * (lp.Ho - hole_n[i]) / lp.Ho; }
             if (crop[i] > 0) { lq.crop_hi = crop[i]; lq.crop_lo = crop0[i]; lq.flops = lp.flops * crop[i] / lp.Hi; lq.bytes = lp.bytes * crop[i] / lp.Hi; }
             RY_TRY(launch_conv2d(Lc, l, lq, B, s1, l.cin_a, s2, l.cin_b, slope));
         }
@@ -1355,6 +1402,8 @@ static int read_env_switches() {
     g_x3_min_m = 128; g_s2_crop = 2; g_igemm_dbg = 0;
     if (const char* e = getenv("RY_X3_MINM")) g_x3_min_m = atoi(e);
     if (const char* e = getenv("RY_S2_CROP")) g_s2_crop = atoi(e);
+    g_s2_hole = 1;
+    if (const char* e = getenv("RY_S2_HOLE")) g_s2_hole = atoi(e);
     if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);
     return read_plan_env();
 }

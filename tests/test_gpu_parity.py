@@ -229,6 +229,46 @@ def test_stage2_dead_row_crop_is_bit_identical(syn64, gpu_ctx, monkeypatch, n_fr
         reread(); n2.set_dtype('f32')
 
 
+@pytest.mark.parametrize('n_frames', [300, 100, 257, 130, 600])
+def test_stage2_identical_padding_rows_are_copied_bit_identical(syn64, gpu_ctx, monkeypatch, n_frames):
+    """Behind the real frames the padded window is copies of one row, so every encoder layer has output rows that are equal bit for bit; the implicit
+    GEMM leaves whole tile rows of that stretch out of its grid and ry_rep_rows copies the row above them (RY_S2_HOLE, default on): bit-identical to
+    the run that computes them -- launch by launch, under graph replay, three windows per call -- and the grids of encoder c1 / c2 shrink."""
+    import ctypes
+    _, (n2, _) = syn64
+    sp = synth.stage2_input(n_frames)[0]
+    reread = lambda: gpu_ctx.lib.check(gpu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    try:
+        out, out3, grids = {}, {}, {}
+        for mode in ('0', '1'):
+            monkeypatch.setenv('RY_S2_HOLE', mode); reread()
+            n2.set_dtype('f32')
+            out[mode] = n2.convert(sp)
+            out[mode + 'g'] = [n2.convert(sp) for _ in range(2)][-1]
+            out3[mode] = n2.convert(numpy.stack([sp, sp[::-1], sp]))
+            grids[mode] = {(q['layer'], q['name'].split('<')[0]): q['grid'][0] for q in n2.profile(1, n_frames, 1, window=True)}
+        for k in out:
+            assert numpy.array_equal(out[k], out['0']), (n_frames, k)
+        assert numpy.array_equal(out3['0'], out3['1'])
+        assert not [k for k in grids['0'] if k[1] == 'ry_rep_rows']
+        for dtype in ('bf16x3', 'bf16'):          # the bf16 pipes: the copies the consumers read ([pixel][N] bf16, split [pixel][hi | lo]) are filled in too
+            o16 = {}
+            for mode in ('0', '1'):
+                monkeypatch.setenv('RY_S2_HOLE', mode); reread()
+                n2.set_dtype(dtype)
+                o16[mode] = n2.convert(sp)
+                if n_frames == 300 and mode == '1':
+                    assert [q for q in n2.profile(1, n_frames, 1, window=True) if q['name'] == 'ry_rep_rows'], dtype
+            assert numpy.array_equal(o16['0'], o16['1']), (n_frames, dtype)
+        if n_frames == 300:             # 40 of 192 rows of encoder c1 are identical: five tile rows of six rows (30 rows) go; 19 of 96 of c2: two tile rows
+            assert grids['1'][('encoder/c1', 'ry_rep_rows')] > 0 and grids['1'][('encoder/c2', 'ry_rep_rows')] > 0
+            assert grids['1'][('encoder/c1', 'ry_igemm_ldsdma')] == 432 and grids['0'][('encoder/c1', 'ry_igemm_ldsdma')] == 512
+            assert grids['1'][('encoder/c2', 'ry_igemm_ldsdma')] == 224 and grids['0'][('encoder/c2', 'ry_igemm_ldsdma')] == 256
+    finally:
+        monkeypatch.delenv('RY_S2_HOLE', raising=False)
+        reread(); n2.set_dtype('f32')
+
+
 @pytest.mark.parametrize('n_frames,discard', [(300, (100, 100)), (300, (0, 37)), (300, (150, 0)), (100, (20, 20)), (600, (200, 200)), (257, (1, 1))])
 def test_stage2_discarded_frames_are_not_computed(syn64, n_frames, discard):
     """`ry_sr_convert_rows` (the frames a caller like ConvertStream.process throws away are announced): kept rows bit-identical to the full

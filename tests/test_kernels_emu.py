@@ -201,6 +201,34 @@ def test_stage2_x3_pipeline_emu(emu_ctx, monkeypatch):
     net.close()
 
 
+def test_stage2_identical_padding_rows_emu(emu_ctx, monkeypatch):
+    """The encoder's rows behind the real frames that equal the row above them are copied, not computed (RY_S2_HOLE): split-free implicit-GEMM layers
+    leave whole tile rows out of their grids; bit-identical to computing them, also around a discard and for two windows per call."""
+    import ctypes
+    reread = lambda: emu_ctx.lib.check(emu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    d = NetDesc(2, 1, 1, 64, 3)
+    P = synthetic_params(d, 451, bias_std=0.05)
+    sp = numpy.exp(numpy.random.default_rng(72).normal(-6.0, 1.5, (70, 65))).astype('f4')
+    try:
+        monkeypatch.setenv('RY_PLAN', '1:3:1:1,2:4:1:1'); reread()          # encoder c1 / c2 without split-K (as at full size), 64- and 32-row tiles
+        net = engine.Net(emu_ctx, d, flatten_params(d, P), width=64)
+        y1 = net.convert(sp)
+        reps = [q for q in net.profile(1, 70, 1, window=True) if q['name'] == 'ry_rep_rows']
+        assert {q['layer'] for q in reps} == {'encoder/c1', 'encoder/c2'}, reps
+        assert float(numpy.abs(y1 / unet.stage2_convert(sp, P, 3) - 1).max()) < cases.TOL
+        part = net.convert(sp, discard=(20, 30))
+        two = net.convert(numpy.stack([sp, sp[::-1]]))
+        monkeypatch.setenv('RY_S2_HOLE', '0'); reread(); net.set_dtype('f32')
+        assert not [q for q in net.profile(1, 70, 1, window=True) if q['name'] == 'ry_rep_rows']
+        y0 = net.convert(sp)
+        assert numpy.array_equal(y0, y1)
+        assert numpy.array_equal(part[20:40], y0[20:40])
+        assert numpy.array_equal(net.convert(numpy.stack([sp, sp[::-1]])), two)
+        net.close()
+    finally:
+        monkeypatch.delenv('RY_S2_HOLE', raising=False); monkeypatch.delenv('RY_PLAN', raising=False); reread()
+
+
 def test_stage2_output_stationary_layers_emu(emu_ctx, monkeypatch):
     """Round 5: layers with few rows per phase and the ry_c2d_os filter layout run output-stationary (PATH_OS2D: one node, no slabs) inside the
     predictor -- k4 s2 convolutions, sub-pixel deconvolutions over a two-source skip concat -- next to implicit-GEMM neighbours, in the
