@@ -126,7 +126,9 @@ def rocprof_table():
             except (ValueError, IndexError):
                 continue
             tab[name.replace('void ', '').replace(' ', '')] = avg
-        return tab, Path(path).name
+        import re
+        m = re.search(r'box (\S+) (\d{4}-\d\d-\d\d)', lines[0])          # where and when the summary was measured (scripts/gpu_r5_profile.sh)
+        return tab, Path(path).name + (' [measured on box %s, %s]' % m.groups() if m else '')
     return {}, None
 
 
@@ -764,7 +766,7 @@ def main(argv=None):
             ach = dv['flops'] / dv['launches'] / (rp_us * 1e-6) / 1e12
         out['roofline'] = {'kernel': dname, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                            'frac': round(ach / peak_tf, 4),
-                           'frac_source': ('%s: avg %.3f us per launch (rocprofv3 --kernel-trace --stats, one window at a time)' % (rpf_file, rp_us)) if rp_us
+                           'frac_source': ('%s: avg %.3f us per launch (rocprofv3 --kernel-trace --stats, one window at a time); this run: box %s, %s, frac_events' % (rpf_file, rp_us, os.uname().nodename, time.strftime('%Y-%m-%d', time.gmtime()))) if rp_us
                                           else 'HIP events of this run (no rocprofv3 summary of source %s under profiles/)' % source_hash(),
                            'achieved_events': round(ach_ev, 2), 'frac_events': round(ach_ev / peak_tf, 4),      # HIP events around every launch, THIS run
                            'frac_rocprof': round(ach / peak_tf, 4) if rp_us else None,                         # committed rocprofv3 summary of the same source
