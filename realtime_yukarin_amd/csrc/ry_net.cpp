@@ -391,7 +391,10 @@ static int best_split(long blocks, int bm, int bn, int nk, bool tinyM, int occ, 
     return best;
 }
 
+static int g_kg_slabs = 1;    // RY_KG_SLABS=0: the lone-time pick between two K groups per workgroup and an external split only stands even on a near-tie (A/B)
+
 static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits, int* kg, int bf16 = 0 /* 1 bf16, 2 split-bf16 */) {
+    const bool kg_auto = *kg == 0, splits_auto = *splits == 0;
     // bf16: 64 channels per chunk; the kernel is bound by the operand movement, not the matrix pipe: price
     // the main loop at the measured rate so that the fixed costs (launch, stores, slabs) weigh as they do in the measurements
     g_plan_peak = bf16 == 2 ? g_x3_peak : bf16 ? 0.86e9 : 157.3e6; g_plan_ck = bf16 ? 64 : 32;   // 128x128 bf16 tiles measured ~620 TF = 0.72 x 860
@@ -437,6 +440,17 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
         }
     }
     if (*splits == 0) *splits = best_split(blocks, bm, bn, nk, M <= 64, tile_occ(*tile, *kg), *kg, M, N, nullptr);
+    // Two K groups in one workgroup (8 waves, 125 KiB of LDS: nothing else fits beside it on a CU) exist to save slabs and reduce work.  Where the plan
+    // needs an external split anyway and the external-split-only form (four-wave workgroups of 62 KiB: two of ANY two launches share a CU, which is what
+    // the window on the other lane needs) is estimated within one per cent, take that form: a tie alone, and measured under two lanes (round 5,
+    // profiles/r05_r_plan_ab_n300.txt) decoder c3 -- the one layer this selects at 300 frames -- moves the step 1.1015 -> 1.0767 ms per window and ends
+    // the bimodal phase lock of the lanes; encoder c4 / c5 and decoder c2 (4 - 12 % apart by the estimate) gain nothing and stay.
+    if (g_kg_slabs && kg_auto && splits_auto && bf16 == 0 && *kg == 2 && *splits > 1 && M > 64) {
+        double t1 = 0.0;
+        const int s1 = best_split(blocks, bm, bn, nk, false, tile_occ(*tile, 1), 1, M, N, &t1);
+        const double t2 = est_time(blocks, bm, bn, *splits, tile_occ(*tile, 2), 2, M, N, nk);
+        if (t1 <= 1.01 * t2) { *kg = 1; *splits = s1; }
+    }
     if (*splits * *kg > nk) { *kg = 1; if (*splits > nk) *splits = nk; }
 }
 
@@ -1404,6 +1418,8 @@ static int read_env_switches() {
     if (const char* e = getenv("RY_S2_CROP")) g_s2_crop = atoi(e);
     g_s2_hole = 1;
     if (const char* e = getenv("RY_S2_HOLE")) g_s2_hole = atoi(e);
+    g_kg_slabs = 1;
+    if (const char* e = getenv("RY_KG_SLABS")) g_kg_slabs = atoi(e);
     if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);
     return read_plan_env();
 }

@@ -41,10 +41,19 @@ def say(s):
     lines.append(s + '\n'); print(s, flush=True)
 
 
+ENV_KEYS = set()
+
+
 def setup(plan):
-    if plan == '-':
-        os.environ.pop('RY_PLAN', None)
-    else:
+    """'-': the planner's picks; 'env:K=V[,K=V]': the planner's picks under these switches; else an RY_PLAN string"""
+    for k in ENV_KEYS:
+        os.environ.pop(k, None)
+    os.environ.pop('RY_PLAN', None)
+    if plan.startswith('env:'):
+        for kv in plan[4:].split(','):
+            k, v = kv.split('=')
+            os.environ[k] = v; ENV_KEYS.add(k)
+    elif plan != '-':
         os.environ['RY_PLAN'] = plan
     reread(); n2.set_dtype('f32')
 
@@ -94,7 +103,7 @@ for p in PLANS:
     say('# median  %-60s forward alone %.4f ms   two-lane step %.4f ms' % (p, numpy.median(a[:, 0]), numpy.median(a[:, 1])))
     setup(p)
     for q in n2.profile(1, N, 5, window=True):
-        if q['name'].startswith('ry_igemm') and q['ms'] > 0.04:
+        if q['name'].startswith('ry_igemm') and q['ms'] > 0.02:
             say('#     %-11s %-44s grid=%-5d %7.2f us' % (q['layer'], q['name'], q['grid'][0], q['ms'] * 1e3))
 Path(OUT).parent.mkdir(parents=True, exist_ok=True)
 Path(OUT).write_text(''.join(lines))
