@@ -140,6 +140,29 @@ def test_output_stationary_planner_follows_the_measured_ranking(lib):
     assert f(12, 512, 1, 6, ctypes.byref(a), ctypes.byref(b), ctypes.byref(w), ctypes.byref(d), None) != 0      # 6 units: no whole rounds of four per wave
 
 
+def test_stage2_planner_near_tie_goes_to_the_small_workgroup(lib, monkeypatch):
+    """Round 5: where slabs are needed anyway, two K groups per workgroup (125 KiB of LDS: nothing fits beside it on a CU) must beat the external-split-only
+    form (62 KiB) by more than 1 % of the estimate.  At 300 / 400 frames that is decoder c3 (768 / 1024 rows per phase, 512 channels, 128 K chunks);
+    encoder c4 / c5 and decoder c2 are 4 - 12 % apart and keep two K groups; RY_KG_SLABS=0 restores the lone-time pick (profiles/r05_r_plan_ab_n300.txt)."""
+    def plan(M, N, nph, nk):
+        t, s, k, e = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        lib.check(lib.dll.ry_debug_plan_igemm(M, N, nph, nk, ctypes.byref(t), ctypes.byref(s), ctypes.byref(k), ctypes.byref(e)))
+        return t.value, s.value, k.value, e.value
+    d3, c4, c5, d2 = (768, 512, 4, 128), (1536, 512, 1, 256), (384, 512, 1, 256), (192, 512, 4, 128)
+    try:
+        monkeypatch.setenv('RY_KG_SLABS', '0')
+        old = {n: plan(*sh) for n, sh in (('d3', d3), ('c4', c4), ('c5', c5), ('d2', d2))}
+        assert all(v[2] == 2 and v[1] > 1 for v in old.values()), old
+        monkeypatch.delenv('RY_KG_SLABS')
+        new = {n: plan(*sh) for n, sh in (('d3', d3), ('c4', c4), ('c5', c5), ('d2', d2))}
+        assert new['d3'][2] == 1 and new['d3'][1] == 2 * old['d3'][1] and new['d3'][3] <= 1.01 * old['d3'][3], (old, new)
+        assert plan(1024, 512, 4, 128)[2] == 1                       # the same layer at 400 frames
+        assert all(new[n][:3] == old[n][:3] for n in ('c4', 'c5', 'd2')), (old, new)
+    finally:
+        monkeypatch.delenv('RY_KG_SLABS', raising=False)
+        plan(*d3)
+
+
 def test_stage2_planner_rejects_non_igemm_shapes(lib):
     t, s, k = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.dll.ry_debug_plan_igemm(100, 48, 1, 8, ctypes.byref(t), ctypes.byref(s), ctypes.byref(k), None) != 0
