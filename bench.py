@@ -53,7 +53,7 @@ def parse(argv=None):
     ap.add_argument('--lanes', type=int, default=None, help='windows that run side by side on their own predictor streams (ry_vc_set_lanes; default RY_VC_LANES or 2)')
     ap.add_argument('--model', default=None)
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'bf16x3'],
-                    help="stage-2 MFMA operand type ('bf16' = BASELINE config #5; 'bf16x3' = split-bf16, DESIGN.md 4.7); the headline is f32")
+                    help="stage-2 MFMA operand type ('bf16' = BASELINE config #5; 'bf16x3' = split-bf16, DESIGN.md 5.1); the headline is f32")
     ap.add_argument('--comm', default='torch', choices=['torch', 'native'], help='transport of the weight broadcast / barrier when N > 1')
     ap.add_argument('--force-dist', action='store_true', help='run the N > 1 code path with one rank (real RCCL init on one GPU)')
     ap.add_argument('--emulator', action='store_true', help='TESTS ONLY: emulator build of the kernels on the CPU, gloo; numbers are meaningless')

@@ -79,7 +79,7 @@ int ry_net_clone(ry_net* net, ry_net** out);
  * bf16 activations between those layers; filters converted once).  dtype 2 ("split-bf16") runs them as three bf16 products per fp32
  * product -- x = hi + lo, w = hi + lo, x w ~ hi hi + lo hi + hi lo -- on the same instruction with fp32 accumulation: results agree
  * with the fp32 path to ~2e-6 (inside the 1e-4 parity bar) at 3/16 of the matrix-pipe time.  dtype 0 (default) is exact fp32.
- * Tolerances: DESIGN.md 4.6 / 4.7. */
+ * Tolerances: DESIGN.md 5.1 (bf16, split-bf16). */
 int ry_net_set_dtype(ry_net* net, int dtype);
 
 /* `Predictor.__call__` / `SRPredictor.__call__` on an already padded block (frames % 128 == 0 when

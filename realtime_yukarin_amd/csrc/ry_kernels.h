@@ -13,7 +13,11 @@
 //                       patches shared by the taps (PATCH), split-K inside the workgroup (KG), folded BN + activation
 //                       epilogue with 16-byte stores, optional split-K slabs; tiles 128x128 / 96x128 / 128x64 / 64x128 / 32x128
 //                       (the bf16 form also runs the split-bf16 mode: sources [pixel][hi | lo], K axis [hi | lo | hi] against
-//                       filters [w_hi | w_hi | w_lo] = three bf16 products per fp32 product, fp32 accumulate -- DESIGN.md 4.7)
+//                       filters [w_hi | w_hi | w_lo] = three bf16 products per fp32 product, fp32 accumulate -- DESIGN.md 5.1)
+//                       (a hole of whole tile rows can be left out of the grid: the encoder's padding rows that equal the row above, copied by ry_rep_rows)
+//   ry_c2d_os           stage-2 layers with a handful of output pixels and megabytes of filters, output-stationary on v_mfma_f32_4x4x1_16B_f32
+//                       (sixteen K positions per instruction): one node per layer, no slabs; pixels by LDS-DMA with explicit waits
+//   ry_c1d_os           stage-1 layer, output-stationary: lanes over the input channels, every load before the first FMA, DPP reduce-scatter
 //   ry_splitk_reduce    sum of split-K slabs + folded BN + activation
 //   ry_sr_first / ry_sr_last   the 1 -> N and C -> 1 3x3 end layers of stage 2 (HBM / L2-bound)
 //   ry_conv_direct      generic VALU conv (odd channel counts)
@@ -69,7 +73,7 @@ RY_DEV void ry_st4_bf16(unsigned short* q, f32x4 v) {
 RY_DEV float ry_bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 // Split-bf16 copy of four channels n .. n + 3 of pixel `pix` (N channels): the pixel keeps [hi (N) | lo (N)] with
 // hi = bf16(v), lo = bf16(v - hi) (both RNE; v - hi is exact in fp32), so that hi + lo carries 16 mantissa bits of v.
-// The implicit GEMM then runs hi*hi + lo*hi + hi*lo on the bf16 matrix pipe with fp32 accumulation.
+// The implicit GEMM then runs hi*hi + lo*hi + hi*lo on the bf16 matrix pipe with fp32 accumulation (split-bf16).
 RY_DEV void ry_st4_bf16_x3(unsigned short* base, size_t pix, int N, int n, f32x4 v) {
     u16x4 h, l;
 #pragma unroll
@@ -133,7 +137,7 @@ struct RyIgemmParams {
 };
 
 // ---------------------------------------------------------------------------------------------
-// ry_igemm_ldsdma<BM, BN, WM, WN, KG, BF16, PATCH> -- the stage-2 implicit GEMM (DESIGN.md 4.1 has the measurements behind
+// ry_igemm_ldsdma<BM, BN, WM, WN, KG, BF16, PATCH> -- the stage-2 implicit GEMM (DESIGN.md 5.1 and section 9 have the measurements behind
 // every choice below).
 //   BF16 = false: fp32 operands, v_mfma_f32_32x32x2_f32, 32 input channels per K chunk (exact fp32: the headline path);
 //   BF16 = true:  bf16 activations and filters, v_mfma_f32_32x32x16_bf16, 64 channels per chunk (BASELINE config #5).
@@ -750,7 +754,7 @@ RY_KERNEL(256) void ry_splitk_reduce_wide(RyReduceParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// ry_c2d_os<MT4, NT4, WAVES, DEPTH> -- stage-2 layer, OUTPUT-STATIONARY form for the weight-streaming bottom of the U-Net (round 5).
+// ry_c2d_os<MT4, NT4, WAVES, DEPTH, XL> -- stage-2 layer, OUTPUT-STATIONARY form for the weight-streaming bottom of the U-Net (round 5).
 // A layer with a handful of output pixels (encoder c6 / c7, decoder c0 / c1 at 300 frames: 12-48 pixels against 16.8-33.5 MB of filters)
 // is a stream of filters with a little arithmetic attached.  The implicit GEMM above can only fill the chip with it by cutting K over
 // hundreds of workgroups: two chunks each -- all prologue and epilogue -- then raw slabs and a reduce launch of equal length.  Here a
@@ -761,8 +765,8 @@ RY_KERNEL(256) void ry_splitk_reduce_wide(RyReduceParams p) {
 // whose tile can be as small as 4 x 4 (the 32 x 32 form needs 32 output channels per workgroup, i.e. 16 workgroups for 512 channels).
 //   K units of 64 input channels x one tap are dealt to the WAVES waves of the workgroup in contiguous runs; every wave streams its
 //   filters ([phase][N / 4][tap][C / 64][lane][4]: one contiguous KiB per (4 channels, unit), consecutive units consecutive) and its
-//   activations (NHWC, out-of-image taps read the zero pixel behind the buffer) straight into registers through a ring of DEPTH
-//   units in flight, no LDS, no barrier in the K loop;
+//   activations (NHWC, out-of-image taps read the zero pixel behind the buffer) through a ring of DEPTH units in flight -- straight into
+//   registers, or (XL, described at the template) by DMA through a wave-private LDS slot with explicit waits --, no barrier in the K loop;
 //   then: reduce-scatter over the sixteen blocks (lane bits 2-5: DPP inside a row of 16, ds_bpermute across), a fixed-order sum over
 //   the waves through the LDS, folded BN + activation, dense store.
 // The host guarantees (launch_c2d_os): C1, C2 multiples of 256 (a round of four units never straddles a source), N a multiple of 4 NT4,

@@ -316,7 +316,7 @@ static int g_x3_min_m = 128;  // RY_X3_MINM: split-bf16 mode runs a layer on the
 static int g_autotune = 0;    // RY_AUTOTUNE="1[:reps[:max[:pick]]]": time candidate launch plans of every stage-2 implicit-GEMM layer on the device when a plan is built (autotune_plan)
 static int g_autotune_reps = 3, g_autotune_max = 0;   // ... timed rounds per candidate; cap on the candidates per layer (0 = all; tests)
 static int g_autotune_pick = -1;                      // ... (tests only) take candidate `pick` of every layer instead of the fastest
-static const int g_patch = 3;      // bit 0 = input-patch reuse in the deconvolution layers, bit 1 = in the k4 s2 convolution layers (A/B measured, both on)
+static const int g_patch = 3;      // bit 0 = input-patch reuse in the deconvolution layers, bit 1 = in the k4 s2 convolution layers (DESIGN.md 5.1 + section 9: A/B measured, both on)
 
 // Kernel names as rocprofv3 prints them (template arguments, no spaces): bench.py matches them against profiles/*.
 static const char* tile_name(int tile, int kg, bool bf16, int patch) {
@@ -395,7 +395,7 @@ static int g_kg_slabs = 1;    // RY_KG_SLABS=0: the lone-time pick between two K
 
 static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits, int* kg, int bf16 = 0 /* 1 bf16, 2 split-bf16 */) {
     const bool kg_auto = *kg == 0, splits_auto = *splits == 0;
-    // bf16: 64 channels per chunk; the kernel is bound by the operand movement, not the matrix pipe (DESIGN.md 4.6): price
+    // bf16: 64 channels per chunk; the kernel is bound by the operand movement, not the matrix pipe (DESIGN.md 5.1, bf16): price
     // the main loop at the measured rate so that the fixed costs (launch, stores, slabs) weigh as they do in the measurements
     g_plan_peak = bf16 == 2 ? g_x3_peak : bf16 ? 0.86e9 : 157.3e6; g_plan_ck = bf16 ? 64 : 32;   // 128x128 bf16 tiles measured ~620 TF = 0.72 x 860
     g_plan_kg2 = bf16 == 2 ? g_x3_kg2 : 1.0;
@@ -726,7 +726,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         dim3 grid((unsigned)((total + 7) / 8));
         if (C1 + C2 == 128 && lp.Wi % 16 == 0) {
             const long long strips = (long long)B * p.rows_valid * (lp.Wi / 16);
-            p.xcd_band = 1;                                   // every XCD owns a contiguous band of output rows (DESIGN.md 4.2: 45.0 -> 31.5 us against raster order)
+            p.xcd_band = 1;                                   // every XCD owns a contiguous band of output rows (DESIGN.md section 9, round 2: 45.0 -> 31.5 us against raster order)
             const long long nb = (strips + 7) / 8;
             dim3 sg((unsigned)(((nb + 7) / 8) * 8));
             RY_TRY(Lc.begin("ry_sr_last<false>", l.name, lp.flops, lp.bytes, sg));

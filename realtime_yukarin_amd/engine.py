@@ -133,7 +133,7 @@ class VcCore(object):
         self._pending = {}
         self.discard = (0, 0)
         # lanes: the six ring slots spread over two pairs of predictor handles (`ry_vc_set_lanes`), so that two windows really run side by side
-        # (RY_VC_LANES=1: one stage-2 forward after the other; 3 measured slower than 2, DESIGN.md 4.5)
+        # (RY_VC_LANES=1: one stage-2 forward after the other; 3 measured slower than 2, DESIGN.md 5.5)
         self.lanes = int(os.environ.get('RY_VC_LANES', '2')) if lanes is None else int(lanes)
         if self.lanes != 1:
             self.set_lanes(self.lanes)
@@ -372,7 +372,7 @@ class Net(object):
     def set_dtype(self, dtype: str):
         """'f32' (exact fp32 MFMA, default), 'bf16' (stage-2 only: bf16 operands, fp32 accumulate -- BASELINE config #5) or
         'bf16x3' (stage-2 only: every fp32 product as three bf16 products hi*hi + lo*hi + hi*lo on the bf16 matrix pipe, fp32
-        accumulate -- fp32-class results, DESIGN.md 4.7)."""
+        accumulate -- fp32-class results, DESIGN.md 5.1)."""
         self.ctx.lib.check(self.ctx.lib.dll.ry_net_set_dtype(self.handle, {'f32': 0, 'bf16': 1, 'bf16x3': 2}[dtype]))
 
     def close(self):

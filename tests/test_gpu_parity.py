@@ -204,7 +204,7 @@ def test_stage2_syn64_convert(syn64, n_frames):
 @pytest.mark.parametrize('n_frames', [300, 100, 257, 383, 600])
 def test_stage2_dead_row_crop_is_bit_identical(syn64, gpu_ctx, monkeypatch, n_frames):
     """Decoder layers of a single padded window skip the rows that only feed the padding `SuperResolution.convert` crops away
-    (DESIGN.md 4.1b): every kept element must be bit-identical to the run that computes all padded rows, whichever layers are cropped
+    (DESIGN.md 5.1): every kept element must be bit-identical to the run that computes all padded rows, whichever layers are cropped
     (1 = only the layers it speeds up by themselves; 2 = every decoder layer the rule allows, the default)."""
     import ctypes
     _, (n2, _) = syn64
