@@ -775,6 +775,14 @@ def main(argv=None):
                            'traffic_source': pmc_file, 'source_hash': source_hash(),
                            'launches': dv['launches'], 'avg_launch_ms': round(dv['ms'] / dv['launches'], 4),
                            'alg_flops_per_launch': dv['flops'] / dv['launches'], 'alg_bytes_per_launch': dv['bytes'] / dv['launches']}
+        # the other MFMA-bound families of the forward, same arithmetic (rocprofv3 average of this source where there is one, else this run's HIP events):
+        # which family carries the most time can change with the plans (round 5: decoder c3 moved from the <..,2,false,1> to the <..,1,false,1> family)
+        others = {}
+        for k, v in sorted(((k, v) for k, v in fam.items() if k in st2_names and k != dname and k.startswith('ry_igemm_ldsdma<') and v['flops'] > 0),
+                           key=lambda kv: -kv[1]['ms'])[:4]:
+            us = rpf.get(k.replace(' ', '')) or v['ms'] / v['launches'] * 1e3
+            others[k] = {'launches': v['launches'], 'avg_launch_us': round(us, 2), 'frac': round(v['flops'] / v['launches'] / (us * 1e-6) / 1e12 / peak_tf, 4)}
+        out['roofline']['other_families'] = others
         if args.dtype == 'bf16x3' and is_bf16:
             out['roofline']['mfma_flops_per_alg_flop'] = 3
         alg2 = net_flops(d2, T, synth.FFT_BINS - 1)
@@ -842,7 +850,7 @@ def compact_line(out, details):
     if 'roofline' in out:
         line['roofline'] = pick(out['roofline'], ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_source', 'frac_events', 'frac_rocprof',
                                                   'traffic', 'traffic_source', 'source_hash', 'launches', 'avg_launch_ms', 'alg_flops_per_launch',
-                                                  'alg_bytes_per_launch', 'mfma_flops_per_alg_flop'))
+                                                  'alg_bytes_per_launch', 'mfma_flops_per_alg_flop', 'other_families'))
     if 'roofline_stage2_forward' in out:
         line['roofline_stage2_forward'] = pick(out['roofline_stage2_forward'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'executed_gflop', 'padded_forward_gflop'))
     if 'roofline_stage1' in out:
