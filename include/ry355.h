@@ -212,6 +212,7 @@ typedef struct ry_kernel_stat {
     double flops;           /* algorithmic FLOPs of this launch */
     double bytes;           /* algorithmic bytes: weights + input + output once */
     int grid[3];
+    double flops_exec;      /* matrix-pipe FLOPs the launch executes: = flops, except 9 / 16 of it for the Winograd F(2x2, 2x2) kernels */
 } ry_kernel_stat;
 /* Runs the forward `reps` times launch by launch, bracketing every kernel with HIP events. */
 int ry_net_profile(ry_net* net, int batch, int frames, int reps, ry_kernel_stat* stats, int max_stats, int* n_stats);
@@ -222,6 +223,10 @@ int ry_net_profile_window(ry_net* net, int n_frames, int reps, ry_kernel_stat* s
 /* diagnostics: ratio[i * n + j] = wall time of a `us`-microsecond spin kernel on each of two fresh streams i and j, divided by `us`:
  * ~1 when the two streams run side by side, ~2 when one waits for the other (scripts/gpu_queues.py). */
 int ry_debug_stream_overlap(ry_ctx* ctx, int n, int us, float* ratio);
+
+/* diagnostics / tests: read the process-wide RY_* environment switches again (otherwise read by ry_init).  Launch plans
+ * that exist keep their choices until ry_net_set_dtype drops them. */
+int ry_debug_reload_env(void);
 
 /* diagnostics: the launch configuration the stage-2 planner picks for an implicit-GEMM layer with M output rows (pixels of
  * one sub-pixel phase), Cout output channels, `nphases` phases (4 for the k4s2 deconvolution, else 1) and K = 32 * nk:

@@ -135,6 +135,7 @@ struct Arena {
         for (void* q : bufs) rt::dfree(q);
         bufs.clear();
     }
+    std::map<int, float*> lazy;          // filter layouts built on first use (key = layer index): shared by the clones of a predictor like everything in this arena
     void free_one(void* q) {               // a buffer that is being replaced by a larger one
         for (size_t i = 0; i < bufs.size(); ++i)
             if (bufs[i] == q) { rt::dfree(q); bufs.erase(bufs.begin() + (long)i); return; }
@@ -162,13 +163,15 @@ struct Layer {
     float* wdir = nullptr;               // stage-2 direct [phase][tap][Ctot][N]
     float* wig16 = nullptr;              // stage-2 implicit-GEMM bf16 blocks [phase][N/64][tap][Ctot/64][fragment order], see wig16_inblock() (ry_net_set_dtype)
     float* w2os = nullptr;               // stage-2 output-stationary kernel ry_c2d_os: [phase][N/4][tap][Ctot/64][lane][4], see relayout_c2d_os() (the weight-streaming layers only)
+    float* wwin = nullptr;               // stage-2 Winograd F(2x2, 2x2) filters [phase][N/64][slice of 8 channels][position 9][n/32][lane][4], see relayout_wino() (op-level calls; predictors: Arena::lazy)
     float* wigx3 = nullptr;              // split-bf16 blocks [phase][N/64][tap][3 Ctot/64][fragment order]: K runs over [hi | hi | lo] per source, see build_wigx3()
     int cin() const { return cin_a + cin_b; }
 };
 
 enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4, PATH_IGEMM_BF16 = 5,
        PATH_IGEMM_X3 = 6,     // op-level selector only (ry_conv2d): runs as PATH_IGEMM_BF16 with LayerPlan::x3
-       PATH_OS2D = 7 };       // output-stationary weight-streaming layer (ry_c2d_os): one node, no slabs
+       PATH_OS2D = 7,         // output-stationary weight-streaming layer (ry_c2d_os): one node, no slabs
+       PATH_WINO = 8 };       // k4 s2 p1 layer in Winograd F(2x2, 2x2) form on the fp32 matrix pipe (ry_wino_ldsdma): 9 / 16 of the direct form's MFMA work
 enum { TILE_128x128 = 1, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5, TILE_96x128 = 6 };   // (2 and 7 were the 256-row tiles of the register-staged kernel, removed in round 3)
 
 struct LayerPlan {
@@ -183,6 +186,7 @@ struct LayerPlan {
     int path = 0, tile = 0;
     bool any_m_patch = false;                 // op-level calls (tests): take the input-patch variants whatever the row count
     int os2_mt4 = 0, os2_nt4 = 0, os2_waves = 0, os2_depth = 0;   // PATH_OS2D: tile of 4 mt4 pixels x 4 nt4 channels per workgroup, waves that share the K axis, units in flight per wave
+    int wino_cfg = 0, wino_mbw = 0;           // PATH_WINO: workgroup shape (1 = 2 x 2 waves, one 8-channel slice per iteration; 2 = 4 x 2 waves, two slices) and M-blocks per tile row
     int kg = 1;                               // K groups inside a workgroup (LDS-DMA implicit GEMM): 2 = split-K summed through the LDS
     float* out = nullptr;                     // NHWC activation, fp32
     unsigned short* out16 = nullptr;          // NHWC activation, bf16 copy for consumers on the bf16 path (bf16 / split-bf16 mode only)
@@ -197,6 +201,7 @@ struct LayerPlan {
     int last_rows = 0, last_cols = 0, last_exp = 0;   // PATH_LAST: fused exp / edge-pad / crop
     int last_row0 = 0, last_out_rows = 0;     // PATH_LAST: first output row computed, rows per image of the caller's block (0: last_rows)
     double flops = 0, bytes = 0;
+    double flops_exec = 0;                    // MFMA flops the launch executes when they differ from the algorithmic ones (Winograd: 9 / 16); 0 = the same
 };
 
 struct Plan {
@@ -227,7 +232,7 @@ struct Plan {
 
 struct KernelRec {           // filled by the launch helpers when profiling
     std::string name, layer;
-    double flops, bytes;
+    double flops, bytes, flops_exec;
     int grid[3];
 };
 
@@ -263,9 +268,9 @@ struct Launcher {
     std::vector<KernelRec>* rec;
     std::vector<std::pair<rt::Event, rt::Event>>* ev;
 
-    int begin(const char* name, const char* layer, double flops, double bytes, dim3 grid) {
+    int begin(const char* name, const char* layer, double flops, double bytes, dim3 grid, double flops_exec = 0) {
         if (rec) {
-            KernelRec r; r.name = name; r.layer = layer; r.flops = flops; r.bytes = bytes;
+            KernelRec r; r.name = name; r.layer = layer; r.flops = flops; r.bytes = bytes; r.flops_exec = flops_exec > 0 ? flops_exec : flops;
             r.grid[0] = (int)grid.x; r.grid[1] = (int)grid.y; r.grid[2] = (int)grid.z;
             rec->push_back(r);
         }

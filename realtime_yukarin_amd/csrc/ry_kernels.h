@@ -672,6 +672,306 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ry_wino_ldsdma<WM, WN, NSL, MODE> -- the MFMA-bound stage-2 layers in Winograd F(2x2, 2x2) form (round 6).
+// Every k4 s2 p1 layer of the U-Net is a sum of 2 x 2-tap stride-1 stencils: a transposed convolution is four sub-pixel phases of one
+// each (MODE 1: output (2 ry + pdy, 2 rx + pdx) = sum_{a,b} in[ry + pdy - 1 + a][rx + pdx - 1 + b] g_phase[a][b]), a convolution is four
+// input-parity planes P_rc[y][x] = in[2 y - 1 + r][2 x - 1 + c] summed (MODE 2: out[oy][ox] = sum_{r,c} sum_{a,b} P_rc[oy + a][ox + b] W[2 a + r][2 b + c]).
+// F(2x2, 2x2) computes a 2 x 2 block of such a stencil's outputs from its 3 x 3 inputs with 9 products instead of 16:
+//   V = B^T d B   (rows, then columns: [d0 - d1, d1, d2 - d1]),   U = G g G^T ([g0, g0 + g1, g1], in float64 on the host, rounded once),
+//   M_p = sum over channels (and parities) of V_p U_p for the nine positions p,   Y = A^T M A ([m0 + m1, m1 + m2]).
+// -44 % of the matrix-pipe time of the direct form for fp32-class results (measured 3e-7 against 1e-7 of the direct kernel, float64 reference).
+// Mapping: an M-block is 4 x 8 Winograd tiles (8 x 16 pixels of the stencil's output grid) = the 32 rows of ONE v_mfma_f32_32x32x2_f32 per
+// position; a wave owns one M-block x 32 output channels x 9 positions = 144 accumulator registers, all nine blocks of a lane hold the same
+// (tile, channel), so the output transform is per-lane adds.  A workgroup is WM x WN waves: (WM / mbw) x mbw M-blocks by 32 WN channels.
+// K loop, one iteration = NSL slices of 8 input channels, all nine positions:
+//   A: the raw input patch ((2 TTH + 1) x (2 TTW + 1) pixels, 16 channels = two slices) goes global -> LDS by DMA, double-buffered; a lane
+//      reads the 3 x 3 pixels of its tile (nine ds_read_b128 = 4 channels each) and transforms them in registers (12 float4 subtractions).
+//      Patch pixel (py, px) sits at position py * PW + (even columns first, then odd) with its four 16-byte slots XOR-ed by (py >> 1) & 3:
+//      the nine fragment reads are bank-conflict free (the lanes of a tile row read consecutive positions).
+//   B: the transformed filters, stored by the host as [phase][N / 32 WN][slice][position][n / 32][lane][4] = one contiguous 9 WN KiB run per
+//      iteration and slice in fragment order, double-buffered.
+// One barrier per iteration.  Epilogue: output transform, folded BN + activation, 32 x 32 transposition through the LDS, 16-byte stores
+// (or raw split-K slabs for ry_splitk_reduce).  Tile rows left out of the grid (hole_*) and row ranges (Hs / Hos) as in ry_igemm_ldsdma.
+// ---------------------------------------------------------------------------------------------
+struct RyWinoParams {
+    RyConvGeom g;               // src1 / src2, C1 / C2 (S1 = C1, S2 = C2), B, Hi, Wi, Hs, Ho, Wo, Hos, Mh, Mw, ostride, nphases, N, zoff1 / zoff2, pdy / pdx
+    const float* wt;            // transformed filters (relayout_wino)
+    const float* scale;
+    const float* shift;
+    float* out;                 // splits == 1: NHWC output; else slabs [split][B * Ho * Wo][N] of raw sums
+    int splits;
+    int act;
+    float slope;
+    long long slab_stride;
+    int mtiles, ntiles;         // 1-D XCD-aware grid as ry_igemm_ldsdma: logical id = ((split * mtiles + mt) * ntiles + nt) * nphases + phase
+    int mbw;                    // M-blocks per tile row: a tile is (WM / mbw) x mbw blocks of 8 x 16 pixels
+    int tcols, trows;           // M-tiles per row of the grid, computed tile rows per image
+    float inv_nphases, inv_ntiles, inv_tcols, inv_trows, inv_pw;
+    int xcd_gs, xcd_gs_shift, xcd_nsg, xcd_mtg;
+    float inv_xcd_nsg, inv_nsl;
+    int npatches;               // K axis in patches of 16 channels (MODE 2: x 4 parities, parity fastest)
+    int kq, krem;               // patches per split: split s takes kq + (s < krem) patches starting at s * kq + min(s, krem)
+    int hole_ty, hole_nt;       // as RyIgemmParams
+    int dbg_flags;              // diagnostics (WRONG results): 4 skip the output stores, 8 skip the K loop, 128 skip the loads in the K loop
+};
+
+template <int WM, int WN, int NSL, int MODE>
+RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int NPOS = WM == 2 ? 304 : 592;          // patch positions per A buffer: 17 x 17 / 9 x 33 (WM = 2), 17 x 33 / 33 x 17 / 9 x 65 (WM = 4), rounded up to whole DMA pieces
+    constexpr int AG = NPOS / 16;                      // 1-KiB DMA pieces per patch (16 positions x 64 bytes)
+    constexpr int AI = (AG + NW - 1) / NW;
+    constexpr int AH = NSL == 1 ? (AI + 1) / 2 : AI;   // pieces of the next patch issued in the first iteration of the current one
+    constexpr int BSL = 9 * WN * 256;                  // floats of one filter slice (8 channels x 9 positions x 32 WN output channels)
+    constexpr int BG = NSL * 9 * WN;                   // DMA pieces per iteration
+    constexpr int BI = (BG + NW - 1) / NW;
+    static_assert((WM == 2 || WM == 4) && (WN == 2 || WN == 4) && (NSL == 1 || NSL == 2) && (MODE == 1 || MODE == 2), "shape");
+    static_assert(NW * 1024 <= NSL * BSL, "the epilogue's transposition scratch fits one B buffer");
+    __shared__ __attribute__((aligned(16))) float As0[NPOS * 16];
+    __shared__ __attribute__((aligned(16))) float As1[NPOS * 16];
+    __shared__ __attribute__((aligned(16))) float Bs0[NSL * BSL];
+    __shared__ __attribute__((aligned(16))) float Bs1[NSL * BSL];
+    __shared__ int rO[WM * 32];
+
+    const RyConvGeom& g = p.g;
+    const int tid = (int)threadIdx.x;
+    const int total_tiles = p.splits * p.mtiles * p.ntiles * g.nphases;
+    int mt, sl;
+    if (p.xcd_gs > 0) {                                    // XCD (xm, xs) owns M-tile block xm and slice block xs (see ry_igemm_ldsdma)
+        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        const int xm = xcd >> p.xcd_gs_shift, xs = xcd & (p.xcd_gs - 1);
+        const int mtl = ry_fdiv(j, p.xcd_nsg, p.inv_xcd_nsg);
+        if (mtl >= p.xcd_mtg) return;
+        mt = xm * p.xcd_mtg + mtl;
+        sl = xs * p.xcd_nsg + (j - mtl * p.xcd_nsg);
+    } else {
+        const int per_xcd = (total_tiles + 7) >> 3;
+        const int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+        if (lid >= total_tiles) return;
+        const int nsl = p.splits * p.ntiles * g.nphases;
+        mt = ry_fdiv(lid, nsl, p.inv_nsl);
+        sl = lid - mt * nsl;
+    }
+    int q_ = ry_fdiv(sl, g.nphases, p.inv_nphases);
+    const int phase = sl - q_ * g.nphases; sl = q_;
+    const int split = ry_fdiv(sl, p.ntiles, p.inv_ntiles);
+    const int nt = sl - split * p.ntiles;
+    const int n0 = nt * (32 * WN);
+    const int pdy = MODE == 1 ? (phase >> 1) : 0, pdx = MODE == 1 ? (phase & 1) : 0;
+
+    const int lane = tid & 63, wave = ry_uniform(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int mbw = p.mbw;                                  // blocks per tile row
+    const int TTH = 4 * (WM / mbw), TTW = 8 * mbw;          // Winograd tiles per M-tile
+    const int PW = 2 * TTW + 1, PH = 2 * TTH + 1, NE = TTW + 1;   // patch size in pixels; even columns per patch row
+
+    // K range of this workgroup, in patches and in iterations
+    const int pbeg = split * p.kq + (split < p.krem ? split : p.krem);
+    const int npat = (p.dbg_flags & 8) ? 0 : p.kq + (split < p.krem ? 1 : 0);
+    const int nit = npat * (2 / NSL);
+    // filters of this (phase, N-tile): consecutive slices are consecutive runs of BSL floats
+    const float* wt_it = p.wt + ((size_t)(phase * p.ntiles + nt) * (size_t)(2 * p.npatches) + (size_t)(2 * pbeg)) * BSL;
+    auto b_item = [&](int j, float* Bd) {
+        const int gi = j * NW + wave;
+        if (BG % NW == 0 || gi < BG) ry_glds16_off(wt_it, (unsigned)(gi * 1024 + lane * 16), Bd + gi * 256);     // (uniform base + 32-bit lane offset: the scalar-base addressing mode)
+    };
+    if (nit > 0) {                                          // the filters of the first iteration travel while the A side is set up
+#pragma unroll
+        for (int j = 0; j < BI; ++j) b_item(j, Bs0);
+        wt_it += NSL * BSL;
+    }
+
+    // ---- the M-tile ----
+    const int trow = ry_fdiv(mt, p.tcols, p.inv_tcols);
+    const int txt = mt - trow * p.tcols;
+    const int bimg = ry_fdiv(trow, p.trows, p.inv_trows);
+    const int tyc = trow - bimg * p.trows;
+    const int tyt = tyc + (tyc >= p.hole_ty ? p.hole_nt : 0);
+    const int ry0 = tyt * (2 * TTH), rx0 = txt * (2 * TTW);          // first row / column of the tile on the stencil's output grid
+    if (tid < WM * 32) {                                    // output pixel of (a, b) = (0, 0) of every Winograd tile (epilogue)
+        const int blk = tid >> 5, lr_ = tid & 31;
+        const int tyl = (blk / mbw) * 4 + (lr_ >> 3), txl = (blk % mbw) * 8 + (lr_ & 7);
+        const int ry = ry0 + 2 * tyl, rx = rx0 + 2 * txl;
+        rO[tid] = bimg < g.B ? (bimg * g.Hos + ry * g.ostride + pdy) * g.Wo + rx * g.ostride + pdx : -1;
+    }
+    // ---- A: DMA role of this lane in each piece its wave fills: position pp = 16 gi + lane / 4, physical slot lane & 3 ----
+    constexpr int PS = MODE == 1 ? 1 : 2;                   // input pixels per patch pixel
+    const int oy0 = MODE == 1 ? ry0 + pdy - 1 : 2 * ry0;    // input pixel of patch (0, 0): MODE 2: of the parity-(1, 1) plane
+    const int ox0 = MODE == 1 ? rx0 + pdx - 1 : 2 * rx0;
+    unsigned aoff1[AI], aoff2[AI];
+    unsigned amask = 0;                                     // MODE 2: bit 4 j + 2 r + c = piece j's pixel of parity (r, c) lies inside the image
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int gi = j * NW + wave;
+        const int pp = gi * 16 + (lane >> 2), ps = lane & 3;
+        const int py = ry_fdiv(pp, PW, p.inv_pw), rem = pp - py * PW;
+        const int px = rem < NE ? 2 * rem : 2 * (rem - NE) + 1;
+        const int ls = ps ^ ((py >> 1) & 3);                // logical slot (4 channels) stored at this physical slot
+        const int iy = oy0 + PS * py, ix = ox0 + PS * px;
+        const bool inp = gi < AG && py < PH && bimg < g.B;
+        const unsigned pix = (unsigned)((bimg * g.Hs + iy) * g.Wi + ix);     // (wraps for pixels outside the image: never used then)
+        if (MODE == 1) {
+            const bool ok = inp && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            aoff1[j] = ok ? pix * (unsigned)g.S1 * 4u + (unsigned)ls * 16u : g.zoff1;
+            aoff2[j] = ok ? pix * (unsigned)g.S2 * 4u + (unsigned)ls * 16u : g.zoff2;
+        } else {
+            aoff1[j] = pix * (unsigned)g.S1 * 4u + (unsigned)ls * 16u; aoff2[j] = pix * (unsigned)g.S2 * 4u + (unsigned)ls * 16u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int y2 = iy + (q >> 1) - 1, x2 = ix + (q & 1) - 1;
+                if (inp && (unsigned)y2 < (unsigned)g.Hi && (unsigned)x2 < (unsigned)g.Wi) amask |= 1u << (4 * j + q);
+            }
+        }
+    }
+    // state of the patch being fetched (wave-uniform)
+    int pch = pbeg;
+    const float* c_src = nullptr; bool c_first = true; int c_par = 0; unsigned c_delta1 = 0, c_delta2 = 0;
+    auto next_patch = [&]() {
+        const int chunk = MODE == 2 ? pch >> 2 : pch;
+        const int ci0 = chunk * 16;
+        c_first = ci0 < g.C1;
+        c_src = (c_first ? g.src1 : g.src2) + (c_first ? ci0 : ci0 - g.C1);     // the channel offset rides on the scalar base (the zero tail is a whole zeroed pixel)
+        if (MODE == 2) {
+            c_par = pch & 3;
+            const int dpix = (((pch >> 1) & 1) - 1) * g.Wi + ((pch & 1) - 1);
+            c_delta1 = (unsigned)(dpix * g.S1 * 4); c_delta2 = (unsigned)(dpix * g.S2 * 4);
+        }
+        ++pch;
+    };
+    auto a_item = [&](int j, float* Ad) {
+        const int gi = j * NW + wave;
+        if (AG % NW == 0 || gi < AG) {
+            unsigned off;
+            if (MODE == 1) off = c_first ? aoff1[j] : aoff2[j];
+            else {
+                const bool ok = (amask >> (4 * j + c_par)) & 1u;
+                off = ok ? (c_first ? aoff1[j] + c_delta1 : aoff2[j] + c_delta2) : (c_first ? g.zoff1 : g.zoff2);
+            }
+            ry_glds16_off(c_src, off, Ad + gi * 256);
+        }
+    };
+    if (nit > 0) {
+        next_patch();
+#pragma unroll
+        for (int j = 0; j < AI; ++j) a_item(j, As0);
+    }
+    // ---- A fragments: float index of the lane's 3 x 3 pixels (slice 0; slice 1 = index ^ 8) ----
+    const int lr = lane & 31, lh = lane >> 5;
+    const int tyl = (wm / mbw) * 4 + (lr >> 3), txl = (wm % mbw) * 8 + (lr & 7);
+    int aaddr[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int py = 2 * tyl + i;
+            const int rem = j == 1 ? NE + txl : txl + (j >> 1);
+            aaddr[i * 3 + j] = (py * PW + rem) * 16 + ((lh ^ ((py >> 1) & 3)) << 2);
+        }
+    f32x16 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    __syncthreads();
+
+    auto run_it = [&](auto k4c, int k) {
+        constexpr int K4 = decltype(k4c)::value;
+        constexpr int SL = NSL == 1 ? (K4 & 1) : 0;                       // slice of the patch this iteration starts with
+        constexpr int ABUF = NSL == 1 ? ((K4 >> 1) & 1) : (K4 & 1), BBUF = K4 & 1;
+        const float* Ac = ABUF ? As1 : As0;
+        const float* Bc = BBUF ? Bs1 : Bs0;
+        float* An = ABUF ? As0 : As1;
+        float* Bn = BBUF ? Bs0 : Bs1;
+        const bool loads = !(p.dbg_flags & 128);
+        const bool more_b = (k + 1 < nit) && loads;
+        const bool more_a = (k - SL + 2 / NSL < nit) && loads;            // a next patch exists
+        if (more_a && SL == 0) next_patch();
+        // DMA pieces of the next iteration (filters) and of the next patch (its first AH pieces with the first slice, the rest with the second), one per position
+        constexpr int A_LO = SL == 0 ? 0 : AH, A_HI = SL == 0 ? AH : AI, NITEM = BI + (A_HI - A_LO);
+        auto issue = [&](int step) {
+            if (step < BI) { if (more_b) b_item(step, Bn); }
+            else if (step < NITEM) { if (more_a) a_item(A_LO + step - BI, An); }
+        };
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+            f32x4 v[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) v[q] = ry_ld4(Ac + (aaddr[q] ^ ((SL + s) * 8)));
+            // V = B^T d B: rows, then columns
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { v[j] -= v[3 + j]; v[6 + j] -= v[3 + j]; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { v[3 * i] -= v[3 * i + 1]; v[3 * i + 2] -= v[3 * i + 1]; }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const f32x4 bf = ry_ld4(Bc + s * BSL + (q * WN + wn) * 256 + lane * 4);
+                issue(s * 9 + q);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[q] = ry_mfma_32x32x2(v[q][t], bf[t], acc[q]);
+            }
+        }
+        static_assert(NITEM <= 9 * NSL, "one DMA piece per position step");
+        if (more_b) wt_it += NSL * BSL;
+        __syncthreads();                       // the DMA of iteration k + 1 landed (vmcnt) and this iteration's buffers are free again
+    };
+    for (int k = 0; k < nit; k += 4) {
+        run_it(RyConst<0>(), k);
+        if (k + 1 < nit) run_it(RyConst<1>(), k + 1);
+        if (k + 2 < nit) run_it(RyConst<2>(), k + 2);
+        if (k + 3 < nit) run_it(RyConst<3>(), k + 3);
+    }
+
+    if (p.dbg_flags & 4) return;
+    // ---- epilogue: Y = A^T M A per lane, folded BN + activation, 32 x 32 transposition through a 4-KiB per-wave scratch, 16-byte stores ----
+    float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
+    float* T = Bs0 + wave * 1024;
+    const bool final_ = p.splits == 1;
+    const int erow = lane >> 3, eslot = lane & 7;
+    const int nbase = n0 + wn * 32;
+    float sc = 1.f, sh = 0.f;
+    if (final_) { sc = p.scale[nbase + lr]; sh = p.shift[nbase + lr]; }
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+        const int a = ab >> 1, b = ab & 1;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // (m[a][b] + m[a][b + 1]) + (m[a + 1][b] + m[a + 1][b + 1]), fixed order
+            const float top = acc[3 * a + b][r] + acc[3 * a + b + 1][r];
+            const float bot = acc[3 * a + 3 + b][r] + acc[3 * a + 3 + b + 1][r];
+            v[r] = top + bot;
+        }
+        if (final_) {
+            if (p.act == RY_ACT_LRELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float x = fmaf(v[r], sc, sh); v[r] = x >= 0.f ? x : x * p.slope; }
+            } else if (p.act == RY_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float x = fmaf(v[r], sc, sh); v[r] = x > 0.f ? x : 0.f; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaf(v[r], sc, sh);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            T[row * 32 + ((((lr >> 2) ^ (row & 7)) << 2) | (lr & 3))] = v[r];
+        }
+        ry_wave_sync();
+        const int dpix = (a * g.Wo + b) * g.ostride;             // output pixel of (a, b) relative to (0, 0) of the tile
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = erow + 8 * q;
+            const f32x4 o = ry_ld4(T + row * 32 + ((eslot ^ (row & 7)) << 2));
+            const int ob = rO[wm * 32 + row];
+            if (ob >= 0) ry_st4(outp + (size_t)(ob + dpix) * g.N + nbase + eslot * 4, o);
+        }
+        ry_wave_sync();
+    }
+}
+
 struct RyReduceParams {
     const float* slabs;
     int splits;

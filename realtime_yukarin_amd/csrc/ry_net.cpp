@@ -224,6 +224,51 @@ static void relayout_c2d_os(const Layer& l, const float* W, std::vector<float>& 
                 }
 }
 
+// ry_wino_ldsdma filters: a k4 s2 p1 layer is a sum of 2 x 2-tap stride-1 stencils -- one per sub-pixel phase of a transposed convolution
+// (taps g[a][b] = W[KY[pdy][1 - a]][KY[pdx][1 - b]] on input offset (pdy - 1 + a, pdx - 1 + b)), one per input parity (r, c) of a convolution
+// (g[a][b] = W[2 a + r][2 b + c] on the parity plane) -- and each stencil's F(2x2, 2x2) filters are U = G g G^T, G = [[1, 0], [1, 1], [0, 1]],
+// computed in float64 and rounded once.  Layout [phase][N / 64][slice][position i * 3 + j][n / 32 : 2][lane = 32 * lh + n % 32][t : 4] with channel
+// 8 * slice' + 4 * lh + t: one (slice, position, 32 channels) piece is the KiB a wave-instruction of the kernel copies, the pieces of a slice and
+// consecutive slices are consecutive.  Slices follow the kernel's K loop: deconvolution slice = channel / 8; convolution
+// slice = ((channel / 16) * 4 + parity) * 2 + (channel / 8) % 2.  2.25 x the floats of the direct layout (9 positions for 4 taps).
+static bool wino_eligible(const Layer& l, int ndim) {
+    return ndim == 2 && l.k == 4 && l.stride == 2 && l.pad == 1 && l.dil == 1 && l.cin_a % 16 == 0 && l.cin_b % 16 == 0 && l.cout % 64 == 0 &&
+           l.cin_a > 0 && l.cin_a <= 2032 && l.cin_b <= 2032;     // (the channel offset of a patch rides on the base of its zero-tail fetches: ZTAIL floats)
+}
+
+// w(n, c, ky, kx) = the layer's filter element (any accessor: the Chainer blob, or the device's direct layout read back)
+template <class F>
+static void relayout_wino(const Layer& l, F w, std::vector<float>& out) {
+    const int C = l.cin(), N = l.cout;
+    const int nph = l.deconv ? 4 : 1, nsl = l.deconv ? C / 8 : (C / 16) * 8;
+    out.assign((size_t)nph * N * nsl * 72, 0.f);
+    static const double G[3][2] = {{1, 0}, {1, 1}, {0, 1}};
+    for (int ph = 0; ph < nph; ++ph)
+        for (int n = 0; n < N; ++n)
+            for (int ks = 0; ks < nsl; ++ks)
+                for (int cc = 0; cc < 8; ++cc) {
+                    int c; double g[2][2];
+                    if (l.deconv) {
+                        c = ks * 8 + cc;
+                        for (int a = 0; a < 2; ++a)
+                            for (int b = 0; b < 2; ++b) g[a][b] = w(n, c, DECONV_KY[ph >> 1][1 - a], DECONV_KY[ph & 1][1 - b]);
+                    } else {
+                        const int par = (ks >> 1) & 3;
+                        c = (ks >> 3) * 16 + (ks & 1) * 8 + cc;
+                        for (int a = 0; a < 2; ++a)
+                            for (int b = 0; b < 2; ++b) g[a][b] = w(n, c, 2 * a + (par >> 1), 2 * b + (par & 1));
+                    }
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) {
+                            double u = 0.0;
+                            for (int a = 0; a < 2; ++a)
+                                for (int b = 0; b < 2; ++b) u += G[i][a] * g[a][b] * G[j][b];
+                            const size_t piece = ((((size_t)ph * (N / 64) + n / 64) * nsl + ks) * 9 + (i * 3 + j)) * 2 + (n % 64) / 32;
+                            out[piece * 256 + (size_t)((32 * (cc >> 2) + n % 32) * 4 + (cc & 3))] = (float)u;
+                        }
+                }
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-layer launch plans
 // ------------------------------------------------------------------------------------------------
@@ -561,8 +606,165 @@ static int launch_c2d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     return Lc.end();
 }
 
+// the rows a launch left out of its grid (LayerPlan::hole_*): copies of the row above them, into the fp32 output and / or the bf16 copy ([pixel][N] or split [pixel][hi | lo])
+static int launch_rep_rows(Launcher& Lc, const Layer& l, const LayerPlan& lp, int B) {
+    for (int copy = 0; copy < 2; ++copy) {
+        if (copy == 0 ? !lp.w32 : !lp.w16) continue;
+        const int px_bytes = copy == 0 ? 4 * l.cout : (lp.o16x3 ? 4 : 2) * l.cout;
+        RyRepRowsParams q;
+        q.base = copy == 0 ? lp.out : reinterpret_cast<float*>(lp.out16);
+        q.row_f4 = lp.Wo * px_bytes / 16; q.img_f4 = (long long)lp.Ho * q.row_f4;
+        q.src = lp.hole_lo - 1; q.dst0 = lp.hole_lo; q.nrows = lp.hole_n;
+        dim3 rg((unsigned)((q.row_f4 + 255) / 256), (unsigned)lp.hole_n, (unsigned)B);
+        RY_TRY(Lc.begin("ry_rep_rows", l.name, 0, (double)B * lp.hole_n * lp.Wo * px_bytes, rg));
+        RY_LAUNCH(ry_rep_rows, rg, 256, Lc.stream, q);
+        RY_TRY(Lc.end());
+    }
+    return RY_OK;
+}
+
+// sum of the raw split-K slabs of a launch + folded BN + activation (Ho_run = the output rows per image the launch covered, oo = their float offset)
+static int launch_reduce(Launcher& Lc, const Layer& l, const LayerPlan& lp, int B, int Ho_run, size_t oo, long long slab_stride, float slope) {
+    RyReduceParams r;
+    const size_t ro = B == 1 ? oo : 0;                                    // one window: only the rows this launch wrote
+    r.slabs = lp.slabs + ro; r.splits = lp.splits; r.slab_stride = slab_stride;
+    r.scale = l.scale; r.shift = l.shift; r.out = lp.w32 ? lp.out + ro : nullptr; r.out16 = lp.w16 ? lp.out16 + ro * (lp.o16x3 ? 2 : 1) : nullptr;
+    r.x3 = lp.o16x3 ? 1 : 0;
+    r.total = B == 1 ? (long long)Ho_run * lp.Wo * l.cout : slab_stride; r.N = l.cout;      // one window: only the rows this launch wrote (a prefix when cropped)
+    r.act = l.act; r.slope = slope;
+    if (lp.splits >= 16 && r.total <= (1 << 20)) {      // many slabs, few outputs
+        dim3 rg((unsigned)((r.total / 4 + 63) / 64));
+        RY_TRY(Lc.begin("ry_splitk_reduce_wide", l.name, 0, (double)r.total * 4 * (lp.splits + 1), rg));
+        RY_LAUNCH(ry_splitk_reduce_wide, rg, 256, Lc.stream, r);
+    } else {
+        dim3 rg((unsigned)((r.total / 4 + 255) / 256));
+        RY_TRY(Lc.begin("ry_splitk_reduce", l.name, 0, (double)r.total * 4 * (lp.splits + 1), rg));
+        RY_LAUNCH(ry_splitk_reduce, rg, 256, Lc.stream, r);
+    }
+    return Lc.end();
+}
+
+// ---- stage-2 layers in Winograd F(2x2, 2x2) form (ry_wino_ldsdma) ----
+// Workgroup shapes: cfg 1 = 2 x 2 waves (two M-blocks of 8 x 16 pixels x 64 channels, one 8-channel slice per iteration, 74 KiB of LDS: two per CU),
+// cfg 2 = 4 x 2 waves (four M-blocks x 64 channels, two slices per iteration, 146 KiB: one per CU).  mbw = M-blocks per tile row.
+static int g_wino = 1;                 // RY_WINOGRAD=0: every layer keeps the direct implicit GEMM (the bit-exact reference of the Winograd form; A/B)
+static int g_wino_min_m = 512;         // RY_WINO_MINM: rows (pixels of one phase) from which an eligible layer takes the Winograd form
+static int g_wino_force[16][3];        // RY_WINO="layer:cfg:mbw:splits,...": tuning aid, fixes the Winograd plan of single layers ("layer:0" keeps that layer on the direct kernel)
+static bool g_wino_forced[16];
+
+static bool wino_cfg_dims(int cfg, int* wm, int* wn, int* nsl) {
+    if (cfg == 1) { *wm = 2; *wn = 2; *nsl = 1; return true; }
+    if (cfg == 2) { *wm = 4; *wn = 2; *nsl = 2; return true; }
+    return false;
+}
+static void wino_tile_hw(int cfg, int mbw, int* th, int* tw) {              // pixels of the stencil's output grid per M-tile
+    int wm = 2, wn = 2, nsl = 1; wino_cfg_dims(cfg, &wm, &wn, &nsl);
+    *th = 8 * (wm / mbw); *tw = 16 * mbw;
+}
+static const char* wino_name(int cfg, int mode) {
+    static char buf[4][40];
+    char* b = buf[(cfg - 1) * 2 + (mode - 1)];
+    int wm = 2, wn = 2, nsl = 1; wino_cfg_dims(cfg, &wm, &wn, &nsl);
+    snprintf(b, 40, "ry_wino_ldsdma<%d,%d,%d,%d>", wm, wn, nsl, mode);      // as rocprofv3 prints it
+    return b;
+}
+
+// Plan of one layer: workgroup shape, tile shape (the squarest one that divides the grid: the patch carries one extra row and column), external split-K.
+// Returns false when no tile shape divides the Mh x Mw grid.
+static bool choose_wino(int Mh, int Mw, int N, int nphases, int npatches, int B, int* cfg, int* mbw, int* splits) {
+    double best = 1e30; int bc = 0, bm = 0, bs = 0;
+    for (int c = 1; c <= 2; ++c) {
+        if (*cfg != 0 && *cfg != c) continue;
+        int wm, wn, nsl; wino_cfg_dims(c, &wm, &wn, &nsl);
+        for (int m = 1; m <= wm; m *= 2) {
+            if (*mbw != 0 && *mbw != m) continue;
+            int th, tw; wino_tile_hw(c, m, &th, &tw);
+            if (Mh % th || Mw % tw) continue;
+            const long units = (long)B * (Mh / th) * (Mw / tw) * (N / 64) * nphases;
+            const int slots = c == 1 ? 512 : 256;
+            const double halo = (double)(th + 1) * (tw + 1) / ((double)th * tw) + 0.002 * th;      // (short tiles: the dead-row crop and the copied padding rows round to whole tile rows)
+            for (int sp = 1; sp <= 32 && sp <= npatches; ++sp) {
+                if (*splits != 0 ? *splits != sp : (sp > 1 && sp > npatches / 2)) continue;      // (the planner's own splits leave two patches per workgroup)
+                // rounds of workgroups x iterations of the longest split (+ prologue / epilogue of a workgroup, in iterations) x time of an iteration relative to
+                // cfg 1 (cfg 2 runs twice the slices on twice the rows per slot), + the slab traffic and the reduce node of an external split
+                const long rounds = (units * sp + slots - 1) / slots;
+                const double its = (double)((npatches + sp - 1) / sp) * 2.0;          // 8-channel slices
+                double t = (double)rounds * (its + 6.0) * (c == 1 ? 1.0 : 2.0) * (0.9 + 0.1 * halo);
+                if (sp > 1) t += 8.0 + 0.02 * sp * (double)B * Mh * Mw * nphases * N / 65536.0;
+                if (t < best - 1e-9) { best = t; bc = c; bm = m; bs = sp; }
+            }
+        }
+    }
+    if (bc == 0) return false;
+    *cfg = bc; *mbw = bm; *splits = bs;
+    return true;
+}
+
+static int launch_wino(Launcher& Lc, const Layer& l, const LayerPlan& lp, const float* wwin, int B, const float* s1, int C1, const float* s2, int C2, float slope) {
+    RyConvGeom g;
+    fill_geom(g, l, lp, B, s1, C1, s2, C2);
+    int wm, wn, nsl;
+    if (!wwin || !wino_eligible(l, 2) || !wino_cfg_dims(lp.wino_cfg, &wm, &wn, &nsl) || lp.wino_mbw < 1 || lp.wino_mbw > wm || (wm % lp.wino_mbw))
+        return fail(RY_ESTATE, "%s: not a layer / plan for the Winograd kernel (cfg %d, %d blocks per tile row)", l.name, lp.wino_cfg, lp.wino_mbw);
+    int th, tw; wino_tile_hw(lp.wino_cfg, lp.wino_mbw, &th, &tw);
+    if (g.Mh % th || g.Mw % tw) return fail(RY_ESTATE, "%s: the %d x %d grid is not a multiple of the %d x %d Winograd tile", l.name, g.Mh, g.Mw, th, tw);
+    RyWinoParams p;
+    memset(&p, 0, sizeof p);
+    p.g = g; p.wt = wwin; p.scale = l.scale; p.shift = l.shift;
+    p.splits = lp.splits; p.act = l.act; p.slope = slope;
+    p.slab_stride = (long long)B * lp.Ho * lp.Wo * l.cout;
+    const size_t oo = lp.crop_hi > 0 ? (size_t)(l.deconv ? 2 : 1) * lp.crop_lo * lp.Wo * l.cout : 0;     // output rows start (2 x for the sub-pixel form) crop_lo rows into every image
+    p.out = lp.splits > 1 ? lp.slabs + oo : lp.out + oo;
+    if (!p.out) return fail(RY_ESTATE, "%s: no output buffer", l.name);
+    p.mbw = lp.wino_mbw; p.tcols = g.Mw / tw; p.trows = g.Mh / th;
+    p.hole_ty = 1 << 30; p.hole_nt = 0;
+    if (lp.hole_n > 0) {
+        if (l.deconv || lp.crop_hi > 0 || lp.hole_lo % th || lp.hole_n % th || lp.hole_lo + lp.hole_n > g.Mh)
+            return fail(RY_ESTATE, "%s: rows %d..%d cannot be left out of this launch", l.name, lp.hole_lo, lp.hole_lo + lp.hole_n - 1);
+        p.hole_ty = lp.hole_lo / th; p.hole_nt = lp.hole_n / th; p.trows -= p.hole_nt;
+    }
+    p.mtiles = B * p.trows * p.tcols; p.ntiles = l.cout / (32 * wn);
+    p.npatches = (l.deconv ? 1 : 4) * ((C1 + C2) / 16);
+    if (lp.splits < 1 || lp.splits > p.npatches) return fail(RY_ESTATE, "%s: %d splits for %d patches", l.name, lp.splits, p.npatches);
+    p.kq = p.npatches / lp.splits; p.krem = p.npatches % lp.splits;
+    const int nsl_ = lp.splits * p.ntiles * g.nphases;
+    if ((long long)p.mtiles * nsl_ >= (1 << 24) || (long long)B * g.Mh * g.Mw >= (1 << 24)) return fail(RY_EINVAL, "%s: more than 2^24 output rows or tiles in one launch; lower the batch", l.name);
+    p.inv_nphases = 1.f / g.nphases; p.inv_ntiles = 1.f / p.ntiles; p.inv_tcols = 1.f / p.tcols; p.inv_trows = 1.f / p.trows; p.inv_pw = 1.f / (float)(tw + 1);
+    p.inv_nsl = 1.f / nsl_;
+    p.xcd_gs = 0; p.xcd_gs_shift = 0; p.xcd_nsg = 1; p.xcd_mtg = 1; p.inv_xcd_nsg = 1.f;
+    {   // XCD grouping as the implicit GEMM: gm M-tile groups x gs slice groups, the split with the least L2 miss traffic among those that divide evenly
+        const double wbytes = 2.25 * g.nphases * l.cout * 4.0 * (C1 + C2), abytes = (double)B * lp.Hi * lp.Wi * (C1 + C2);
+        double best = 1e300;
+        for (int sh = 0; sh <= 3; ++sh) {
+            const int gs = 1 << sh, gm = 8 >> sh;
+            if (nsl_ % gs != 0 || p.mtiles % gm != 0) continue;
+            const double cost = gm * wbytes + gs * abytes;
+            if (cost < best) { best = cost; p.xcd_gs = gs; p.xcd_gs_shift = sh; p.xcd_nsg = nsl_ / gs; p.xcd_mtg = p.mtiles / gm; }
+        }
+        if (p.xcd_gs) p.inv_xcd_nsg = 1.f / p.xcd_nsg;
+    }
+    p.dbg_flags = g_igemm_dbg;
+    const int total_tiles = p.mtiles * nsl_;
+    dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
+    const int mode = l.deconv ? 1 : 2;
+    RY_TRY(Lc.begin(wino_name(lp.wino_cfg, mode), l.name, lp.flops, lp.bytes, grid, lp.flops * 9.0 / 16.0));
+    if (lp.wino_cfg == 1) {
+        if (mode == 1) RY_LAUNCH((ry_wino_ldsdma<2, 2, 1, 1>), grid, 256, Lc.stream, p);
+        else RY_LAUNCH((ry_wino_ldsdma<2, 2, 1, 2>), grid, 256, Lc.stream, p);
+    } else {
+        if (mode == 1) RY_LAUNCH((ry_wino_ldsdma<4, 2, 2, 1>), grid, 512, Lc.stream, p);
+        else RY_LAUNCH((ry_wino_ldsdma<4, 2, 2, 2>), grid, 512, Lc.stream, p);
+    }
+    RY_TRY(Lc.end());
+    // (with an external split the rows left out of the grid have no slabs: the reduce node writes whatever their slab memory holds, the copy node behind it fills them in)
+    if (lp.splits > 1 && !(g_igemm_dbg & 16)) RY_TRY(launch_reduce(Lc, l, lp, B, g.Ho, oo, p.slab_stride, slope));
+    if (p.hole_nt > 0) RY_TRY(launch_rep_rows(Lc, l, lp, B));
+    return RY_OK;
+}
+
 static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int B, const float* s1, int C1, const float* s2, int C2, float slope) {
     if (lp.path == PATH_OS2D) return launch_c2d_os(Lc, l, lp, B, s1, C1, s2, C2, slope);
+    if (lp.path == PATH_WINO) return launch_wino(Lc, l, lp, l.wwin, B, s1, C1, s2, C2, slope);
     RyConvGeom g;
     fill_geom(g, l, lp, B, s1, C1, s2, C2);
     const int M = B * g.Mh * g.Mw;
@@ -670,37 +872,8 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         }
 #undef RY_IGEMM_LAUNCH
         RY_TRY(Lc.end());
-        for (int copy = 0; copy < 2 && p.hole_nt > 0; ++copy) {            // the fp32 output and / or the bf16 copy ([pixel][N] or split [pixel][hi | lo])
-            if (copy == 0 ? !lp.w32 : !lp.w16) continue;
-            const int px_bytes = copy == 0 ? 4 * l.cout : (lp.o16x3 ? 4 : 2) * l.cout;
-            RyRepRowsParams q;
-            q.base = copy == 0 ? lp.out : reinterpret_cast<float*>(lp.out16);
-            q.row_f4 = lp.Wo * px_bytes / 16; q.img_f4 = (long long)lp.Ho * q.row_f4;
-            q.src = lp.hole_lo - 1; q.dst0 = lp.hole_lo; q.nrows = lp.hole_n;
-            dim3 rg((unsigned)((q.row_f4 + 255) / 256), (unsigned)lp.hole_n, (unsigned)B);
-            RY_TRY(Lc.begin("ry_rep_rows", l.name, 0, (double)B * lp.hole_n * lp.Wo * px_bytes, rg));
-            RY_LAUNCH(ry_rep_rows, rg, 256, Lc.stream, q);
-            RY_TRY(Lc.end());
-        }
-        if (lp.splits > 1 && !(g_igemm_dbg & 16)) {
-            RyReduceParams r;
-            const size_t ro = B == 1 ? oo : 0;                                    // one window: only the rows this launch wrote
-            r.slabs = lp.slabs + ro; r.splits = lp.splits; r.slab_stride = p.slab_stride;
-            r.scale = l.scale; r.shift = l.shift; r.out = lp.w32 ? lp.out + ro : nullptr; r.out16 = lp.w16 ? lp.out16 + ro * (lp.o16x3 ? 2 : 1) : nullptr;
-            r.x3 = lp.o16x3 ? 1 : 0;
-            r.total = B == 1 ? (long long)g.Ho * lp.Wo * l.cout : p.slab_stride; r.N = l.cout;      // one window: only the rows this launch wrote (a prefix when cropped)
-            r.act = l.act; r.slope = slope;
-            if (lp.splits >= 16 && r.total <= (1 << 20)) {      // many slabs, few outputs
-                dim3 rg((unsigned)((r.total / 4 + 63) / 64));
-                RY_TRY(Lc.begin("ry_splitk_reduce_wide", l.name, 0, (double)r.total * 4 * (lp.splits + 1), rg));
-                RY_LAUNCH(ry_splitk_reduce_wide, rg, 256, Lc.stream, r);
-            } else {
-                dim3 rg((unsigned)((r.total / 4 + 255) / 256));
-                RY_TRY(Lc.begin("ry_splitk_reduce", l.name, 0, (double)r.total * 4 * (lp.splits + 1), rg));
-                RY_LAUNCH(ry_splitk_reduce, rg, 256, Lc.stream, r);
-            }
-            RY_TRY(Lc.end());
-        }
+        if (p.hole_nt > 0) RY_TRY(launch_rep_rows(Lc, l, lp, B));
+        if (lp.splits > 1 && !(g_igemm_dbg & 16)) RY_TRY(launch_reduce(Lc, l, lp, B, g.Ho, oo, p.slab_stride, slope));
     } else if (lp.path == PATH_FIRST) {
         RySrFirstParams p;
         p.x = s1; p.w = l.wdir; p.scale = l.scale; p.shift = l.shift; p.out16 = lp.w16 ? lp.out16 : nullptr;
@@ -876,6 +1049,46 @@ static int launch_c1d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     return Lc.end();
 }
 
+// The Winograd filters of predictor layer i, built when a plan first takes the layer onto that path (2.25 x the floats of the layer's filters, kept in the
+// arena the clones of the predictor share): the direct layout [phase][tap][C][N] holds every filter element once -- read it back, transform, upload.
+// Never called under stream capture (plans are built before their first run).
+static int ensure_wwin(ry_net* net, int i, const float** out) {
+    auto& lazy = net->weights->lazy;
+    auto it = lazy.find(i);
+    if (it == lazy.end()) {
+        const Layer& l = net->layers[i];
+        if (!l.wdir || !wino_eligible(l, net->desc.ndim)) return fail(RY_ESTATE, "%s: no Winograd form of this layer", l.name);
+        const TapTable t = make_taps(l);
+        const int C = l.cin(), N = l.cout;
+        std::vector<float> wd((size_t)t.nphases * t.ntaps * C * N);
+        RT_TRY(rt::d2h(wd.data(), l.wdir, wd.size() * sizeof(float), net->ctx->stream));
+        RT_TRY(rt::stream_sync(net->ctx->stream));
+        int where[4][4];
+        for (int ph = 0; ph < t.nphases; ++ph)
+            for (int tt = 0; tt < t.ntaps; ++tt) where[t.ky[ph][tt]][t.kx[ph][tt]] = ph * t.ntaps + tt;
+        std::vector<float> w;
+        relayout_wino(l, [&](int n, int c, int ky, int kx) { return (double)wd[((size_t)where[ky][kx] * C + c) * N + n]; }, w);
+        float* d = nullptr;
+        RY_TRY(upload(*net->weights, net->ctx, w, &d));
+        it = lazy.emplace(i, d).first;
+    }
+    *out = it->second;
+    return RY_OK;
+}
+
+// rows of the 2-D pixel tiles a layer's launch walks (the dead-row crop and the copied padding rows round to whole tile rows); false: raster tiles
+static bool plan_tile_rows(const LayerPlan& lp, int Mh, int Mw, int* th, int* tw_out = nullptr) {
+    if (lp.path == PATH_WINO) {
+        int tw; wino_tile_hw(lp.wino_cfg, lp.wino_mbw, th, &tw);
+        if (tw_out) *tw_out = tw;
+        return Mh % *th == 0 && Mw % tw == 0;
+    }
+    int bm, bn; tile_dims(lp.tile, &bm, &bn);
+    for (int tw = 16; tw >= 4; tw >>= 1)
+        if (bm % tw == 0 && Mw % tw == 0 && Mh % (bm / tw) == 0) { *th = bm / tw; if (tw_out) *tw_out = tw; return true; }
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------------
 // plan construction
 // ------------------------------------------------------------------------------------------------
@@ -974,6 +1187,21 @@ static int build_plan(ry_net* net, Plan& P) {
                         lp.os2_mt4 = c[0]; lp.os2_nt4 = c[1]; lp.os2_waves = c[2]; lp.os2_depth = c[3];
                     } else if (g_os2_forced[i]) {
                         return fail(RY_EINVAL, "RY_OS2: no output-stationary slice %d:%d:%d:%d for %s", c[0], c[1], c[2], c[3], l.name);
+                    }
+                }
+                // the MFMA-bound k4 s2 p1 layers: Winograd F(2x2, 2x2), 9 / 16 of the matrix-pipe work -- exact-fp32 mode only (RY_WINOGRAD=0: the direct kernels, bit-exact reference)
+                if (lp.path == PATH_IGEMM && net->dtype == 0 && g_wino && wino_eligible(l, 2) && !(g_wino_forced[i] && g_wino_force[i][0] == 0) &&
+                    !(g_force[i][0] || g_force[i][1] || g_force[i][2])) {                  // (a layer whose direct plan RY_PLAN fixes stays direct)
+                    const int Mh = l.deconv ? lp.Hi : lp.Ho, Mw = l.deconv ? lp.Wi : lp.Wo;
+                    int c[3] = {0, 0, 0};
+                    if (g_wino_forced[i]) { c[0] = g_wino_force[i][0]; c[1] = g_wino_force[i][1]; c[2] = g_wino_force[i][2]; }
+                    const int npatches = (l.deconv ? 1 : 4) * (l.cin() / 16);
+                    if ((g_wino_forced[i] || M >= g_wino_min_m) && choose_wino(Mh, Mw, l.cout, t.nphases, npatches, B, &c[0], &c[1], &c[2])) {
+                        lp.path = PATH_WINO; lp.wino_cfg = c[0]; lp.wino_mbw = c[1]; lp.splits = c[2]; lp.kg = 1; lp.tile = 0;
+                        const float* ww = nullptr;
+                        RY_TRY(ensure_wwin(net, i, &ww));
+                    } else if (g_wino_forced[i]) {
+                        return fail(RY_EINVAL, "RY_WINO: no Winograd plan %d:%d:%d for %s", c[0], c[1], c[2], l.name);
                     }
                 }
                 if (lp.splits > 1) RY_TRY(P.arena.alloc(&lp.slabs, out_elems * lp.splits));
@@ -1088,22 +1316,23 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
             const LayerPlan& lp = P.lp[i];
             if (need1 > lp.Ho) need1 = lp.Ho;
             if (need0 <= 0 && need1 >= lp.Ho) break;
-            if (lp.path != PATH_IGEMM && lp.path != PATH_IGEMM_BF16) break;
+            if (lp.path != PATH_IGEMM && lp.path != PATH_IGEMM_BF16 && lp.path != PATH_WINO) break;
             if (l.src_a != i - 1) break;
             int r0, r1;
             if (l.deconv) { r0 = need0 > 0 ? (need0 - 1) / 2 : 0; r1 = need1 / 2 + 1; }
             else if (l.k == 1 && l.stride == 1) { r0 = need0; r1 = need1; }
             else break;
-            int bm, bn; tile_dims(lp.tile, &bm, &bn);
             const int Mw = l.deconv ? lp.Wi : lp.Wo, Mh = l.deconv ? lp.Hi : lp.Ho;
-            for (int tw = 16; tw >= 4; tw >>= 1)                      // keep the 2-D pixel tiles of launch_conv2d: whole tile rows
-                if (bm % tw == 0 && Mw % tw == 0 && Mh % (bm / tw) == 0) { const int th = bm / tw; r0 = r0 / th * th; r1 = (r1 + th - 1) / th * th; break; }
+            int th = 1;
+            if (plan_tile_rows(lp, Mh, Mw, &th)) { r0 = r0 / th * th; r1 = (r1 + th - 1) / th * th; }      // keep the 2-D pixel tiles of the launch: whole tile rows
             if (r1 > lp.Hi) r1 = lp.Hi;
             if (r0 <= 0 && r1 >= lp.Hi) break;
             // measured at 300 frames (round 2, interleaved A/B on one box): decoder c6 (1536 -> 1216 workgroups, six per CU -> five) 208 -> 177 us, decoder c5
             // (512 -> 416, two per CU) 198 -> 193 us, decoder c4 (256 -> 224, one per CU) 196 -> 194 us: a grid of one workgroup per CU
             // gains nothing by itself, but the CUs it leaves idle go to the window on the other lane (ry_vc_set_lanes): 1.160 -> 1.137 ms
             // per window with two lanes, so it is cropped too (RY_S2_CROP=1 keeps such grids whole)
+            int bm = 256, bn = 64;
+            if (lp.path == PATH_WINO) { if (lp.wino_cfg == 2) bm = 512; } else tile_dims(lp.tile, &bm, &bn);
             const long wgs = (long)(((long)B * Mh * Mw + bm - 1) / bm) * (l.cout / bn) * (l.deconv ? 4 : 1) * lp.splits;
             if (g_s2_crop >= 2 || wgs > 256) { crop0[i] = r0; crop[i] = r1 - r0; need0 = r0; need1 = r1; }
             else { need0 = 0; need1 = lp.Hi; }                      // this layer runs whole: it reads every row of its producer
@@ -1127,10 +1356,10 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
             a = (a + l.pad + l.stride - 1) / l.stride; b = top / l.stride;
             if (b >= lp.Ho) b = lp.Ho - 1;
             if (b - a < 1) break;
-            if ((lp.path != PATH_IGEMM && lp.path != PATH_IGEMM_BF16) || lp.splits != 1 || crop[i] > 0 || (lp.Wo * l.cout) % 8) continue;
-            int bm, bn; tile_dims(lp.tile, &bm, &bn);
-            if (bm % 16 || lp.Wo % 16 || lp.Ho % (bm / 16)) continue;
-            const int th = bm / 16, r0 = (a + 1 + th - 1) / th * th, r1 = (b + 1) / th * th;      // rows [r0, r1) are whole tile rows and copies of row r0 - 1 >= a
+            if ((lp.path != PATH_IGEMM && lp.path != PATH_IGEMM_BF16 && lp.path != PATH_WINO) || (lp.splits != 1 && lp.path != PATH_WINO) || crop[i] > 0 || (lp.Wo * l.cout) % 8) continue;
+            int th = 1, tw = 0;
+            if (!plan_tile_rows(lp, lp.Ho, lp.Wo, &th, &tw) || (lp.path != PATH_WINO && tw != 16)) continue;
+            const int r0 = (a + 1 + th - 1) / th * th, r1 = (b + 1) / th * th;      // rows [r0, r1) are whole tile rows and copies of row r0 - 1 >= a
             if (r1 - r0 >= th) { hole_lo[i] = r0; hole_n[i] = r1 - r0; }
         }
     }
@@ -1156,7 +1385,13 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
             if (i == 15 && P.mode == 1 && lp.path == PATH_LAST) { lq.last_rows = k1 - k0; lq.last_row0 = k0; lq.last_out_rows = P.n_frames; lq.flops = lp.flops * (k1 - k0) / lp.Ho; }
             if (hole_n[i] > 0) { lq.hole_lo = hole_lo[i]; lq.hole_n = hole_n[i]; lq.flops = lp.flops * (lp.Ho - hole_n[i]) / lp.Ho; }
             if (crop[i] > 0) { lq.crop_hi = crop[i]; lq.crop_lo = crop0[i]; lq.flops = lp.flops * crop[i] / lp.Hi; lq.bytes = lp.bytes * crop[i] / lp.Hi; }
-            RY_TRY(launch_conv2d(Lc, l, lq, B, s1, l.cin_a, s2, l.cin_b, slope));
+            if (lq.path == PATH_WINO) {
+                auto it = net->weights->lazy.find(i);
+                if (it == net->weights->lazy.end()) return fail(RY_ESTATE, "%s: the Winograd filters of this plan are gone", l.name);
+                RY_TRY(launch_wino(Lc, l, lq, it->second, B, s1, l.cin_a, s2, l.cin_b, slope));
+            } else {
+                RY_TRY(launch_conv2d(Lc, l, lq, B, s1, l.cin_a, s2, l.cin_b, slope));
+            }
         }
     }
     if (nd == 1 && P.s1_os) {
@@ -1378,6 +1613,21 @@ static int read_plan_env() {
     g_os2_maxcost = 4608; g_os2_min_filter = (size_t)1 << 21;
     if (const char* e = getenv("RY_OS2_MAXCOST")) g_os2_maxcost = atoi(e);
     if (const char* e = getenv("RY_OS2_MINW")) g_os2_min_filter = (size_t)atoll(e);
+    memset(g_wino_force, 0, sizeof(g_wino_force)); memset(g_wino_forced, 0, sizeof(g_wino_forced));
+    g_wino = 1; g_wino_min_m = 512;
+    if (const char* e = getenv("RY_WINOGRAD")) g_wino = atoi(e);
+    if (const char* e = getenv("RY_WINO_MINM")) g_wino_min_m = atoi(e);
+    if (const char* e = getenv("RY_WINO")) {
+        for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
+            int i = -1, a = 0, b = 0, c = 0;
+            const int got = sscanf(q, "%d:%d:%d:%d", &i, &a, &b, &c);
+            if (got >= 2 && i >= 0 && i < 16 && a >= 0 && a <= 2 && b >= 0 && c >= 0) {
+                g_wino_forced[i] = true; g_wino_force[i][0] = a; g_wino_force[i][1] = got >= 3 ? b : 0; g_wino_force[i][2] = got >= 4 ? c : 0;
+            } else {
+                return fail(RY_EINVAL, "RY_WINO: expected layer:cfg[:mbw[:splits]][,...]");
+            }
+        }
+    }
     g_os2_dbg = 0; g_poison = 0; g_os2_xl = 1;
     if (const char* e = getenv("RY_OS2_XL")) g_os2_xl = atoi(e);
     if (const char* e = getenv("RY_POISON")) g_poison = atoi(e);
@@ -1407,7 +1657,7 @@ static int read_plan_env() {
 }
 
 static int read_env_switches() {
-    g_autotune = 0; g_autotune_reps = 3; g_autotune_max = 0; g_autotune_pick = -1;      // (re-read by ry_debug_plan_igemm: an absent variable means the defaults)
+    g_autotune = 0; g_autotune_reps = 3; g_autotune_max = 0; g_autotune_pick = -1;      // (re-read by ry_debug_reload_env: an absent variable means the defaults)
     if (const char* e = getenv("RY_AUTOTUNE")) {                                        // "1[:reps[:max[:pick]]]"
         int on = 0, reps = 3, mx = 0, pick = -1;
         if (sscanf(e, "%d:%d:%d:%d", &on, &reps, &mx, &pick) < 1) return fail(RY_EINVAL, "RY_AUTOTUNE: expected 1[:reps[:max[:pick]]]");
@@ -1742,7 +1992,7 @@ static int profile_plan(ry_net* net, Plan* P, int reps, ry_kernel_stat* stats, i
         snprintf(stats[i].name, sizeof stats[i].name, "%s", rec[i].name.c_str());
         snprintf(stats[i].layer, sizeof stats[i].layer, "%s", rec[i].layer.c_str());
         stats[i].ms = (float)(total[i] / reps);
-        stats[i].flops = rec[i].flops; stats[i].bytes = rec[i].bytes;
+        stats[i].flops = rec[i].flops; stats[i].bytes = rec[i].bytes; stats[i].flops_exec = rec[i].flops_exec;
         for (int k = 0; k < 3; ++k) stats[i].grid[k] = rec[i].grid[k];
     }
     *n_stats = n;
@@ -1791,11 +2041,14 @@ int ry_debug_stream_overlap(ry_ctx* ctx, int n, int us, float* ratio) {
 #endif
 }
 
+// diagnostics / tests: read the process-wide RY_* switches again (they are otherwise read when a context is created; launch plans built before keep
+// their choices until ry_net_set_dtype drops them)
+int ry_debug_reload_env(void) { return read_env_switches(); }
+
 // diagnostics: the plan (tile, external splits, K groups, estimated time) the stage-2 planner picks for one layer shape
 int ry_debug_plan_igemm(int M, int Cout, int nphases, int nk, int* tile, int* splits, int* kgroups, double* est_us) {
     if (!tile || !splits || !kgroups) return fail(RY_EINVAL, "null argument");
     if (M < 1 || Cout < 64 || Cout % 64 != 0 || nphases < 1 || nk < 1) return fail(RY_EINVAL, "not an implicit-GEMM layer shape");
-    RY_TRY(read_env_switches());
     Layer l; l.cout = Cout;
     *tile = 0; *splits = 0; *kgroups = 0;
     choose_igemm(l, M, nphases, nk, tile, splits, kgroups);
@@ -1812,7 +2065,6 @@ int ry_debug_plan_igemm_bf16(int mode, int M, int Cout, int nphases, int nk, int
     if (mode != 1 && mode != 2) return fail(RY_EINVAL, "mode must be 1 (bf16) or 2 (split-bf16)");
     if (!tile || !splits || !kgroups) return fail(RY_EINVAL, "null argument");
     if (M < 1 || Cout < 64 || Cout % 64 != 0 || nphases < 1 || nk < 1) return fail(RY_EINVAL, "not an implicit-GEMM layer shape");
-    RY_TRY(read_env_switches());
     Layer l; l.cout = Cout;
     choose_igemm(l, M, nphases, nk, tile, splits, kgroups, mode);
     if (est_us) {
@@ -1827,7 +2079,6 @@ int ry_debug_plan_igemm_bf16(int mode, int M, int Cout, int nphases, int nk, int
 int ry_debug_plan_os2(int M, int Cout, int nphases, int units, int* mt4, int* nt4, int* waves, int* depth, double* cost) {
     if (!mt4 || !nt4 || !waves || !depth) return fail(RY_EINVAL, "null argument");
     if (M < 1 || Cout < 4 || Cout % 4 != 0 || nphases < 1 || units < 1) return fail(RY_EINVAL, "not an output-stationary layer shape");
-    RY_TRY(read_env_switches());
     if (!choose_os2(M, Cout, nphases, units, mt4, nt4, waves, depth, cost))
         return fail(RY_EINVAL, "no output-stationary slice for %d rows x %d channels x %d units", M, Cout, units);
     return RY_OK;
@@ -1915,6 +2166,18 @@ int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin
     if ((path == PATH_IGEMM_BF16 || path == PATH_IGEMM_X3) && !(l.wig && Cin % 64 == 0)) return fail(RY_EINVAL, "bf16 implicit-GEMM path needs Cin %% 64 == 0 and Cout %% 64 == 0");
     lp.path = path ? path : (l.wig ? PATH_IGEMM : PATH_DIRECT);
     if (path == PATH_IGEMM_X3) { lp.path = PATH_IGEMM_BF16; lp.x3 = true; }
+    if (path == PATH_WINO) {                 // `tile` = cfg + 16 mbw (zeros: the planner's choice); `splits` external split-K (0: the planner's)
+        if (!wino_eligible(l, 2)) return fail(RY_EINVAL, "the Winograd path is the k4 s2 p1 layer with Cin %% 16 == 0 and Cout %% 64 == 0");
+        const int Mh = transposed ? H : lp.Ho, Mw = transposed ? Wd : lp.Wo;
+        int c[3] = {tile & 15, (tile >> 4) & 15, splits};
+        if (!choose_wino(Mh, Mw, Cout, transposed ? 4 : 1, (transposed ? 1 : 4) * (Cin / 16), B, &c[0], &c[1], &c[2]))
+            return fail(RY_EINVAL, "no Winograd plan %d:%d:%d for a %d x %d grid", c[0], c[1], c[2], Mh, Mw);
+        lp.wino_cfg = c[0]; lp.wino_mbw = c[1]; splits = c[2];
+        std::vector<float> w;
+        relayout_wino(l, [&](int n, int cc, int ky, int kx) { return (double)w2d_at(l, Wt, n, cc, ky, kx); }, w);
+        RY_TRY(upload(arena, ctx, w, &l.wwin));
+        tile = 0;
+    }
     if (path == PATH_OS2D) {                 // `tile` = mt4 + 16 nt4 + 256 waves + 8192 depth (zeros: the planner's choice)
         if (!l.w2os) return fail(RY_EINVAL, "output-stationary path needs Cin %% 256 == 0 and Cout %% 4 == 0");
         const TapTable t = make_taps(l);
@@ -1926,8 +2189,9 @@ int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin
         tile = 0;
     }
     const size_t out_elems = (size_t)B * lp.Ho * lp.Wo * Cout;
-    lp.splits = 1;
+    lp.splits = path == PATH_WINO ? splits : 1;
     lp.last_rows = lp.Ho; lp.last_cols = lp.Wo; lp.last_exp = 0;
+    if (path == PATH_WINO && lp.splits > 1) RY_TRY(arena.alloc(&lp.slabs, out_elems * lp.splits));
     if (lp.path == PATH_IGEMM || lp.path == PATH_IGEMM_BF16) {
         const TapTable t = make_taps(l);
         const int M = B * (transposed ? H * Wd : lp.Ho * lp.Wo);
@@ -2000,7 +2264,7 @@ int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin
         RT_TRY(rt::h2d(dx, x16.data(), x16.size() * sizeof(unsigned short), ctx->stream));
         RT_TRY(rt::stream_sync(ctx->stream));
         RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Cin, nullptr, 0, 0.2f));
-    } else if (lp.path == PATH_OS2D && Cin % 512 == 0) {
+    } else if ((lp.path == PATH_OS2D && Cin % 512 == 0) || (lp.path == PATH_WINO && Cin % 32 == 0)) {
         // exercise the un-materialised skip concat: the channels are handed over as two half-width sources, each followed by its zero pixel
         const int Ch = Cin / 2;
         const size_t npix = (size_t)B * H * Wd;

@@ -37,6 +37,11 @@ class Context(object):
     def stream(self) -> int:
         return int(self.lib.dll.ry_stream(self.handle) or 0)
 
+    def reload_env(self):
+        """Read the process-wide RY_* switches again (`ry_debug_reload_env`; tests and A/B scripts).  Launch plans that exist keep their choices until
+        `Net.set_dtype` drops them."""
+        self.lib.check(self.lib.dll.ry_debug_reload_env())
+
     def timer_start(self):
         self.lib.check(self.lib.dll.ry_timer_start(self.handle))
 
@@ -105,8 +110,11 @@ class Context(object):
         y = numpy.empty((B, max(Ho, 0), max(Wo, 0), Cout), dtype=numpy.float32)
         bnv = None if bn is None else numpy.ascontiguousarray(numpy.concatenate([numpy.ravel(v) for v in bn]), dtype=numpy.float32)
         bv = None if b is None else numpy.ascontiguousarray(b, dtype=numpy.float32)
-        pth = {'auto': 0, 'igemm': 1, 'direct': 2, 'first': 3, 'last': 4, 'igemm_bf16': 5, 'igemm_x3': 6, 'os': 7}[path]
-        if path == 'os':         # output-stationary weight-streaming kernel: tile = (mt4, nt4, waves, depth), zeros / None = the planner's choice
+        pth = {'auto': 0, 'igemm': 1, 'direct': 2, 'first': 3, 'last': 4, 'igemm_bf16': 5, 'igemm_x3': 6, 'os': 7, 'wino': 8}[path]
+        if path == 'wino':       # Winograd F(2x2, 2x2) form of a k4 s2 p1 layer: tile = (cfg, mbw): workgroup shape (1: 2x2 waves, 2: 4x2 waves) and M-blocks per tile row; zeros / None = the planner's choice
+            c = tuple(tile or ()) + (0, 0)
+            tcode = int(c[0]) + 16 * int(c[1])
+        elif path == 'os':         # output-stationary weight-streaming kernel: tile = (mt4, nt4, waves, depth), zeros / None = the planner's choice
             c = tuple(tile or ()) + (0, 0, 0, 0)
             tcode = int(c[0]) + 16 * int(c[1]) + 256 * int(c[2]) + 8192 * int(c[3])
         else:
@@ -439,5 +447,5 @@ class Net(object):
         else:
             self.ctx.lib.check(self.ctx.lib.dll.ry_net_profile(self.handle, batch, frames, reps, stats, 96, ctypes.byref(n)))
         return [dict(name=stats[i].name.decode(), layer=stats[i].layer.decode(), ms=float(stats[i].ms),
-                     flops=float(stats[i].flops), bytes=float(stats[i].bytes), grid=tuple(stats[i].grid))
+                     flops=float(stats[i].flops), bytes=float(stats[i].bytes), grid=tuple(stats[i].grid), flops_exec=float(stats[i].flops_exec))
                 for i in range(n.value)]

@@ -24,7 +24,7 @@ sp = synth.stage2_input(N)[0]
 
 
 def reread():
-    ctx.lib.check(ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    ctx.reload_env()
 
 
 def replay_ms(reps=40):

@@ -89,6 +89,38 @@ CONV2D_OS_CASES = [
 ]
 
 
+# ry_wino_ldsdma, the k4 s2 p1 layers in Winograd F(2x2, 2x2) form (round 6): tile = (cfg, mbw): cfg 1 = 2 x 2 waves (M-tile of two 8 x 16-pixel blocks,
+# 64 channels), cfg 2 = 4 x 2 waves (four blocks); mbw = blocks per tile row.  Cin % 32 == 0 cases are handed over as two half-width sources.
+CONV2D_WINO_CASES = [
+    (1, 8, 32, 16, 64, 4, 2, 1, True, 'relu', 'wino', (1, 2), 1),      # sub-pixel deconvolution, ONE 8 x 32 tile per phase, one 16-channel patch, single source: image borders on every side
+    (1, 16, 16, 32, 64, 4, 2, 1, True, 'relu', 'wino', (1, 1), 1),     # 16 x 16 tile, two sources of 16 channels
+    (1, 16, 32, 64, 128, 4, 2, 1, True, 'lrelu', 'wino', (1, 2), 2),   # two tile rows, two channel tiles, external split of 2 + 2 patches (slabs + reduce)
+    (1, 32, 64, 32, 64, 4, 2, 1, False, 'lrelu', 'wino', (1, 2), 1),   # k4 s2 convolution: four parity planes per chunk accumulate in the transform domain, 16 x 32 outputs
+    (2, 32, 32, 48, 64, 4, 2, 1, False, None, 'wino', (1, 1), 3),      # batch 2, 12 (chunk, parity) patches over 3 splits, single source of 48 channels
+    (1, 8, 64, 16, 64, 4, 2, 1, True, 'relu', 'wino', (2, 4), 1),      # eight waves: 8 x 64 tile
+    (1, 16, 32, 32, 64, 4, 2, 1, True, 'relu', 'wino', (2, 2), 1),     # 16 x 32 tile
+    (1, 32, 16, 64, 128, 4, 2, 1, True, 'lrelu', 'wino', (2, 1), 2),   # 32 x 16 tile, split-K
+    (1, 32, 64, 32, 64, 4, 2, 1, False, 'lrelu', 'wino', (2, 2), 1),   # convolution on eight waves
+    (2, 64, 32, 48, 64, 4, 2, 1, False, None, 'wino', (2, 1), 3),
+    (1, 32, 64, 80, 128, 4, 2, 1, True, 'relu', 'wino', (1, 2), 0),    # 5 patches (odd iteration counts per buffer), the planner's split
+    (1, 48, 64, 16, 64, 4, 2, 1, False, 'relu', 'wino', None, 0),      # the planner's everything: 24 x 32 outputs
+    (1, 24, 32, 64, 64, 4, 2, 1, True, None, 'wino', (1, 2), 4),       # 3 tile rows, one patch per split
+]
+
+
+def wino_vs_direct(ctx, transposed, seed=41):
+    """The Winograd form against the direct implicit GEMM of the same operator on trained-like magnitudes (activations after a ReLU, filters ~ N(0, 0.02)):
+    -> (max |y_wino - y_direct| / max |y_direct|, max |y_direct|)"""
+    rng = numpy.random.default_rng(seed)
+    B, H, W_, Cin, Cout = (1, 16, 32, 128, 64) if transposed else (1, 32, 64, 128, 64)      # a 16 x 32 grid of the stencil either way
+    x = numpy.maximum(rng.normal(size=(B, H, W_, Cin)), 0).astype('f4')
+    Wt = rng.normal(0, 0.02, size=(Cin, Cout, 4, 4) if transposed else (Cout, Cin, 4, 4)).astype('f4')
+    kw = dict(stride=2, pad=1, transposed=transposed, act=None)
+    yd = ctx.conv2d(x, Wt, None, None, path='igemm', **kw)
+    yw = ctx.conv2d(x, Wt, None, None, path='wino', **kw)
+    return float(numpy.abs(yw - yd).max() / numpy.abs(yd).max()), float(numpy.abs(yd).max())
+
+
 def os_identity_rows(ctx):
     """1x1 'conv' = plain GEMM with one-hot rows on the output-stationary path: pixel i selects input channel 65 i mod 1024, so every K block,
     every K step of a unit and several units are hit.  -> (y [16][16], W rows expected)"""
@@ -271,7 +303,7 @@ def poisoned_converts(ctx, net, sizes, monkeypatch, modes=('f32', 'bf16', 'bf16x
     row / pixel / channel its producer did not write in THIS forward (dead-row crop, row ranges of a discard, skipped fp32 copies of the bf16
     modes) turns the result into NaN instead of depending on what the allocator handed out.  -> [(n, mode, NaNs, NaNs in the kept rows of a discard)]"""
     import ctypes
-    reread = lambda: ctx.lib.check(ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    reread = lambda: ctx.reload_env()
     out = []
     try:
         monkeypatch.setenv('RY_POISON', '1'); reread()

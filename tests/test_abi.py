@@ -150,17 +150,17 @@ def test_stage2_planner_near_tie_goes_to_the_small_workgroup(lib, monkeypatch):
         return t.value, s.value, k.value, e.value
     d3, c4, c5, d2 = (768, 512, 4, 128), (1536, 512, 1, 256), (384, 512, 1, 256), (192, 512, 4, 128)
     try:
-        monkeypatch.setenv('RY_KG_SLABS', '0')
+        monkeypatch.setenv('RY_KG_SLABS', '0'); lib.check(lib.dll.ry_debug_reload_env())
         old = {n: plan(*sh) for n, sh in (('d3', d3), ('c4', c4), ('c5', c5), ('d2', d2))}
         assert all(v[2] == 2 and v[1] > 1 for v in old.values()), old
-        monkeypatch.delenv('RY_KG_SLABS')
+        monkeypatch.delenv('RY_KG_SLABS'); lib.check(lib.dll.ry_debug_reload_env())
         new = {n: plan(*sh) for n, sh in (('d3', d3), ('c4', c4), ('c5', c5), ('d2', d2))}
         assert new['d3'][2] == 1 and new['d3'][1] == 2 * old['d3'][1] and new['d3'][3] <= 1.01 * old['d3'][3], (old, new)
         assert plan(1024, 512, 4, 128)[2] == 1                       # the same layer at 400 frames
         assert all(new[n][:3] == old[n][:3] for n in ('c4', 'c5', 'd2')), (old, new)
     finally:
         monkeypatch.delenv('RY_KG_SLABS', raising=False)
-        plan(*d3)
+        lib.check(lib.dll.ry_debug_reload_env())
 
 
 def test_stage2_planner_rejects_non_igemm_shapes(lib):

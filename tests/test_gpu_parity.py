@@ -101,6 +101,45 @@ def test_conv2d_os_full_size_gpu(gpu_ctx, case):
         assert rel_max(y, r) < cases.TOL
 
 
+@pytest.mark.parametrize('case', cases.CONV2D_WINO_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_wino_gpu(gpu_ctx, case):
+    """ry_wino_ldsdma (round 6): the k4 s2 p1 layers in Winograd F(2x2, 2x2) form on v_mfma_f32_32x32x2_f32, nine accumulator blocks per wave."""
+    y, r = cases.run_conv2d(gpu_ctx, numpy.random.default_rng(23), case, bn_params)
+    assert rel_max(y, r) < 1e-5
+
+
+@pytest.mark.parametrize('transposed', [True, False])
+def test_conv2d_wino_vs_direct_gpu(gpu_ctx, transposed):
+    err, scale = cases.wino_vs_direct(gpu_ctx, transposed)
+    assert err < 1e-5 and scale > 0.1, (err, scale)
+
+
+WINO_FULL_SIZE = [        # the eight MFMA-bound layers of SYN-64 at the 300-frame window (T = 384), the planner's plan: B, H, W, Cin, Cout, transposed
+    (1, 384, 512, 64, 128, False), (1, 192, 256, 128, 256, False), (1, 96, 128, 256, 512, False), (1, 48, 64, 512, 512, False),      # encoder c1 .. c4
+    (1, 24, 32, 1024, 512, True), (1, 48, 64, 1024, 256, True), (1, 96, 128, 512, 128, True), (1, 192, 256, 256, 64, True),          # decoder c3 .. c6
+    (2, 48, 64, 1024, 256, True),                                                                                                     # two windows per call
+]
+
+
+@pytest.mark.parametrize('case', WINO_FULL_SIZE, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_wino_full_size_gpu(gpu_ctx, case):
+    """BASELINE layer sizes on trained-like magnitudes (inputs behind a ReLU, filters ~ N(0, 0.02), BatchNormalization): against the direct implicit
+    GEMM of the same operator (1e-5: the verdict's bar for the Winograd form), both workgroup shapes; run twice: deterministic."""
+    B, H, W_, Cin, Cout, tr = case
+    rng = numpy.random.default_rng(61)
+    x = numpy.maximum(rng.normal(size=(B, H, W_, Cin)), 0).astype('f4')
+    Wt = rng.normal(0, 0.02, size=(Cin, Cout, 4, 4) if tr else (Cout, Cin, 4, 4)).astype('f4')
+    b = rng.normal(0, 0.1, Cout).astype('f4')
+    bn = bn_params(rng, Cout)
+    kw = dict(stride=2, pad=1, transposed=tr, act='relu' if tr else 'lrelu')
+    yd = gpu_ctx.conv2d(x, Wt, b, bn, path='igemm', **kw)
+    for tile in (None, (2, 0)):
+        y = gpu_ctx.conv2d(x, Wt, b, bn, path='wino', tile=tile, **kw)
+        y2 = gpu_ctx.conv2d(x, Wt, b, bn, path='wino', tile=tile, **kw)
+        assert numpy.array_equal(y, y2)
+        assert rel_max(y, yd) < 1e-5, (case, tile, rel_max(y, yd))
+
+
 def test_mfma_4x4x1_block_map_is_transpose_detecting(gpu_ctx):
     """Asymmetric 1x1 'conv' = plain GEMM with identity rows on the output-stationary path: catches a swapped row / column map of the sixteen
     4 x 4 blocks of v_mfma_f32_4x4x1_16B_f32 (registers = rows = pixels, lanes = columns = output channels) and a wrong K position of a block."""
@@ -201,15 +240,17 @@ def test_stage2_syn64_convert(syn64, n_frames):
     assert numpy.array_equal(y[:, -1], y[:, -2]), "pad(mode='edge') repeats the last predicted bin"
 
 
+@pytest.mark.parametrize('wino', ['1', '0'], ids=['winograd', 'direct'])
 @pytest.mark.parametrize('n_frames', [300, 100, 257, 383, 600])
-def test_stage2_dead_row_crop_is_bit_identical(syn64, gpu_ctx, monkeypatch, n_frames):
+def test_stage2_dead_row_crop_is_bit_identical(syn64, gpu_ctx, monkeypatch, n_frames, wino):
     """Decoder layers of a single padded window skip the rows that only feed the padding `SuperResolution.convert` crops away
     (DESIGN.md 5.1): every kept element must be bit-identical to the run that computes all padded rows, whichever layers are cropped
     (1 = only the layers it speeds up by themselves; 2 = every decoder layer the rule allows, the default)."""
     import ctypes
     _, (n2, _) = syn64
     sp = synth.stage2_input(n_frames)[0]
-    reread = lambda: gpu_ctx.lib.check(gpu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    reread = lambda: gpu_ctx.reload_env()
+    monkeypatch.setenv('RY_WINOGRAD', wino)                            # (round 6: in Winograd form -- the default -- and with the direct kernels)
     try:
         out, out3 = {}, []
         for mode in ('0', '1', '2'):
@@ -225,19 +266,21 @@ def test_stage2_dead_row_crop_is_bit_identical(syn64, gpu_ctx, monkeypatch, n_fr
             assert numpy.array_equal(o, out3[0]) and numpy.array_equal(o[2], o[0])
             assert float(numpy.abs(o[0] / out['0'] - 1).max()) < 1e-5          # a batch may run under another plan: summation order only
     finally:
-        monkeypatch.delenv('RY_S2_CROP', raising=False)
+        monkeypatch.delenv('RY_S2_CROP', raising=False); monkeypatch.delenv('RY_WINOGRAD', raising=False)
         reread(); n2.set_dtype('f32')
 
 
+@pytest.mark.parametrize('wino', ['1', '0'], ids=['winograd', 'direct'])
 @pytest.mark.parametrize('n_frames', [300, 100, 257, 130, 600])
-def test_stage2_identical_padding_rows_are_copied_bit_identical(syn64, gpu_ctx, monkeypatch, n_frames):
+def test_stage2_identical_padding_rows_are_copied_bit_identical(syn64, gpu_ctx, monkeypatch, n_frames, wino):
     """Behind the real frames the padded window is copies of one row, so every encoder layer has output rows that are equal bit for bit; the implicit
     GEMM leaves whole tile rows of that stretch out of its grid and ry_rep_rows copies the row above them (RY_S2_HOLE, default on): bit-identical to
     the run that computes them -- launch by launch, under graph replay, three windows per call -- and the grids of encoder c1 / c2 shrink."""
     import ctypes
     _, (n2, _) = syn64
     sp = synth.stage2_input(n_frames)[0]
-    reread = lambda: gpu_ctx.lib.check(gpu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    reread = lambda: gpu_ctx.reload_env()
+    monkeypatch.setenv('RY_WINOGRAD', wino)                            # (round 6: in Winograd form -- the default -- and with the direct kernels)
     try:
         out, out3, grids = {}, {}, {}
         for mode in ('0', '1'):
@@ -262,10 +305,14 @@ def test_stage2_identical_padding_rows_are_copied_bit_identical(syn64, gpu_ctx, 
             assert numpy.array_equal(o16['0'], o16['1']), (n_frames, dtype)
         if n_frames == 300:             # 40 of 192 rows of encoder c1 are identical: five tile rows of six rows (30 rows) go; 19 of 96 of c2: two tile rows
             assert grids['1'][('encoder/c1', 'ry_rep_rows')] > 0 and grids['1'][('encoder/c2', 'ry_rep_rows')] > 0
-            assert grids['1'][('encoder/c1', 'ry_igemm_ldsdma')] == 432 and grids['0'][('encoder/c1', 'ry_igemm_ldsdma')] == 512
-            assert grids['1'][('encoder/c2', 'ry_igemm_ldsdma')] == 224 and grids['0'][('encoder/c2', 'ry_igemm_ldsdma')] == 256
+            if wino == '0':
+                assert grids['1'][('encoder/c1', 'ry_igemm_ldsdma')] == 432 and grids['0'][('encoder/c1', 'ry_igemm_ldsdma')] == 512
+                assert grids['1'][('encoder/c2', 'ry_igemm_ldsdma')] == 224 and grids['0'][('encoder/c2', 'ry_igemm_ldsdma')] == 256
+            else:                       # 8-row Winograd tiles: 32 of the 40 identical rows of encoder c1, 16 of the 19 of c2 are left out of the grids
+                for layer in ('encoder/c1', 'encoder/c2'):
+                    assert grids['1'][(layer, 'ry_wino_ldsdma')] < grids['0'][(layer, 'ry_wino_ldsdma')], (layer, grids)
     finally:
-        monkeypatch.delenv('RY_S2_HOLE', raising=False)
+        monkeypatch.delenv('RY_S2_HOLE', raising=False); monkeypatch.delenv('RY_WINOGRAD', raising=False)
         reread(); n2.set_dtype('f32')
 
 

@@ -43,6 +43,19 @@ def test_conv2d_os_identity_rows_emu(emu_ctx):
     assert numpy.array_equal(y, ref)
 
 
+@pytest.mark.parametrize('case', cases.CONV2D_WINO_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_wino_emu(emu_ctx, case):
+    """the Winograd F(2x2, 2x2) kernel (ry_wino_ldsdma): patch layout + swizzle, in-register input transform, nine accumulator blocks, output transform"""
+    y, r = cases.run_conv2d(emu_ctx, numpy.random.default_rng(23), case, bn_params)
+    assert rel_max(y, r) < 1e-5
+
+
+@pytest.mark.parametrize('transposed', [True, False])
+def test_conv2d_wino_vs_direct_emu(emu_ctx, transposed):
+    err, scale = cases.wino_vs_direct(emu_ctx, transposed)
+    assert err < 1e-5 and scale > 0.1, (err, scale)
+
+
 @pytest.mark.parametrize('case', cases.CONV2D_DILATED_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
 def test_conv2d_dilated_emu(emu_ctx, case):
     y, r = cases.run_conv2d_dilated(emu_ctx, numpy.random.default_rng(19), case, bn_params)
@@ -205,7 +218,7 @@ def test_stage2_identical_padding_rows_emu(emu_ctx, monkeypatch):
     """The encoder's rows behind the real frames that equal the row above them are copied, not computed (RY_S2_HOLE): split-free implicit-GEMM layers
     leave whole tile rows out of their grids; bit-identical to computing them, also around a discard and for two windows per call."""
     import ctypes
-    reread = lambda: emu_ctx.lib.check(emu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    reread = lambda: emu_ctx.reload_env()
     d = NetDesc(2, 1, 1, 64, 3)
     P = synthetic_params(d, 451, bias_std=0.05)
     sp = numpy.exp(numpy.random.default_rng(72).normal(-6.0, 1.5, (70, 65))).astype('f4')
@@ -229,12 +242,63 @@ def test_stage2_identical_padding_rows_emu(emu_ctx, monkeypatch):
         monkeypatch.delenv('RY_S2_HOLE', raising=False); monkeypatch.delenv('RY_PLAN', raising=False); reread()
 
 
+def test_stage2_winograd_layers_emu(emu_ctx, monkeypatch):
+    """Round 6: the k4 s2 p1 layers with enough rows run in Winograd F(2x2, 2x2) form (PATH_WINO) inside the predictor -- convolutions over four parity
+    planes, sub-pixel deconvolutions over a two-source skip concat -- in the convert wrapper with the copied padding rows, the dead-row crop, a discard and
+    two windows per call (bit-identical among themselves); RY_WINOGRAD=0 is the direct form of the same predictor (1e-5 apart, both on the oracle)."""
+    d = NetDesc(2, 1, 1, 64, 3)
+    P = synthetic_params(d, 451, bias_std=0.05)
+    sp = numpy.exp(numpy.random.default_rng(72).normal(-6.0, 1.5, (70, 65))).astype('f4')
+    ref = unet.stage2_convert(sp, P, 3)
+    wino = lambda net: {q['layer'] for q in net.profile(1, 70, 1, window=True) if q['name'].startswith('ry_wino_ldsdma<')}
+    try:
+        monkeypatch.setenv('RY_WINO_MINM', '1'); emu_ctx.reload_env()
+        net = engine.Net(emu_ctx, d, flatten_params(d, P), width=64)
+        y = net.convert(sp)
+        assert wino(net) == {'encoder/c1', 'encoder/c2', 'decoder/c5', 'decoder/c6'}
+        st = net.profile(1, 70, 1, window=True)
+        assert all(abs(q['flops_exec'] - (q['flops'] * 9 / 16 if q['name'].startswith('ry_wino') else q['flops'])) <= 1e-6 * q['flops'] for q in st), st
+        assert float(numpy.abs(y / ref - 1).max()) < cases.TOL
+        monkeypatch.setenv('RY_WINOGRAD', '0'); emu_ctx.reload_env(); net.set_dtype('f32')
+        assert not wino(net)
+        yd = net.convert(sp)
+        assert 0 < float(numpy.abs(y / yd - 1).max()) < 2e-5 and float(numpy.abs(yd / ref - 1).max()) < cases.TOL
+        # both workgroup shapes, split-free so that the encoder's identical padding rows are left out of the grids (ry_rep_rows)
+        for spec in ('1:1:2:2,2:1:1:1,13:1:1:1,14:1:2:1', '1:2:2:1,2:2:1:1,13:2:1:2,14:2:2:1'):      # (encoder c1 of the first: copied rows AND an external split -- reduce node, then copy node)
+            monkeypatch.setenv('RY_WINOGRAD', '1'); monkeypatch.setenv('RY_WINO', spec); monkeypatch.delenv('RY_S2_HOLE', raising=False)
+            emu_ctx.reload_env(); net.set_dtype('f32')
+            names = {q['layer']: q['name'] for q in net.profile(1, 70, 1, window=True) if q['name'].startswith('ry_wino')}
+            cfg = spec.split(',')[0].split(':')[1]
+            assert names['encoder/c1'] == ('ry_wino_ldsdma<2,2,1,2>' if cfg == '1' else 'ry_wino_ldsdma<4,2,2,2>') and names['decoder/c6'][-3:] == ',1>', names
+            if cfg == '1':       # (8-row tiles: rows 40 .. 55 of encoder c1 are whole tile rows inside the stretch of identical rows; the 16-row tiles of the other spec have none)
+                assert {q['layer'] for q in net.profile(1, 70, 1, window=True) if q['name'] == 'ry_rep_rows'} >= {'encoder/c1'}
+            y1 = net.convert(sp)
+            assert float(numpy.abs(y1 / ref - 1).max()) < cases.TOL
+            part = net.convert(sp, discard=(20, 30))
+            two = net.convert(numpy.stack([sp, sp[::-1]]))
+            assert numpy.array_equal(part[20:40], y1[20:40]) and float(numpy.abs(two[1] / unet.stage2_convert(sp[::-1], P, 3) - 1).max()) < cases.TOL
+            monkeypatch.setenv('RY_S2_HOLE', '0'); monkeypatch.setenv('RY_S2_CROP', '0'); emu_ctx.reload_env(); net.set_dtype('f32')
+            assert not [q for q in net.profile(1, 70, 1, window=True) if q['name'] == 'ry_rep_rows']
+            assert numpy.array_equal(net.convert(sp), y1)                    # computing the copied rows and the cropped rows changes nothing
+            assert numpy.array_equal(net.convert(numpy.stack([sp, sp[::-1]])), two)       # (two windows per call: the planner's splits of the other layers may differ from one window's)
+            monkeypatch.delenv('RY_S2_HOLE'); monkeypatch.delenv('RY_S2_CROP')
+        # a forced plan that does not exist is refused
+        monkeypatch.setenv('RY_WINO', '1:1:4:1'); emu_ctx.reload_env()
+        with pytest.raises(RuntimeError, match='RY_WINO'):
+            net.set_dtype('f32'); net.convert(sp)
+        net.close()
+    finally:
+        for k in ('RY_WINO_MINM', 'RY_WINOGRAD', 'RY_WINO', 'RY_S2_HOLE', 'RY_S2_CROP'):
+            monkeypatch.delenv(k, raising=False)
+        emu_ctx.reload_env()
+
+
 def test_stage2_output_stationary_layers_emu(emu_ctx, monkeypatch):
     """Round 5: layers with few rows per phase and the ry_c2d_os filter layout run output-stationary (PATH_OS2D: one node, no slabs) inside the
     predictor -- k4 s2 convolutions, sub-pixel deconvolutions over a two-source skip concat -- next to implicit-GEMM neighbours, in the
     convert wrapper with the dead-row crop / a discard (bit-identical kept rows), and as producers of split-bf16 copies in 'bf16x3' mode."""
     import ctypes
-    reread = lambda: emu_ctx.lib.check(emu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    reread = lambda: emu_ctx.reload_env()
     d = NetDesc(2, 1, 1, 64, 3)
     P = synthetic_params(d, 451, bias_std=0.05)
     x = numpy.random.default_rng(71).normal(size=(1, 16, 16)).astype('f4')
@@ -300,7 +364,7 @@ def test_stage2_dead_row_crop_emu(emu_ctx, monkeypatch):
     d = NetDesc(2, 1, 1, 64, 3)
     P = synthetic_params(d, 433, bias_std=0.05)
     net = engine.Net(emu_ctx, d, flatten_params(d, P), width=16)
-    reread = lambda: emu_ctx.lib.check(emu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    reread = lambda: emu_ctx.reload_env()
     try:
         for n in (11,):
             sp = numpy.exp(numpy.random.default_rng(40 + n).normal(-6.0, 1.5, (n, 17))).astype('f4')
@@ -358,7 +422,7 @@ def test_autotuned_plans_stay_correct_emu(emu_ctx, monkeypatch):
     net = engine.Net(emu_ctx, d, flatten_params(d, P), width=16)
     x = numpy.random.default_rng(31).normal(size=(1, 8, 16)).astype('f4')
     ref = cases.oracle_forward(d, P, x)
-    reread = lambda: emu_ctx.lib.check(emu_ctx.lib.dll.ry_debug_plan_igemm(64, 128, 1, 16, *(ctypes.byref(ctypes.c_int()) for _ in range(3)), None))
+    reread = lambda: emu_ctx.reload_env()
     monkeypatch.setenv('RY_X3_MINM', '1')
     base = {}
     for mode in ('f32', 'bf16x3'):
