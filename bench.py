@@ -747,12 +747,14 @@ def main(argv=None):
                             s['flops'] / max(s['ms'], 1e-9) / 1e9, s['bytes'] / max(s['ms'], 1e-9) / 1e6))
         fam = {}
         for s in st2 + st1:
-            f = fam.setdefault(s['name'], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-            f['ms'] += s['ms']; f['flops'] += s['flops']; f['bytes'] += s['bytes']; f['launches'] += 1
+            f = fam.setdefault(s['name'], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, exec=0.0))
+            f['ms'] += s['ms']; f['flops'] += s['flops']; f['bytes'] += s['bytes']; f['launches'] += 1; f['exec'] += s.get('flops_exec', s['flops'])
         # dominant kernel = the family with the most time in the stage that bounds the step (stage 2; stage 1 overlaps on its own stream)
         st2_names = set(s['name'] for s in st2)
         dname, dv = max(((k, v) for k, v in fam.items() if k in st2_names), key=lambda kv: kv[1]['ms'])
-        ach = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
+        # `achieved` / `frac` count the matrix-pipe FLOPs the launches EXECUTE (round 6: the Winograd F(2x2, 2x2) kernels run 9 / 16 of the direct
+        # convolution's products -- ry_kernel_stat.flops_exec); the SURVEY 8(d) direct-convolution figure stays beside it as `frac_algorithmic`
+        ach = dv['exec'] / (dv['ms'] * 1e-3) / 1e12
         pmc, pmc_file = pmc_table()
         rpf, rpf_file = rocprof_table()
         targs = dname[dname.find('<') + 1:-1].split(',') if dname.startswith('ry_igemm_ldsdma<') else []
@@ -763,7 +765,7 @@ def main(argv=None):
         ach_ev = ach
         rp_us = rpf.get(dname.replace(' ', ''))
         if rp_us:
-            ach = dv['flops'] / dv['launches'] / (rp_us * 1e-6) / 1e12
+            ach = dv['exec'] / dv['launches'] / (rp_us * 1e-6) / 1e12
         out['roofline'] = {'kernel': dname, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                            'frac': round(ach / peak_tf, 4),
                            'frac_source': ('%s: avg %.3f us per launch (rocprofv3 --kernel-trace --stats, one window at a time); this run: box %s, %s, frac_events' % (rpf_file, rp_us, os.uname().nodename, time.strftime('%Y-%m-%d', time.gmtime()))) if rp_us
@@ -774,23 +776,30 @@ def main(argv=None):
                            'traffic_unit': 'HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)',
                            'traffic_source': pmc_file, 'source_hash': source_hash(),
                            'launches': dv['launches'], 'avg_launch_ms': round(dv['ms'] / dv['launches'], 4),
-                           'alg_flops_per_launch': dv['flops'] / dv['launches'], 'alg_bytes_per_launch': dv['bytes'] / dv['launches']}
+                           'alg_flops_per_launch': dv['flops'] / dv['launches'], 'alg_bytes_per_launch': dv['bytes'] / dv['launches'],
+                           'exec_flops_per_launch': dv['exec'] / dv['launches'],
+                           'frac_algorithmic': round(ach / peak_tf * dv['flops'] / max(dv['exec'], 1.0), 4),
+                           'flops_basis': 'achieved / frac: matrix-pipe FLOPs the launches execute (Winograd F(2x2, 2x2): 9 products per 2 x 2 outputs of a 2 x 2-tap stencil instead of 16); '
+                                          'frac_algorithmic: the direct-convolution FLOPs of SURVEY.md 8(d) over the same time'}
         # the other MFMA-bound families of the forward, same arithmetic (rocprofv3 average of this source where there is one, else this run's HIP events):
         # which family carries the most time can change with the plans (round 5: decoder c3 moved from the <..,2,false,1> to the <..,1,false,1> family)
         others = {}
-        for k, v in sorted(((k, v) for k, v in fam.items() if k in st2_names and k != dname and k.startswith('ry_igemm_ldsdma<') and v['flops'] > 0),
+        for k, v in sorted(((k, v) for k, v in fam.items() if k in st2_names and k != dname and k.startswith(('ry_igemm_ldsdma<', 'ry_wino_ldsdma<')) and v['flops'] > 0),
                            key=lambda kv: -kv[1]['ms'])[:4]:
             us = rpf.get(k.replace(' ', '')) or v['ms'] / v['launches'] * 1e3
-            others[k] = {'launches': v['launches'], 'avg_launch_us': round(us, 2), 'frac': round(v['flops'] / v['launches'] / (us * 1e-6) / 1e12 / peak_tf, 4)}
+            others[k] = {'launches': v['launches'], 'avg_launch_us': round(us, 2), 'frac': round(v['exec'] / v['launches'] / (us * 1e-6) / 1e12 / peak_tf, 4),
+                         'frac_algorithmic': round(v['flops'] / v['launches'] / (us * 1e-6) / 1e12 / peak_tf, 4)}
         out['roofline']['other_families'] = others
         if args.dtype == 'bf16x3' and is_bf16:
             out['roofline']['mfma_flops_per_alg_flop'] = 3
         alg2 = net_flops(d2, T, synth.FFT_BINS - 1)
         pk2 = F32_MFMA_PEAK_TF if args.dtype == 'f32' else 2500.0
-        run2 = sum(s['flops'] for s in st2)                              # what the launches execute: decoder rows that only feed the cropped padding are skipped
+        run2 = sum(s.get('flops_exec', s['flops']) for s in st2)         # what the launches execute: decoder rows that only feed the cropped padding are skipped, Winograd layers run 9 / 16 of their products
+        run2_alg = sum(s['flops'] for s in st2)                          # the same rows as direct convolutions (SURVEY.md 8(d) formula)
         out['roofline_stage2_forward'] = {'bound': 'mfma', 'achieved': round(run2 / (s2_ms * 1e-3) / 1e12, 2), 'peak': pk2,
                                           'unit': 'TFLOP/s', 'frac': round(run2 / (s2_ms * 1e-3) / 1e12 / pk2, 4),
-                                          'executed_gflop': round(run2 / 1e9, 3), 'padded_forward_gflop': round(alg2 / 1e9, 3),
+                                          'frac_algorithmic': round(run2_alg / (s2_ms * 1e-3) / 1e12 / pk2, 4),
+                                          'executed_gflop': round(run2 / 1e9, 3), 'direct_form_gflop': round(run2_alg / 1e9, 3), 'padded_forward_gflop': round(alg2 / 1e9, 3),
                                           'frac_if_all_padded_rows_counted': round(alg2 / (s2_ms * 1e-3) / 1e12 / pk2, 4),
                                           'note': 'FLOPs the stage-2 launches execute / graph replay time of the whole forward (end layers, reduces and launches included); '
                                                   'padded_forward_gflop is the forward over all T padded rows, which the reference computes and then crops'}
@@ -850,9 +859,9 @@ def compact_line(out, details):
     if 'roofline' in out:
         line['roofline'] = pick(out['roofline'], ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_source', 'frac_events', 'frac_rocprof',
                                                   'traffic', 'traffic_source', 'source_hash', 'launches', 'avg_launch_ms', 'alg_flops_per_launch',
-                                                  'alg_bytes_per_launch', 'mfma_flops_per_alg_flop', 'other_families'))
+                                                  'alg_bytes_per_launch', 'exec_flops_per_launch', 'frac_algorithmic', 'mfma_flops_per_alg_flop', 'other_families'))
     if 'roofline_stage2_forward' in out:
-        line['roofline_stage2_forward'] = pick(out['roofline_stage2_forward'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'executed_gflop', 'padded_forward_gflop'))
+        line['roofline_stage2_forward'] = pick(out['roofline_stage2_forward'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_algorithmic', 'executed_gflop', 'direct_form_gflop', 'padded_forward_gflop'))
     if 'roofline_stage1' in out:
         line['roofline_stage1'] = pick(out['roofline_stage1'], ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_graph_cold', 'traffic',
                                                                 'alg_bytes_per_forward', 'kernel_ms_per_forward'))
