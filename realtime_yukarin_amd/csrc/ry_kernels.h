@@ -716,13 +716,17 @@ struct RyWinoParams {
     int dbg_flags;              // diagnostics (WRONG results): 4 skip the output stores, 8 skip the K loop, 128 skip the loads in the K loop
 };
 
+#ifndef RY_WINO_ABL
+#define RY_WINO_ABL 0     // diagnostic builds only (scripts/gpu_r6_abl.sh, WRONG results): 1 no input transform, 2 no patch fragment reads, 4 no filter fragment reads, 8 no barrier in the K loop, 32 no MFMAs
+#endif
 template <int WM, int WN, int NSL, int MODE>
 RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int NPOS = WM == 2 ? 304 : 592;          // patch positions per A buffer: 17 x 17 / 9 x 33 (WM = 2), 17 x 33 / 33 x 17 / 9 x 65 (WM = 4), rounded up to whole DMA pieces
     constexpr int AG = NPOS / 16;                      // 1-KiB DMA pieces per patch (16 positions x 64 bytes)
     constexpr int AI = (AG + NW - 1) / NW;
-    constexpr int AH = NSL == 1 ? (AI + 1) / 2 : AI;   // pieces of the next patch issued in the first iteration of the current one
+    constexpr int AH = AI;                             // pieces of the next patch issued in the first iteration of the current one: all of them (NSL = 1: they have the second iteration to land)
+    constexpr int AFLY = AG / NW;                      // patch pieces EVERY wave issues behind its filter pieces (the waves with a piece more wait for their first one too)
     constexpr int BSL = 9 * WN * 256;                  // floats of one filter slice (8 channels x 9 positions x 32 WN output channels)
     constexpr int BG = NSL * 9 * WN;                   // DMA pieces per iteration
     constexpr int BI = (BG + NW - 1) / NW;
@@ -875,6 +879,8 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     __syncthreads();
 
+    // ONE code path per unrolled iteration (the requests of the next iteration sit behind wave-uniform branches): a variant per request pattern as a
+    // compile-time argument made hipcc 7.2 keep the 144 accumulator registers of the variants in different places and spill them at the joins.
     auto run_it = [&](auto k4c, int k) {
         constexpr int K4 = decltype(k4c)::value;
         constexpr int SL = NSL == 1 ? (K4 & 1) : 0;                       // slice of the patch this iteration starts with
@@ -889,31 +895,65 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
         if (more_a && SL == 0) next_patch();
         // DMA pieces of the next iteration (filters) and of the next patch (its first AH pieces with the first slice, the rest with the second), one per position
         constexpr int A_LO = SL == 0 ? 0 : AH, A_HI = SL == 0 ? AH : AI, NITEM = BI + (A_HI - A_LO);
-        auto issue = [&](int step) {
-            if (step < BI) { if (more_b) b_item(step, Bn); }
-            else if (step < NITEM) { if (more_a) a_item(A_LO + step - BI, An); }
+        auto issue1 = [&](int item) {
+            if (item < BI) { if (more_b) b_item(item, Bn); }
+            else if (item < NITEM) { if (more_a) a_item(A_LO + item - BI, An); }
+        };
+        auto issue = [&](int step) {                   // in order -- filters first (needed at the next barrier), then the patch --, spread evenly over the position steps
+#pragma unroll
+            for (int item = (step * NITEM) / (9 * NSL); item < ((step + 1) * NITEM) / (9 * NSL); ++item) issue1(item);
         };
 #pragma unroll
         for (int s = 0; s < NSL; ++s) {
             f32x4 v[9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) v[q] = ry_ld4(Ac + (aaddr[q] ^ ((SL + s) * 8)));
+            for (int q = 0; q < 9; ++q) {
+                if (RY_WINO_ABL & 2) { const float c = (float)(aaddr[q] + SL + s); v[q] = f32x4{c, c, c, c}; }
+                else v[q] = ry_ld4(Ac + (aaddr[q] ^ ((SL + s) * 8)));
+            }
+            // MFMA order: the three positions of a row TOGETHER, K step by K step -- consecutive MFMAs go to different accumulators.  (The first form ran the four
+            // K steps of one position back to back: every VALU / LDS / DMA instruction the scheduler placed between two MFMAs on the SAME accumulator cost
+            // ~43 cycles (MI355X_MICROARCH.md, cycle constants) -- the input transform alone 13 % of a launch, scripts/gpu_r6_abl.sh.)  The filter fragments
+            // of the next row are requested before the MFMAs of this one.
+            auto ldb = [&](int q) -> f32x4 {
+                if (RY_WINO_ABL & 4) { const float c = (float)(lane + SL + q); return f32x4{c, c, c, c}; }
+                return ry_ld4(Bc + s * BSL + (q * WN + wn) * 256 + lane * 4);
+            };
+            f32x4 bfa[3], bfb[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bfa[j] = ldb(j);
             // V = B^T d B: rows, then columns
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { v[j] -= v[3 + j]; v[6 + j] -= v[3 + j]; }
+            for (int j = 0; j < 3; ++j) { if (RY_WINO_ABL & 1) break; v[j] -= v[3 + j]; v[6 + j] -= v[3 + j]; }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { v[3 * i] -= v[3 * i + 1]; v[3 * i + 2] -= v[3 * i + 1]; }
+            for (int i = 0; i < 3; ++i) { if (RY_WINO_ABL & 1) break; v[3 * i] -= v[3 * i + 1]; v[3 * i + 2] -= v[3 * i + 1]; }
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const f32x4 bf = ry_ld4(Bc + s * BSL + (q * WN + wn) * 256 + lane * 4);
-                issue(s * 9 + q);
+            for (int i = 0; i < 3; ++i) {
+                f32x4 (&bc)[3] = (i & 1) ? bfb : bfa;
+                f32x4 (&bn)[3] = (i & 1) ? bfa : bfb;
+                if (i + 1 < 3) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[q] = ry_mfma_32x32x2(v[q][t], bf[t], acc[q]);
+                    for (int j = 0; j < 3; ++j) bn[j] = ldb(3 * (i + 1) + j);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int q = 3 * i + j;
+                        if (j == 0 && t < 3) issue(s * 9 + 3 * i + t);      // the DMA requests: one step in front of each of the first three K steps of a row
+                        if (RY_WINO_ABL & 32) acc[q][t] += v[q][t] * bc[j][t];
+                        else acc[q] = ry_mfma_32x32x2(v[q][t], bc[j][t], acc[q]);
+                    }
+                }
             }
         }
-        static_assert(NITEM <= 9 * NSL, "one DMA piece per position step");
+        static_assert(NITEM <= 18 * NSL, "at most two DMA pieces per position step");
         if (more_b) wt_it += NSL * BSL;
-        __syncthreads();                       // the DMA of iteration k + 1 landed (vmcnt) and this iteration's buffers are free again
+        // The filters of iteration k + 1 have to be in the LDS behind this barrier; the pieces of the next patch, requested BEHIND them, are read two barriers
+        // from here (NSL = 1) and may stay in flight: vmcnt counts this wave's requests in order, AFLY of the youngest are patch pieces in every wave.
+        // (A __syncthreads() here drains every request: the landing time of the youngest -- activations out of another XCD's L2 -- was exposed at every barrier.)
+        if (NSL == 1 && SL == 0 && more_a) ry_own_dma_landed<AFLY>(); else ry_own_dma_landed<0>();
+        if (!(RY_WINO_ABL & 8)) ry_lds_barrier();      // this wave's fragment reads are done (lgkmcnt), every wave's filters landed: the buffers of iteration k are free again
     };
     for (int k = 0; k < nit; k += 4) {
         run_it(RyConst<0>(), k);

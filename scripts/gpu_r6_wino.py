@@ -24,6 +24,7 @@ OUT = sys.argv[2] if len(sys.argv) > 2 else str(ROOT / 'gpurun_out' / ('r6_wino_
 REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 NAMES = ['encoder/c%d' % i for i in range(8)] + ['decoder/c%d' % i for i in range(8)]
 LAYERS = tuple(int(v) for v in os.environ.get('SWEEP_LAYERS', '12,13,14,11,1,2,3,4').split(',') if v.strip().isdigit())
+BY_FORWARD = os.environ.get('SWEEP_BY', 'forward') == 'forward'       # rank a layer's plans by the graph-replayed forward they give (default) or by the layer's own eager launches
 EMU = bool(os.environ.get('SWEEP_EMU'))                             # flow check on the CPU emulator (numbers mean nothing)
 SPLITS = tuple(int(v) for v in os.environ.get('SWEEP_SPLITS', '0,1,2,3,4,5,6,8').split(','))
 CONFIGS = [(c, m, s) for c in (1, 2) for m in ((1, 2) if c == 1 else (1, 2, 4)) for s in SPLITS]
@@ -142,14 +143,15 @@ for layer in LAYERS:
                 say('%-11s cfg %d mbw %d splits %d: %s' % (NAMES[layer], c[0], c[1], c[2], str(e)[:120]))
             continue
         us, names = lu[NAMES[layer]]
-        rows.append((us, c, names))
-        say('%-11s cfg %d mbw %d splits %2d  %7.2f us  (direct %7.2f)   %s' % (NAMES[layer], c[0], c[1], c[2], us, base[NAMES[layer]][0], ' + '.join(names)))
+        fwd = forward_alone(20) * 1e3                                # the whole stage-2 forward under graph replay with this one layer in Winograd form
+        rows.append((fwd if BY_FORWARD else us, c, names))
+        say('%-11s cfg %d mbw %d splits %2d  %7.2f us  (direct %7.2f)  forward %8.2f us (direct %8.2f)   %s' % (NAMES[layer], c[0], c[1], c[2], us, base[NAMES[layer]][0], fwd, f0 * 1e3, ' + '.join(names)))
     if rows:
         rows.sort()
         best[layer] = rows[0]
-        say('# best %-11s cfg %d mbw %d splits %d: %.2f us against %.2f direct' % ((NAMES[layer],) + rows[0][1] + (rows[0][0], base[NAMES[layer]][0])))
+        say('# best %-11s cfg %d mbw %d splits %d: %.2f us against %.2f direct' % ((NAMES[layer],) + rows[0][1] + (rows[0][0], f0 * 1e3 if BY_FORWARD else base[NAMES[layer]][0])))
 if best:
-    spec = ','.join('%d:%d:%d:%d' % ((l,) + best[l][1]) if best[l][0] < base[NAMES[l]][0] else '%d:0' % l for l in sorted(best))
+    spec = ','.join('%d:%d:%d:%d' % ((l,) + best[l][1]) if best[l][0] < (f0 * 1e3 if BY_FORWARD else base[NAMES[l]][0]) else '%d:0' % l for l in sorted(best))
     setup(spec)
     yb = result()
     fb = forward_alone()
