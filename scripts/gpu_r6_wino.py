@@ -27,7 +27,8 @@ LAYERS = tuple(int(v) for v in os.environ.get('SWEEP_LAYERS', '12,13,14,11,1,2,3
 BY_FORWARD = os.environ.get('SWEEP_BY', 'forward') == 'forward'       # rank a layer's plans by the graph-replayed forward they give (default) or by the layer's own eager launches
 EMU = bool(os.environ.get('SWEEP_EMU'))                             # flow check on the CPU emulator (numbers mean nothing)
 SPLITS = tuple(int(v) for v in os.environ.get('SWEEP_SPLITS', '0,1,2,3,4,5,6,8').split(','))
-CONFIGS = [(c, m, s) for c in (1, 2) for m in ((1, 2) if c == 1 else (1, 2, 4)) for s in SPLITS]
+CFGS = tuple(int(v) for v in os.environ.get('SWEEP_CFGS', '1,2,3,4').split(','))     # 1: 2 x 2 waves, 2: 4 x 2 waves (two slices per barrier), 3 / 4: two channel blocks per wave, one wave per SIMD (2 x 2 / 4 x 1 waves)
+CONFIGS = [(c, m, s) for c in CFGS for m in ((1, 2) if c in (1, 3) else (1, 2, 4)) for s in SPLITS]
 
 (d1, P1), (d2, P2) = synth.model_params('SYN-8' if EMU else 'SYN-64')
 if EMU:

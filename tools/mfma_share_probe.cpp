@@ -36,6 +36,24 @@ __global__ __launch_bounds__(512, 2) void probe(const float* in, float* out, uns
                 if (SELF == 5) { x[q & 3] -= y[(q + 1) & 3]; y[q & 3] -= x[(q + 2) & 3]; x[(q + 1) & 3] -= y[(q + 2) & 3]; y[(q + 3) & 3] -= x[q & 3];
                                  x[(q + 2) & 3] -= y[q & 3]; y[(q + 1) & 3] -= x[(q + 3) & 3]; x[(q + 3) & 3] -= y[(q + 1) & 3]; y[(q + 2) & 3] -= x[(q + 1) & 3]; }   // eight
             }
+            if (SELF == 6) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { x[q & 3] -= y[(q + 1) & 3]; y[q & 3] -= x[(q + 2) & 3]; }
+            }
+            if (SELF == 7) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    f32x2 a2 = {x[0], x[1]}, b2 = {y[2], y[3]}, c2 = {x[2], x[3]}, d2 = {y[0], y[1]};
+                    a2 -= b2; c2 -= d2; x[0] = a2[0]; x[1] = a2[1]; x[2] = c2[0]; x[3] = c2[1];
+                    f32x2 e2 = {y[0], y[1]}, f2 = {y[2], y[3]};
+                    e2 -= c2; f2 -= a2; y[0] = e2[0]; y[1] = e2[1]; y[2] = f2[0]; y[3] = f2[1];
+                }
+            }
+            if (SELF == 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y += *(const f32x4*)&L[((ii + q * 64) & 8191) * 4];
+            }
         }
         const unsigned long long t1 = clock64();
         float s = x[0] + y[1] + (float)ii;
@@ -45,11 +63,12 @@ __global__ __launch_bounds__(512, 2) void probe(const float* in, float* out, uns
         if (lane == 0) atomicAdd((int*)&done, 1);
     } else {
         f32x4 x = *(const f32x4*)&L[lane * 4], y = *(const f32x4*)&L[lane * 4 + 256];
-        int ii = lane, k = 0;
+        int ii = lane, k = 0, npart = 0;
         f32x16 acc[4];
         for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         if (MODE != 0) {
             while (done < 4) {
+                ++npart;
                 for (int u = 0; u < 16; ++u) {
                     if (MODE == 1) {
 #pragma unroll
@@ -70,12 +89,14 @@ __global__ __launch_bounds__(512, 2) void probe(const float* in, float* out, uns
                 }
             }
         }
+        if (lane == 0 && wave == 4) cyc[blockIdx.x * 16 + 15] = (unsigned long long)npart;        // partner loop bodies executed while the MFMA waves ran
         float s = x[0] + x[1] + x[2] + x[3] + y[0] + y[1] + y[2] + y[3] + (float)ii + (float)k;
         for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
         out[blockIdx.x * 512 + tid] = s;
     }
 }
 
+static double g_part = 0;
 template <int MODE, int SELF>
 void run(const char* name, const float* din, float* dout, unsigned long long* dcyc) {
     const int blocks = 256, n = 16384;
@@ -98,10 +119,12 @@ void run(const char* name, const float* din, float* dout, unsigned long long* dc
             sp += (double)(hi - lo);
         }
         s /= blocks; sp /= blocks;
+        if (MODE != 9 && MODE != 0) { double np = 0; for (int b = 0; b < blocks; ++b) np += (double)h[b * 16 + 15]; g_part = np / blocks; }
         if (s < best) best = s;
         if (sp < best_pair) best_pair = sp;
     }
     if (MODE == 9) printf("%-58s older wave %6.1f cycles per MFMA; both waves done after %6.1f cycles per MFMA PAIR (128 = pipe full)\n", name, best / n, best_pair / n);
+    else if (MODE != 0) printf("%-58s %6.1f cycles per MFMA of the timed wave (64 = the pipe's rate); partner: %.0f loop bodies = one per %.1f cycles\n", name, best / n, g_part, best / g_part);
     else printf("%-58s %6.1f cycles per MFMA of the timed wave (64 = the pipe's rate)\n", name, best / n);
 }
 
@@ -122,6 +145,11 @@ int main() {
     run<1, 1>("two fp32 VALU behind every MFMA + fp32 VALU partner", din, dout, dcyc);
     run<0, 4>("alone, four fp32 VALU behind every MFMA", din, dout, dcyc);
     run<0, 5>("alone, eight fp32 VALU behind every MFMA", din, dout, dcyc);
+    run<0, 6>("alone, 8 MFMAs then 16 fp32 VALU in one block", din, dout, dcyc);
+    run<0, 7>("alone, 8 MFMAs then 32 packed-fp32 VALU in one block", din, dout, dcyc);
+    run<0, 8>("alone, 8 MFMAs then 8 ds_read_b128 + add in one block", din, dout, dcyc);
+    run<9, 6>("both: 8 MFMAs then 16 fp32 VALU in one block", din, dout, dcyc);
+    run<9, 8>("both: 8 MFMAs then 8 ds_read_b128 + add in one block", din, dout, dcyc);
     printf("-- both waves of a SIMD run the SAME loop (cycles per MFMA of one wave: 128 = the pipe shared evenly and full)\n");
     run<9, 0>("both: bare MFMAs", din, dout, dcyc);
     run<9, 1>("both: two fp32 VALU behind every MFMA", din, dout, dcyc);
