@@ -552,7 +552,7 @@ static bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int
                 if ((*waves != 0 && *waves != cw) || (*depth != 0 && *depth != cd) || U % (4 * cw) != 0 || !os2_has_config(m, n, cw, cd)) continue;
                 w = cw; d = cd;
             }
-            if (w == 0 && (*waves != 0 || *depth != 0))                  // a forced pair outside the preference lists
+            if (w == 0 && *waves != 0 && *depth != 0)                    // a forced pair outside the preference lists (only one of the two forced and no preferred pair fits: no plan)
                 if (U % (4 * *waves) == 0 && os2_has_config(m, n, *waves, *depth)) { w = *waves; d = *depth; }
             if (w == 0) continue;
             const double wgs = (double)((M + 4 * m - 1) / (4 * m)) * (N / (4 * n)) * nphases;
@@ -583,6 +583,8 @@ static int launch_c2d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     if (!l.w2os || C1 % 256 || C2 % 256 || l.cout % NT || U % (4 * lp.os2_waves) || (size_t)C1 > ZTAIL || (size_t)C2 > ZTAIL)
         return fail(RY_ESTATE, "%s: not a shape for the output-stationary kernel (slice %dx%d, %d waves, depth %d)", l.name, lp.os2_mt4, lp.os2_nt4, lp.os2_waves, lp.os2_depth);
     if (p.M >= (1 << 24) || (long long)p.mtiles * p.ntiles * p.nphases >= (1 << 24)) return fail(RY_EINVAL, "%s: more than 2^24 rows or tiles in one launch", l.name);
+    if (((size_t)B * lp.Hi * lp.Wi * (size_t)(C1 > C2 ? C1 : C2) + ZTAIL) * 4 >= ((size_t)1 << 32))      // the kernel's pixel offsets (zp1 / zp2, its offset table) are 32-bit byte offsets
+        return fail(RY_EINVAL, "%s: a source of 4 GiB or more does not fit the output-stationary kernel's 32-bit offsets", l.name);
     p.zp1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C1 * 4); p.zp2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C2 * 4);
     p.inv_Mimg = 1.f / (float)(p.Mh * p.Mw); p.inv_Mw = 1.f / p.Mw; p.inv_mtiles = 1.f / p.mtiles; p.inv_ntiles = 1.f / p.ntiles; p.inv_cpt = 1.f / cpt;
     p.kw = l.deconv ? 2 : l.k; p.dil = l.deconv ? 1 : l.dil; p.inv_kw = 1.f / p.kw;

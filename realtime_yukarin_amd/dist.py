@@ -160,7 +160,12 @@ def _id_record_is_live(rec: bytes) -> bool:
         return False
     try:
         pid_s, start = rec[128:].decode().split()
-        return _proc_start(int(pid_s)) == start
+        if start == '0' or _proc_start(os.getpid()) is None:
+            return True              # the check cannot be made (the writer could not read /proc, or this reader cannot): accept, as before the check existed (round-5 advisor)
+        seen = _proc_start(int(pid_s))
+        if seen is None and not os.path.isdir('/proc/%d' % os.getppid()):
+            return True              # another PID namespace than the launcher's (containers sharing the runtime directory): /proc says nothing about the writer
+        return seen == start
     except (ValueError, UnicodeDecodeError):
         return False
 

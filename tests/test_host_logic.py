@@ -122,6 +122,12 @@ def test_rendezvous_record_of_a_dead_writer_is_not_an_id(monkeypatch):
         child.kill(); child.wait()
     assert not rdist._id_record_is_live(other)                                       # the writer is gone: a leftover
     assert not rdist._id_record_is_live(b'\x07' * 128) and not rdist._id_record_is_live(b'\x07' * 128 + b'garbage'.ljust(32, b' '))
+    # round-5 advisor: where the check cannot be made (the writer could not read /proc and wrote start '0', or this reader cannot read its own entry)
+    # the record is accepted, as before the check existed -- otherwise every other rank would spin for the full timeout
+    assert rdist._id_record_is_live(b'\x07' * 128 + b'999999 0'.ljust(32, b' '))
+    monkeypatch.setattr(rdist, '_proc_start', lambda pid: None)
+    assert rdist._id_record_is_live(other)
+    monkeypatch.undo()
     monkeypatch.delenv('RY_COMM_RENDEZVOUS', raising=False)
     monkeypatch.setenv('TORCHELASTIC_RESTART_COUNT', '0'); a = rdist._rendezvous_path()
     monkeypatch.setenv('TORCHELASTIC_RESTART_COUNT', '1'); b = rdist._rendezvous_path()
