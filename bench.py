@@ -88,7 +88,7 @@ def pmc_table():
     the current kernels exists -- traffic is then reported as null rather than read from an older build."""
     import glob
     want = source_hash()
-    for path in sorted(glob.glob(str(ROOT / 'profiles' / '*pmc_summary.txt')), reverse=True):
+    for path in sorted(glob.glob(str(ROOT / 'profiles' / '**' / '*pmc_summary.txt'), recursive=True), reverse=True):
         lines = open(path).read().splitlines()
         if not any(('source ' + want) in ln for ln in lines[:6]):
             continue
@@ -101,7 +101,7 @@ def pmc_table():
                 tab[cols[0]] = ((2.0 * float(cols[-2]) + float(cols[-1])) * 1024.0, float(cols[2]))
             except (ValueError, IndexError):
                 pass
-        return tab, Path(path).name
+        return tab, str(Path(path).relative_to(ROOT))
     return {}, None
 
 
@@ -111,7 +111,7 @@ def rocprof_table():
     the figure in the line can be recomputed from profiles/.  Empty when no summary of the current source exists."""
     import glob
     want = source_hash()
-    for path in sorted(glob.glob(str(ROOT / 'profiles' / '*kernel_stats.txt')), reverse=True):
+    for path in sorted(glob.glob(str(ROOT / 'profiles' / '**' / '*kernel_stats.txt'), recursive=True), reverse=True):
         lines = open(path).read().splitlines()
         if not any(('source ' + want) in ln for ln in lines[:3]):
             continue
@@ -127,8 +127,8 @@ def rocprof_table():
                 continue
             tab[name.replace('void ', '').replace(' ', '')] = avg
         import re
-        m = re.search(r'box (\S+) (\d{4}-\d\d-\d\d)', lines[0])          # where and when the summary was measured (scripts/gpu_r5_profile.sh)
-        return tab, Path(path).name + (' [measured on box %s, %s]' % m.groups() if m else '')
+        m = re.search(r'box (\S+) (\d{4}-\d\d-\d\d)', lines[0])          # where and when the summary was measured (scripts/gpu_profile.sh)
+        return tab, str(Path(path).relative_to(ROOT)) + (' [measured on box %s, %s]' % m.groups() if m else '')
     return {}, None
 
 
@@ -430,7 +430,7 @@ def main(argv=None):
                 step()
             primed['done'] = True
         # Python's cyclic collector runs on allocation counts: a generation-2 pass (34-38 ms here, torch's object graph) lands in whichever
-        # bracket the script's own history puts it -- round 3's single bracket, profiles/r04_driver_cmd.txt.  Everything allocated during
+        # bracket the script's own history puts it -- round 3's single bracket, profiles/r04/driver_cmd.txt.  Everything allocated during
         # set-up is collected once and frozen (moved out of the collector's sight); inside a bracket the collector is off (`bracket`).
         # BEFORE the warm-up: the collection itself idles the chip for those 35 ms, and what runs behind a pause runs slower for a while.
         gc.collect(); gc.freeze()
@@ -479,7 +479,7 @@ def main(argv=None):
         'brackets': [{'wall_ms': round(b[0] * 1e3, 3), 'enq_ms': round(b[1] * 1e3, 3), 'dev_ms': round(b[2], 3)} for b in brs],
         'spread': round((max(b[0] for b in brs) - min(b[0] for b in brs)) / elapsed, 4),
         'slow_brackets': [i for i, b in enumerate(brs) if b[0] > 1.2 * elapsed],
-        'gc': 'heap collected + frozen after set-up, collector off inside a bracket (a generation-2 pass is 34-38 ms: profiles/r04_driver_cmd.txt)',
+        'gc': 'heap collected + frozen after set-up, collector off inside a bracket (a generation-2 pass is 34-38 ms: profiles/r04/driver_cmd.txt)',
         # every frame handed to convert counts in `value`; ConvertStream keeps only the buffer in the middle of a
         # window with extra_time (convert_stream.py:40-42): effective x real-time = buffer_time / t_wall
         'x_realtime': round(value * 0.005, 1), 'x_realtime_per_gpu': round(value * 0.005 / world, 1),

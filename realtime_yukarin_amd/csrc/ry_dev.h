@@ -67,7 +67,7 @@ RY_DEV void ry_lds_barrier() {
 // A wave reads LDS bytes that its OWN earlier global_load_lds wrote, with AFTER younger vector-memory instructions of this wave allowed to be still
 // in flight: an explicit s_waitcnt, and nothing moves across it.  The compiler's own timing of such reads is not to be relied on -- hipcc 7.2 waited for
 // the DMA of the first KiB of a ring slot and read the second KiB, requested after that wait, with no wait at all (round 5, ry_c2d_os<2,2,8,2,true>:
-// NaNs in rows 4-7 of every tile on the MI355X, profiles/r05_n_xl.txt).  (The emulator runs the lanes one after the other: all of them past the copy first.)
+// NaNs in rows 4-7 of every tile on the MI355X, profiles/r05/n_xl.txt).  (The emulator runs the lanes one after the other: all of them past the copy first.)
 // every LDS read of this wave has delivered its registers; nothing moves across (what follows may overwrite the LDS bytes just read, by DMA)
 RY_DEV void ry_lds_reads_returned() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 template <int AFTER>

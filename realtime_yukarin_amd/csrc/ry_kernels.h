@@ -26,7 +26,7 @@
 //                       PRODUCER's split-sum + folded BN + activation (deferred epilogue; skip
 //                       connections read through two source descriptors, no materialised concat)
 //   ry_materialize      split-sum + folded BN + activation (+GLU) into a dense tensor
-//   ry_pad_min_rows / ry_pad_rows / ry_sr_post   the numpy.pad('minimum') / log / exp / edge-pad wrappers
+//   ry_pad_min_rows / ry_sr_post   the numpy.pad('minimum') / log / exp / edge-pad wrappers
 #pragma once
 #include "ry_dev.h"
 
@@ -133,7 +133,6 @@ struct RyIgemmParams {
                                 // padding that equal the row above them, filled in by ry_rep_rows (hole_nt = 0: none)
     int tw;                     // > 0: an M-tile is a 2-D block of (BM/tw) x tw rows of the Mh x Mw grid (compact input footprint:
                                 //      overlapping taps hit L2); 0: BM consecutive rows in raster order
-    int dbg_flags;              // diagnostics of ry_igemm_ldsdma (wrong results): 4 skip the output stores, 8 skip the K loop, 128 skip the loads in the K loop
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -159,19 +158,11 @@ struct RyIgemmParams {
 // are summed through the LDS at the end -- split-K without slabs in HBM or a reduce launch.
 // Epilogue: folded BN + activation in registers, 32 x 32 tiles transposed through the LDS, 16-byte stores (fp32 and / or a
 // bf16 copy for bf16 consumers), or raw split-K slabs.
-// dbg_flags (RY_IGEMM_DBG, diagnostics with wrong results): 4 skip the output stores, 8 skip the K loop, 128 skip the
-// loads inside the K loop.
 // ---------------------------------------------------------------------------------------------
 template <int V> struct RyConst { static constexpr int value = V; };
-#ifndef RY_BF16_ISSUE_STEPS
-#define RY_BF16_ISSUE_STEPS 1
-#endif
-#ifndef RY_F32_FRAG_PREFETCH
-#define RY_F32_FRAG_PREFETCH 0    // 1: experiment -- LDS fragments of K step s + 1 requested before the MFMAs of step s (fp32 patch loops)
-#endif
-#ifndef RY_F32_ISSUE_STEPS
-#define RY_F32_ISSUE_STEPS 4      // fp32: the DMA pieces of the next chunk are spread over this many of the 4 K steps of the current one
-#endif
+// K steps of an iteration over which the DMA pieces of the next one are spread: all four in fp32 (a burst in front of the MFMAs costs 5 %), the
+// first one in bf16 (DESIGN.md ledger: 4 / 2 / 1 steps -> 0.824 / 0.787 / 0.776 ms; fragments requested a K step ahead: no gain, round 4)
+constexpr int RY_F32_ISSUE_STEPS = 4, RY_BF16_ISSUE_STEPS = 1;
 
 template <int BM, int BN, int WM, int WN, int KG, bool BF16, int PATCH>
 RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
@@ -249,7 +240,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
     // K ranges are counted in units of one chunk (PATCH: one patch = four taps, so that every K group starts at tap 0)
     constexpr int KU = PATCH != 0 ? 4 : 1;
     const int kc_begin = split * p.kq + (split < p.krem ? split : p.krem);
-    const int wg_units = (p.dbg_flags & 8) ? 0 : p.kq + (split < p.krem ? 1 : 0);
+    const int wg_units = p.kq + (split < p.krem ? 1 : 0);
     const int g_begin = (kc_begin + (KG > 1 ? (wg_units >> 1) * grp : 0)) * KU;   // this K group's share: the first floor(n / 2) units, the rest
     const int nchunks = (KG > 1 ? (grp ? wg_units - (wg_units >> 1) : (wg_units >> 1)) : wg_units) * KU;
     const int max_chunks = ((wg_units + KG - 1) / KG) * KU;                // barrier count is the same for both groups
@@ -404,7 +395,7 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
             const float* Bc = BUF ? B1 : B0;
             float* An = BUF ? A0 : A1;
             float* Bn = BUF ? B0 : B1;
-            const bool more = (k + 1 < nchunks) && !pre2 && !(p.dbg_flags & 128);
+            const bool more = (k + 1 < nchunks) && !pre2;
             if (more) next_chunk();
             const float* Ab = Ac + ((wm * TM) * 32 + lr) * BK;
             if (KG == 1 || k < nchunks) {
@@ -505,8 +496,8 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
             const float* Bc = BBUF ? B1 : B0;
             float* An = ABUF ? A0 : A1;
             float* Bn = BBUF ? B0 : B1;
-            const bool more_b = (k + 1 < nchunks) && !(p.dbg_flags & 128);
-            const bool more_a = TAP == 0 && (k + 4 < nchunks) && !(p.dbg_flags & 128);
+            const bool more_b = k + 1 < nchunks;
+            const bool more_a = TAP == 0 && (k + 4 < nchunks);
             if (more_b) next_b();
             if (more_a) next_patch();
             if (KG == 1 || k < nchunks) {
@@ -524,33 +515,9 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
                     for (int q = (s * AI) / ISL; q < ((s + 1) * AI) / ISL; ++q) patch_item(q, An);
                 }
             };
-#if RY_F32_FRAG_PREFETCH
-            // experiment: the LDS fragments of K step s + 1 are requested before the MFMAs of step s (a second register set)
-            f32x4 afp[2][TM], bfp[2][TN];
-            auto ldfrag = [&](int s_, int set) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int pr = pbase[i] + TAPOFF;
-                    afp[set][i] = ry_ld4(Ac + pr * BK + (((2 * s_ + lh) ^ ((pr >> 1) & 7)) << 2));
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bfp[set][j] = ry_ld4(Bc + ((wn * TN + j) * 4 + s_) * 256 + lane * 4);
-            };
-            if (!BF16) ldfrag(0, 0);
-#endif
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 f32x4 af[TM], bf[TN];
-#if RY_F32_FRAG_PREFETCH
-                if (!BF16) {
-                    if (s + 1 < NS) ldfrag(s + 1, (s + 1) & 1);
-                    ry_sched_fence();
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af[i] = afp[s & 1][i];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[j] = bfp[s & 1][j];
-                } else
-#endif
                 {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -615,7 +582,6 @@ RY_KERNEL(256 * KG, 2) void ry_igemm_ldsdma(RyIgemmParams p) {
         ry_wave_sync();                        // the epilogue reuses this wave's region as its transposition scratch
     }
 
-    if (p.dbg_flags & 4) return;
     // ---- epilogue: folded BN + activation in registers, then every 32 x 32 accumulator tile is transposed through a
     // 4-KiB per-wave LDS scratch (the operand buffers are idle now) so that a lane holds 4 consecutive channels of one
     // pixel: 4 x 16-byte stores per tile instead of 16 x 4-byte ones, one row lookup per store.  (The scalar-store
@@ -713,12 +679,8 @@ struct RyWinoParams {
     int npatches;               // K axis in patches of 16 channels (MODE 2: x 4 parities, parity fastest)
     int kq, krem;               // patches per split: split s takes kq + (s < krem) patches starting at s * kq + min(s, krem)
     int hole_ty, hole_nt;       // as RyIgemmParams
-    int dbg_flags;              // diagnostics (WRONG results): 4 skip the output stores, 8 skip the K loop, 128 skip the loads in the K loop
 };
 
-#ifndef RY_WINO_ABL
-#define RY_WINO_ABL 0     // diagnostic builds only (scripts/gpu_r6_abl.sh, WRONG results): 1 no input transform, 2 no patch fragment reads, 4 no filter fragment reads, 8 no barrier in the K loop, 32 no MFMAs
-#endif
 template <int WM, int WN, int NSL, int MODE>
 RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -772,7 +734,7 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
 
     // K range of this workgroup, in patches and in iterations
     const int pbeg = split * p.kq + (split < p.krem ? split : p.krem);
-    const int npat = (p.dbg_flags & 8) ? 0 : p.kq + (split < p.krem ? 1 : 0);
+    const int npat = p.kq + (split < p.krem ? 1 : 0);
     const int nit = npat * (2 / NSL);
     // filters of this (phase, N-tile): consecutive slices are consecutive runs of BSL floats
     const float* wt_it = p.wt + ((size_t)(phase * p.ntiles + nt) * (size_t)(2 * p.npatches) + (size_t)(2 * pbeg)) * BSL;
@@ -889,9 +851,8 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
         const float* Bc = BBUF ? Bs1 : Bs0;
         float* An = ABUF ? As0 : As1;
         float* Bn = BBUF ? Bs0 : Bs1;
-        const bool loads = !(p.dbg_flags & 128);
-        const bool more_b = (k + 1 < nit) && loads;
-        const bool more_a = (k - SL + 2 / NSL < nit) && loads;            // a next patch exists
+        const bool more_b = k + 1 < nit;
+        const bool more_a = k - SL + 2 / NSL < nit;                       // a next patch exists
         if (more_a && SL == 0) next_patch();
         // DMA pieces of the next iteration (filters) and of the next patch (its first AH pieces with the first slice, the rest with the second), one per position
         constexpr int A_LO = SL == 0 ? 0 : AH, A_HI = SL == 0 ? AH : AI, NITEM = BI + (A_HI - A_LO);
@@ -908,15 +869,13 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
             f32x4 v[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
-                if (RY_WINO_ABL & 2) { const float c = (float)(aaddr[q] + SL + s); v[q] = f32x4{c, c, c, c}; }
-                else v[q] = ry_ld4(Ac + (aaddr[q] ^ ((SL + s) * 8)));
+                v[q] = ry_ld4(Ac + (aaddr[q] ^ ((SL + s) * 8)));
             }
             // MFMA order: the three positions of a row TOGETHER, K step by K step -- consecutive MFMAs go to different accumulators.  (The first form ran the four
             // K steps of one position back to back: every VALU / LDS / DMA instruction the scheduler placed between two MFMAs on the SAME accumulator cost
-            // ~43 cycles (MI355X_MICROARCH.md, cycle constants) -- the input transform alone 13 % of a launch, scripts/gpu_r6_abl.sh.)  The filter fragments
+            // ~43 cycles (MI355X_MICROARCH.md, cycle constants) -- the input transform alone 13 % of a launch, profiles/r06/wino_ablation.txt.)  The filter fragments
             // of the next row are requested before the MFMAs of this one.
             auto ldb = [&](int q) -> f32x4 {
-                if (RY_WINO_ABL & 4) { const float c = (float)(lane + SL + q); return f32x4{c, c, c, c}; }
                 return ry_ld4(Bc + s * BSL + (q * WN + wn) * 256 + lane * 4);
             };
             f32x4 bfa[3], bfb[3];
@@ -924,9 +883,9 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
             for (int j = 0; j < 3; ++j) bfa[j] = ldb(j);
             // V = B^T d B: rows, then columns
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { if (RY_WINO_ABL & 1) break; v[j] -= v[3 + j]; v[6 + j] -= v[3 + j]; }
+            for (int j = 0; j < 3; ++j) { v[j] -= v[3 + j]; v[6 + j] -= v[3 + j]; }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { if (RY_WINO_ABL & 1) break; v[3 * i] -= v[3 * i + 1]; v[3 * i + 2] -= v[3 * i + 1]; }
+            for (int i = 0; i < 3; ++i) { v[3 * i] -= v[3 * i + 1]; v[3 * i + 2] -= v[3 * i + 1]; }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 f32x4 (&bc)[3] = (i & 1) ? bfb : bfa;
@@ -941,8 +900,7 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
                     for (int j = 0; j < 3; ++j) {
                         const int q = 3 * i + j;
                         if (j == 0 && t < 3) issue(s * 9 + 3 * i + t);      // the DMA requests: one step in front of each of the first three K steps of a row
-                        if (RY_WINO_ABL & 32) acc[q][t] += v[q][t] * bc[j][t];
-                        else acc[q] = ry_mfma_32x32x2(v[q][t], bc[j][t], acc[q]);
+                        acc[q] = ry_mfma_32x32x2(v[q][t], bc[j][t], acc[q]);
                     }
                 }
             }
@@ -953,7 +911,7 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
         // from here (NSL = 1) and may stay in flight: vmcnt counts this wave's requests in order, AFLY of the youngest are patch pieces in every wave.
         // (A __syncthreads() here drains every request: the landing time of the youngest -- activations out of another XCD's L2 -- was exposed at every barrier.)
         if (NSL == 1 && SL == 0 && more_a) ry_own_dma_landed<AFLY>(); else ry_own_dma_landed<0>();
-        if (!(RY_WINO_ABL & 8)) ry_lds_barrier();      // this wave's fragment reads are done (lgkmcnt), every wave's filters landed: the buffers of iteration k are free again
+        ry_lds_barrier();      // this wave's fragment reads are done (lgkmcnt), every wave's filters landed: the buffers of iteration k are free again
     };
     for (int k = 0; k < nit; k += 4) {
         run_it(RyConst<0>(), k);
@@ -962,7 +920,6 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
         if (k + 3 < nit) run_it(RyConst<3>(), k + 3);
     }
 
-    if (p.dbg_flags & 4) return;
     // ---- epilogue: Y = A^T M A per lane, folded BN + activation, 32 x 32 transposition through a 4-KiB per-wave scratch, 16-byte stores ----
     float* outp = p.out + (p.splits > 1 ? (size_t)split * (size_t)p.slab_stride : (size_t)0);
     float* T = Bs0 + wave * 1024;
@@ -1131,8 +1088,6 @@ struct RyC2dOsParams {
     float slope;
     int mtiles, ntiles;         // tiles of 4 MT4 rows x 4 NT4 channels; 1-D grid, XCD-ordered: the M-tiles of one filter slice run on one XCD
     unsigned zp1, zp2;          // byte offset of the zeroed pixel behind each source
-    int dbg;                    // diagnostics (RY_OS2_DBG, WRONG results, timing only): 1 no pixel loads, 2 no filter loads, 4 no MFMAs, 8 no K loop at all,
-                                // 16 no offset table, 32 no reduction / stores
     int kw, dil;                // convolution: taps per kernel row, dilation (tap (ky, kx) reads input offset (ky, kx) * dil); the sub-pixel deconvolution
                                 // (ostride == 2) has 4 phases (py, px) of 2 x 2 taps (ty, tx) reading input offset py ? 1 - ty : -ty (likewise x)
     float inv_Mimg, inv_Mw, inv_mtiles, inv_ntiles, inv_cpt, inv_kw;
@@ -1174,11 +1129,6 @@ RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
     const int m0 = mt * MT, n0 = nt * NT;
     const int Mimg = p.Mh * p.Mw;
 
-#ifdef RY_OS2_DBG_BUILD                        // diagnostic build only (scripts/gpu_r5_os_ablate.py): the product carries no ablation branches in its K loop
-    const int dbg = p.dbg;
-#else
-    constexpr int dbg = 0;
-#endif
     constexpr int RND = 4;                     // units per round: a round never straddles a tap or a source (the host checks C1 / 64, C2 / 64, units per wave)
     static_assert(DEPTH == 2 || DEPTH == 4, "two or four units in flight");
     const int cpt1 = p.C1 >> 6, cpt = (p.C1 + p.C2) >> 6;
@@ -1191,7 +1141,7 @@ RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
     // Byte offset of the input pixel of (source, tap, row of the tile), or of the source's zero pixel when the tap falls outside the image
     // or the row outside the batch: a table in the LDS, filled once; the K loop reads MT4 entries when its tap or source changes.
     __shared__ unsigned otab[2 * 16 * MT];
-    if (!(dbg & 16)) {
+    {
         const int per_src = p.ntaps * MT;
         for (int e = tid; e < 2 * per_src; e += 64 * WAVES) {
             const int src = e >= per_src ? 1 : 0, e1 = e - src * per_src;
@@ -1212,7 +1162,7 @@ RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
 
     // state of the round being REQUESTED (wave-uniform): position in the run, its tap and first chunk, where its filters and pixels start
     // (every wave walks its run from the head: a rotated start -- waves spread over the offsets of their filter regions -- and non-temporal
-    // filter loads were measured as nulls, profiles/r05_b_*)
+    // filter loads were measured as nulls, profiles/r05/b_*)
     int r_rel = 0, r_tap = ry_fdiv(u0, cpt, p.inv_cpt), r_chunk = u0 - r_tap * cpt;
     int r_key = -1;
     unsigned pb[MT4];
@@ -1251,11 +1201,11 @@ RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
         for (int h = 0; h < NT4; ++h) acc[g][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto issue = [&](int d, int j) {                                // unit j of the round being requested -> slot d
-        if (!(dbg & 2)) {
+        {
 #pragma unroll
             for (int h = 0; h < NT4; ++h) wb[d][h] = ry_ld4(wr + j * 256 + (size_t)h * wh);
         }
-        if (!(dbg & 1)) {
+        {
             if (XL) {
                 float* const slot = (d == 0 ? xs0 : d == 1 ? xs1 : d == 2 ? xs2 : xs3) + wave * (MT4 * 256);
 #pragma unroll
@@ -1279,7 +1229,6 @@ RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
             ry_lds_reads_returned();
         }
         const int xd = XL ? 0 : d;
-        if (dbg & 4) return;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1290,7 +1239,7 @@ RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
 
     // Ring of DEPTH units: while unit j of a round is multiplied, unit j + DEPTH is requested -- the last DEPTH requests of a round already
     // belong to the next one, so the round state moves on at j = RND - DEPTH.  The last round requests nothing beyond the run.
-    if (!(dbg & 8)) {
+    {
         round_setup();
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) issue(d, d);
@@ -1308,7 +1257,6 @@ RY_KERNEL(64 * WAVES) void ry_c2d_os(RyC2dOsParams p) {
             if (j + DEPTH < RND) issue(j % DEPTH, j + DEPTH);
         }
     }
-    if (dbg & 32) return;
 
     // ---- sum over the sixteen K blocks (reduce-scatter: lane bits 2..5), then over the waves (LDS, fixed order) ----
     float v16[VP];
@@ -2164,7 +2112,7 @@ RY_KERNEL(256) void ry_rep_rows(RyRepRowsParams p) {     // grid: (pieces of a r
     img[(size_t)(p.dst0 + (int)blockIdx.y) * p.row_f4 + i] = img[(size_t)p.src * p.row_f4 + i];
 }
 
-// ry_pad_min_rows -- ry_colmin + ry_pad_rows in one launch (one graph node less on the convert path): a workgroup owns 16
+// ry_pad_min_rows -- column minimum + padded / logged rows in one launch (one graph node on the convert path): a workgroup owns 16
 // columns (16 row groups x 16 columns), takes their minimum over the real rows, then writes the padded / logged block.
 template <int G>                                              // G row groups x 16 columns = 16 G threads (G = 16 or 64)
 RY_KERNEL(16 * G) void ry_pad_min_rows(RyPadRowsParams p) {   // blockIdx.y = window of the batch
@@ -2198,17 +2146,6 @@ RY_KERNEL(16 * G) void ry_pad_min_rows(RyPadRowsParams p) {   // blockIdx.y = wi
     if (!cout_ok) return;
     const float fill = p.take_log ? logf(mm) : mm;
     for (int r = p.rows_in + grp; r < p.rows_out; r += G) out[(size_t)r * p.cols_out + c] = fill;
-}
-
-RY_KERNEL(256) void ry_pad_rows(RyPadRowsParams p) {  // blockIdx.y = window of the batch
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)p.rows_out * p.cols_out) return;
-    const int c = (int)(idx % p.cols_out);
-    const int r = (int)(idx / p.cols_out);
-    const float* in = p.in + (size_t)blockIdx.y * (size_t)p.in_bstride;
-    float v = (r < p.rows_in) ? in[(size_t)r * p.cols_in + c] : p.minv[(size_t)blockIdx.y * p.minv_bstride + c];
-    if (p.take_log) v = logf(v);
-    p.out[(size_t)blockIdx.y * (size_t)p.out_bstride + idx] = v;
 }
 
 struct RySrPostParams { const float* y; float* out; int rows, cols_in, cols_out; long long y_bstride, out_bstride; };

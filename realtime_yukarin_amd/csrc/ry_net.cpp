@@ -354,8 +354,6 @@ static void tile_dims(int tile, int* bm, int* bn) {
 // kernel, 256-row tiles, burst loads, raster tiles, two-graph cut + stagger, stage-1 tuning aids, ...): their measurements are in DESIGN.md.
 static int g_s2_hole = 1;     // RY_S2_HOLE=0: the encoder computes the identical padding rows behind the real frames instead of copying them (A/B, bit-identity tests)
 static int g_s2_crop = 2;     // RY_S2_CROP=0: every decoder layer of the convert wrapper computes all padded rows (A/B of the dead-row crop, used by the bit-identity tests); 1: only grids of more than one workgroup per CU
-static int g_igemm_dbg = 0;   // RY_IGEMM_DBG: ablation bits (diagnostics; WRONG results): ry_igemm_ldsdma 4 no stores, 8 no K loop, 128 no loads in the K loop;
-                              // stage-2 forward: 16 no split-K reduce launches, 32 no encoder c5 .. decoder c2 (scripts/gpu_r3_ablate.sh)
 static int g_force[16][3];    // RY_PLAN="layer:tile:splits:kgroups,...": tuning aid, fixes the stage-2 plan of single layers (0 = planner's choice)
 static int g_x3_min_m = 128;  // RY_X3_MINM: split-bf16 mode runs a layer on the bf16 pipe from this many GEMM rows (per phase) up (measured at 300 frames: 1 / 32 / 64 / 128 / 512 / 2048 -> 0.861 / 0.865 / 0.867 / 0.864 vs 0.840 / 0.928 ms per step on two boxes; 128 beat 512 by 1 % in the same-box A/B)
 static int g_autotune = 0;    // RY_AUTOTUNE="1[:reps[:max[:pick]]]": time candidate launch plans of every stage-2 implicit-GEMM layer on the device when a plan is built (autotune_plan)
@@ -385,7 +383,7 @@ static const char* tile_name(int tile, int kg, bool bf16, int patch) {
 // buffer, limited to 3 by its VGPR budget.
 static thread_local double g_plan_peak = 157.3e6;   // flop per microsecond the planner prices the main loop at (fp32 MFMA peak; bf16: see choose_igemm)
 static thread_local int g_plan_ck = 32;             // input channels per K chunk of the kernel being planned
-// split-bf16 kernels (measured, profiles/r01_n_x3_plansweep_n300.txt): the main-loop rate the planner prices them at (three times
+// split-bf16 kernels (measured, profiles/r01/n_x3_plansweep_n300.txt): the main-loop rate the planner prices them at (three times
 // the K of the bf16 mode per tile: the fixed costs weigh less, 128x128 tiles reach 730-800 TF of bf16 products = 0.7 x 1150),
 // and the price of two K groups in one 512-thread workgroup against two 256-thread workgroups on the same CU (the GEMM alone
 // ran 10-17 % slower: 69 vs 59 us on decoder c3, 73 vs 66 us on encoder c1).
@@ -436,7 +434,6 @@ static int best_split(long blocks, int bm, int bn, int nk, bool tinyM, int occ, 
     return best;
 }
 
-static int g_kg_slabs = 1;    // RY_KG_SLABS=0: the lone-time pick between two K groups per workgroup and an external split only stands even on a near-tie (A/B)
 
 static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, int* splits, int* kg, int bf16 = 0 /* 1 bf16, 2 split-bf16 */) {
     const bool kg_auto = *kg == 0, splits_auto = *splits == 0;
@@ -488,9 +485,9 @@ static void choose_igemm(const Layer& l, int M, int nphases, int nk, int* tile, 
     // Two K groups in one workgroup (8 waves, 125 KiB of LDS: nothing else fits beside it on a CU) exist to save slabs and reduce work.  Where the plan
     // needs an external split anyway and the external-split-only form (four-wave workgroups of 62 KiB: two of ANY two launches share a CU, which is what
     // the window on the other lane needs) is estimated within one per cent, take that form: a tie alone, and measured under two lanes (round 5,
-    // profiles/r05_r_plan_ab_n300.txt) decoder c3 -- the one layer this selects at 300 frames -- moves the step 1.1015 -> 1.0767 ms per window and ends
+    // profiles/r05/r_plan_ab_n300.txt) decoder c3 -- the one layer this selects at 300 frames -- moves the step 1.1015 -> 1.0767 ms per window and ends
     // the bimodal phase lock of the lanes; encoder c4 / c5 and decoder c2 (4 - 12 % apart by the estimate) gain nothing and stay.
-    if (g_kg_slabs && kg_auto && splits_auto && bf16 == 0 && *kg == 2 && *splits > 1 && M > 64) {
+    if (kg_auto && splits_auto && bf16 == 0 && *kg == 2 && *splits > 1 && M > 64) {
         double t1 = 0.0;
         const int s1 = best_split(blocks, bm, bn, nk, false, tile_occ(*tile, 1), 1, M, N, &t1);
         const double t2 = est_time(blocks, bm, bn, *splits, tile_occ(*tile, 2), 2, M, N, nk);
@@ -519,17 +516,15 @@ static bool os2_has_config(int mt4, int nt4, int waves, int depth) {
     return false;
 }
 
-static int g_os2_xl = 1;               // RY_OS2_XL=0: ry_c2d_os loads its pixels straight into registers (A/B of the LDS-DMA pixel path)
 // The LDS-DMA pixel path keeps one KiB per (wave, four tile rows, unit in flight): slices with two units in flight and at most 64 KiB of ring
 // (what the other window lane's kernels leave free on a CU).
 static constexpr bool os2_xl_ok(int mt4, int waves, int depth) { return depth == 2 && mt4 * waves <= 32; }
-static int g_os2_dbg = 0;              // RY_OS2_DBG: ablation bits of ry_c2d_os, honoured by -DRY_OS2_DBG_BUILD builds only (diagnostics, WRONG results): 1 no pixel loads, 2 no filter loads, 4 no MFMAs, 8 no K loop, 16 no offset table, 32 no reduction / stores
 static int g_os2_maxcost = 4608;       // RY_OS2_MAXCOST: a layer with the ry_c2d_os filter layout runs output-stationary when slice cost x K units stays below this (0: never).
                                        // Fitted: encoder c6 / decoder c1 at 300 frames (4096) win by 2-4 us, encoder c5 at 300 frames (10240) and decoder c2 at 100 frames (8192) lose by 8-11
 static int g_os2_force[16][4];         // RY_OS2="layer:mt4:nt4:waves:depth,...": tuning aid, fixes the slice of single layers ("layer:0" keeps that layer on the implicit GEMM)
 static bool g_os2_forced[16];
 
-// Slice of one layer, by a cost fitted to the slice sweeps on the MI355X (profiles/r05_e_os_sweep_n{300,100}.txt): a workgroup pulls K x (rows +
+// Slice of one layer, by a cost fitted to the slice sweeps on the MI355X (profiles/r05/e_os_sweep_n{300,100}.txt): a workgroup pulls K x (rows +
 // channels) of its tile through its CU's L1, the pixel rows at about half the rate of the filter rows (a wave-load of pixels is four
 // 256-byte pieces of four different pixels, a wave-load of filters one contiguous KiB), and the launch takes as many rounds as there are
 // workgroups per CU.  cost = max(1, workgroups / 256) x (2 rows + channels) of the tile (1.5 rows where the pixels travel by DMA); the sweeps rank the slices of every bottom layer in this
@@ -546,7 +541,7 @@ static bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int
             // the chain request -> landing -> MFMA at one or two workgroups per CU); whatever the run of K units feeds with whole rounds of four
             int w = 0, d = 0;
             static const int WD[4][2] = {{8, 2}, {4, 4}, {16, 2}, {8, 4}}, WD_BIG[4][2] = {{4, 4}, {8, 2}, {4, 2}, {8, 4}};
-            const bool big = m * n >= 12 && !(g_os2_xl && os2_xl_ok(m, 8, 2));        // (a large tile whose pixels go through the LDS keeps eight waves)
+            const bool big = m * n >= 12 && !os2_xl_ok(m, 8, 2);        // (a large tile whose pixels go through the LDS keeps eight waves)
             for (int k = 0; k < 4 && w == 0; ++k) {
                 const int cw = (big ? WD_BIG : WD)[k][0], cd = (big ? WD_BIG : WD)[k][1];
                 if ((*waves != 0 && *waves != cw) || (*depth != 0 && *depth != cd) || U % (4 * cw) != 0 || !os2_has_config(m, n, cw, cd)) continue;
@@ -556,7 +551,7 @@ static bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int
                 if (U % (4 * *waves) == 0 && os2_has_config(m, n, *waves, *depth)) { w = *waves; d = *depth; }
             if (w == 0) continue;
             const double wgs = (double)((M + 4 * m - 1) / (4 * m)) * (N / (4 * n)) * nphases;
-            const double px = g_os2_xl && os2_xl_ok(m, w, d) ? 6.0 : 8.0;      // pixel rows by DMA through the LDS: contiguous 256-byte pieces (encoder c6: 12 x 8 ahead of 8 x 16)
+            const double px = os2_xl_ok(m, w, d) ? 6.0 : 8.0;      // pixel rows by DMA through the LDS: contiguous 256-byte pieces (encoder c6: 12 x 8 ahead of 8 x 16)
             const double cost = (wgs > 256.0 ? wgs / 256.0 : 1.0) * (px * m + 4.0 * n) * ((double)((M + 4 * m - 1) / (4 * m)) * 4 * m / M);   // padded rows are loaded too
             if (cost < best - 1e-9) { best = cost; bm = m; bn = n; bw = w; bd = d; }
         }
@@ -588,18 +583,16 @@ static int launch_c2d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     p.zp1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C1 * 4); p.zp2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C2 * 4);
     p.inv_Mimg = 1.f / (float)(p.Mh * p.Mw); p.inv_Mw = 1.f / p.Mw; p.inv_mtiles = 1.f / p.mtiles; p.inv_ntiles = 1.f / p.ntiles; p.inv_cpt = 1.f / cpt;
     p.kw = l.deconv ? 2 : l.k; p.dil = l.deconv ? 1 : l.dil; p.inv_kw = 1.f / p.kw;
-    p.dbg = g_os2_dbg;
     const int total = p.mtiles * p.ntiles * p.nphases;
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
     char nm[48];
-    const bool xl = g_os2_xl && os2_xl_ok(lp.os2_mt4, lp.os2_waves, lp.os2_depth);
+    const bool xl = os2_xl_ok(lp.os2_mt4, lp.os2_waves, lp.os2_depth);
     snprintf(nm, sizeof nm, "ry_c2d_os<%d,%d,%d,%d,%s>", lp.os2_mt4, lp.os2_nt4, lp.os2_waves, lp.os2_depth, xl ? "true" : "false");      // as rocprofv3 prints it
     RY_TRY(Lc.begin(nm, l.name, lp.flops, lp.bytes, grid));
     bool done = false;
 #define X(A, B_, C, D)                                                                                          \
     if (!done && lp.os2_mt4 == A && lp.os2_nt4 == B_ && lp.os2_waves == C && lp.os2_depth == D) {               \
-        if (xl) RY_LAUNCH((ry_c2d_os<A, B_, C, D, os2_xl_ok(A, C, D)>), grid, 64 * C, Lc.stream, p);            \
-        else RY_LAUNCH((ry_c2d_os<A, B_, C, D, false>), grid, 64 * C, Lc.stream, p);                            \
+        RY_LAUNCH((ry_c2d_os<A, B_, C, D, os2_xl_ok(A, C, D)>), grid, 64 * C, Lc.stream, p);                    \
         done = true;                                                                                            \
     }
     RY_OS2_CONFIGS(X)
@@ -745,7 +738,6 @@ static int launch_wino(Launcher& Lc, const Layer& l, const LayerPlan& lp, const 
         }
         if (p.xcd_gs) p.inv_xcd_nsg = 1.f / p.xcd_nsg;
     }
-    p.dbg_flags = g_igemm_dbg;
     const int total_tiles = p.mtiles * nsl_;
     dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
     const int mode = l.deconv ? 1 : 2;
@@ -759,7 +751,7 @@ static int launch_wino(Launcher& Lc, const Layer& l, const LayerPlan& lp, const 
     }
     RY_TRY(Lc.end());
     // (with an external split the rows left out of the grid have no slabs: the reduce node writes whatever their slab memory holds, the copy node behind it fills them in)
-    if (lp.splits > 1 && !(g_igemm_dbg & 16)) RY_TRY(launch_reduce(Lc, l, lp, B, g.Ho, oo, p.slab_stride, slope));
+    if (lp.splits > 1) RY_TRY(launch_reduce(Lc, l, lp, B, g.Ho, oo, p.slab_stride, slope));
     if (p.hole_nt > 0) RY_TRY(launch_rep_rows(Lc, l, lp, B));
     return RY_OK;
 }
@@ -836,8 +828,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         const int total_tiles = p.mtiles * p.ntiles * g.nphases * lp.splits;
         dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8));
         RY_TRY(Lc.begin(tile_name(lp.tile, lp.kg, bf16, patch), l.name, lp.flops, lp.bytes, grid));
-        p.dbg_flags = g_igemm_dbg;
-#define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_)                                                                    \
+    #define RY_IGEMM_LAUNCH(BM_, BN_, WM_, WN_)                                                                    \
     do {                                                                                                    \
         if (patch == 1 && lp.kg == 2) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 2, false, 1>), grid, 512, Lc.stream, p); \
         else if (patch == 1) RY_LAUNCH((ry_igemm_ldsdma<BM_, BN_, WM_, WN_, 1, false, 1>), grid, 256, Lc.stream, p);          \
@@ -875,7 +866,7 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
 #undef RY_IGEMM_LAUNCH
         RY_TRY(Lc.end());
         if (p.hole_nt > 0) RY_TRY(launch_rep_rows(Lc, l, lp, B));
-        if (lp.splits > 1 && !(g_igemm_dbg & 16)) RY_TRY(launch_reduce(Lc, l, lp, B, g.Ho, oo, p.slab_stride, slope));
+        if (lp.splits > 1) RY_TRY(launch_reduce(Lc, l, lp, B, g.Ho, oo, p.slab_stride, slope));
     } else if (lp.path == PATH_FIRST) {
         RySrFirstParams p;
         p.x = s1; p.w = l.wdir; p.scale = l.scale; p.shift = l.shift; p.out16 = lp.w16 ? lp.out16 : nullptr;
@@ -1368,7 +1359,6 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
     for (int i = lo; i < hi; ++i) {
         const Layer& l = net->layers[i];
         const LayerPlan& lp = P.lp[i];
-        if ((g_igemm_dbg & 32) && nd == 2 && i >= 5 && i <= 10) continue;
         if (nd == 1 && P.s1_os) {
             const bool fused_pad = l.src_a < 0 && padfuse_now;
             const float* sa = l.src_a < 0 ? ((P.mode == 1 && !padfuse_now) ? P.x_in : P.cur_in) : P.lp[l.src_a].out;
@@ -1608,7 +1598,7 @@ int ry_device_count(void) {
 
 // process-wide A/B and diagnostic switches, read when a context is created
 // RY_PLAN="layer:tile:splits:kgroups,...": read when a context is created and again at every ry_net_set_dtype (which drops
-// the launch plans), so that one process can sweep plans (scripts/gpu_x3_plansweep.py, scripts/gpu_r3_lanesweep.py)
+// the launch plans), so that one process can sweep plans (scripts/gpu_x3_plansweep.py, scripts/gpu_lanesweep.py)
 static int read_plan_env() {
     memset(g_force, 0, sizeof(g_force));
     memset(g_os2_force, 0, sizeof(g_os2_force)); memset(g_os2_forced, 0, sizeof(g_os2_forced));
@@ -1630,10 +1620,8 @@ static int read_plan_env() {
             }
         }
     }
-    g_os2_dbg = 0; g_poison = 0; g_os2_xl = 1;
-    if (const char* e = getenv("RY_OS2_XL")) g_os2_xl = atoi(e);
+    g_poison = 0;
     if (const char* e = getenv("RY_POISON")) g_poison = atoi(e);
-    if (const char* e = getenv("RY_OS2_DBG")) g_os2_dbg = atoi(e);
     if (const char* e = getenv("RY_OS2")) {
         for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
             int i = -1, a = 0, b = 0, c = 0, d = 0;
@@ -1665,14 +1653,11 @@ static int read_env_switches() {
         if (sscanf(e, "%d:%d:%d:%d", &on, &reps, &mx, &pick) < 1) return fail(RY_EINVAL, "RY_AUTOTUNE: expected 1[:reps[:max[:pick]]]");
         g_autotune = on; g_autotune_reps = reps > 0 ? reps : 1; g_autotune_max = mx; g_autotune_pick = pick;
     }
-    g_x3_min_m = 128; g_s2_crop = 2; g_igemm_dbg = 0;
+    g_x3_min_m = 128; g_s2_crop = 2;
     if (const char* e = getenv("RY_X3_MINM")) g_x3_min_m = atoi(e);
     if (const char* e = getenv("RY_S2_CROP")) g_s2_crop = atoi(e);
     g_s2_hole = 1;
     if (const char* e = getenv("RY_S2_HOLE")) g_s2_hole = atoi(e);
-    g_kg_slabs = 1;
-    if (const char* e = getenv("RY_KG_SLABS")) g_kg_slabs = atoi(e);
-    if (const char* e = getenv("RY_IGEMM_DBG")) g_igemm_dbg = atoi(e);
     return read_plan_env();
 }
 

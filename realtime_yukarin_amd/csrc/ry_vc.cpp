@@ -233,7 +233,7 @@ int ry_vc_set_discard(ry_vc* vc, int front, int back) {
 }
 
 // 1 .. 8 lanes (six ring slots up to three lanes, else two per lane; measured in round 3 at 300 frames: 1.133 / 1.166 / 1.156 / 1.147 / 1.121 ms per
-// window with 2 / 3 / 4 / 6 / 8 lanes, profiles/r03_h_lane_experiments.txt; the default stays 2: the latency of a window grows with the lanes):
+// window with 2 / 3 / 4 / 6 / 8 lanes, profiles/r03/h_lane_experiments.txt; the default stays 2: the latency of a window grows with the lanes):
 // ring slot k runs on its own pair of predictor handles (clones of the caller's: same filters, own streams, plans,
 // activations and graphs), so that up to `lanes` windows really run side by side.  Measured at 300 frames (round 2):
 // 1.281 / 1.200 / 1.160 ms per window with 1 / 2 / 3 lanes -- the one-round grids of one window leave tails and its bottom layers leave

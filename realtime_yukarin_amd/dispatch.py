@@ -136,7 +136,7 @@ def _worker_main(rank: int, world: int, device: int, ac, sr, threshold, comm: st
         vc = VoiceChanger(acoustic_converter=ac, super_resolution=sr, threshold=threshold)
         vc._fused_core()                                                # contexts, predictors and the window core exist before 'ready'
         import gc
-        gc.collect(); gc.freeze()                                       # a full collection mid-stream is a pause of tens of ms (profiles/r04_driver_cmd.txt)
+        gc.collect(); gc.freeze()                                       # a full collection mid-stream is a pause of tens of ms (profiles/r04/driver_cmd.txt)
         send(('ready', rank, -1, None))
         pending = collections.deque()
 

@@ -1,18 +1,19 @@
 #!/bin/bash
-# Round 5 (form of gpu_r4_driver_cmd.sh): the driver's own command in FRESH processes -- is the first K = 20 bracket deterministically slow, or was the
-# 2.31 ms step of BENCH_r03.json a transient?  Three runs of the exact command, then NRUN - 3 with --no-extras --no-cpu-baseline (the timed
+# The driver's own command in FRESH processes: the distribution behind the driver's one line (round 4: is the first K = 20 bracket deterministically slow, or was the
+# 2.31 ms step of BENCH_r03.json a transient?)  Three runs of the exact command, then NRUN - 3 with --no-extras --no-cpu-baseline (the timed
 # region comes first in the process either way).  Every run prints its brackets; BENCH_DEBUG_FENCE=1 adds the per-bracket stderr lines.
-#   gpu_r4_driver_cmd.sh [NRUN]  ->  gpurun_out/r05_driver_cmd/{run_XX.json, run_XX.err, summary.txt}
-cd "$GRAFT_REPO_ROOT"; N=${1:-12}; O=gpurun_out/r05_driver_cmd; mkdir -p $O
+#   gpu_driver_cmd.sh [NRUN] [round]  ->  gpurun_out/<round>_driver_cmd/{run_XX.json, run_XX.err, summary.txt}
+cd "$GRAFT_REPO_ROOT"; N=${1:-12}; RND=${2:-r06}; export O=gpurun_out/${RND}_driver_cmd; mkdir -p $O
 for i in $(seq 1 $N); do
   X=""; [ $i -gt 3 ] && X="--no-extras --no-cpu-baseline"
   BENCH_DEBUG_FENCE=1 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 $X --details-out $O/details_$i.json > $O/run_$i.json 2> $O/run_$i.err
   echo "run $i exit $?"
 done
-python3 - <<'PY' > gpurun_out/r05_driver_cmd/summary.txt
-import json, glob, re
+python3 - <<'PY' > $O/summary.txt
+import json, glob, os, re
+O = os.environ['O']
 rows = []
-for f in sorted(glob.glob('gpurun_out/r05_driver_cmd/run_*.json'), key=lambda s: int(re.findall(r'run_(\d+)', s)[0])):
+for f in sorted(glob.glob(O + '/run_*.json'), key=lambda s: int(re.findall(r'run_(\d+)', s)[0])):
     try:
         d = json.loads([l for l in open(f) if l.startswith('{')][-1])
     except Exception as e:
@@ -27,6 +28,6 @@ for r in rows:
 first = [r[4][0] for r in rows]; med = [r[2] for r in rows]
 if rows:
     print('first bracket ms/step: min %.4f max %.4f | median-bracket ms/step: min %.4f max %.4f | line bytes: %s'
-          % (min(first), max(first), min(med), max(med), [len(open('gpurun_out/r05_driver_cmd/' + r[0]).read()) for r in rows]))
+          % (min(first), max(first), min(med), max(med), [len(open(O + '/' + r[0]).read()) for r in rows]))
 PY
-cat gpurun_out/r05_driver_cmd/summary.txt
+cat $O/summary.txt

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""Round 5: stage-2 launch plans under TWO window lanes.  The planner prices a layer by its lone time (one workgroup of two K groups per CU: 8 waves,
-124 KiB of LDS); two lanes put two launches on the chip, and two such workgroups do not fit one CU.  Candidates (RY_PLAN strings, "-" = the planner's
-picks) are measured in turn: stage-2 forward alone (graph replay) and the chained two-lane step exactly as bench.py's step.
-usage (GPU box): python scripts/gpu_r5_plan_ab.py [frames] [alternations] [out file] plan [plan ...]"""
+"""Round 5: the encoder's identical padding rows copied instead of computed (RY_S2_HOLE=1, default) against computing them (=0), one process,
+interleaved: stage-2 forward alone (graph replay) and the chained two-lane step exactly as bench.py's step.
+usage (GPU box): python scripts/gpu_hole_ab.py [frames] [alternations] [out file]"""
 import ctypes
 import os
 import sys
@@ -19,8 +18,7 @@ from realtime_yukarin_amd.weights import flatten_params             # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 ALT = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-OUT = sys.argv[3] if len(sys.argv) > 3 else str(ROOT / 'gpurun_out' / ('r5_plan_ab_n%d.txt' % N))
-PLANS = sys.argv[4:] or ['-']
+OUT = sys.argv[3] if len(sys.argv) > 3 else str(ROOT / 'gpurun_out' / ('r5_hole_ab_n%d.txt' % N))
 (d1, P1), (d2, P2) = synth.model_params('SYN-64')
 ctx = engine.get_context(0)
 n1 = engine.Net(ctx, d1, flatten_params(d1, P1))
@@ -41,21 +39,8 @@ def say(s):
     lines.append(s + '\n'); print(s, flush=True)
 
 
-ENV_KEYS = set()
-
-
-def setup(plan):
-    """'-': the planner's picks; 'env:K=V[,K=V]': the planner's picks under these switches; else an RY_PLAN string"""
-    for k in ENV_KEYS:
-        os.environ.pop(k, None)
-    os.environ.pop('RY_PLAN', None)
-    if plan.startswith('env:'):
-        for kv in plan[4:].split(','):
-            k, v = kv.split('=')
-            os.environ[k] = v; ENV_KEYS.add(k)
-    elif plan != '-':
-        os.environ['RY_PLAN'] = plan
-    reread(); n2.set_dtype('f32')
+def setup(hole):
+    os.environ['RY_S2_HOLE'] = hole; reread(); n2.set_dtype('f32')
 
 
 def forward_alone(reps=40):
@@ -68,7 +53,7 @@ def forward_alone(reps=40):
 
 
 def two_lane(steps=100):
-    core = engine.VcCore(n1, n2, mtx, lanes=int(os.environ.get('AB_LANES', '2')))
+    core = engine.VcCore(n1, n2, mtx, lanes=2)
     k = [0]
 
     def step():
@@ -91,19 +76,20 @@ def two_lane(steps=100):
     return best
 
 
-say('# stage-2 plans under two lanes, SYN-64, %d frames, %d rounds over %d candidates' % (N, ALT, len(PLANS)))
-res = {p: [] for p in PLANS}
+say('# RY_S2_HOLE=0 (identical padding rows of encoder c1 / c2 computed) against =1 (copied), SYN-64, %d frames, %d alternations' % (N, ALT))
+rows = []
 for r in range(ALT):
-    for p in PLANS:
-        setup(p); f = forward_alone(); t = two_lane()
-        res[p].append((f, t))
-        say('%2d  %-60s forward alone %.4f ms   two-lane step %.4f ms per window' % (r, p, f, t))
-for p in PLANS:
-    a = numpy.array(res[p])
-    say('# median  %-60s forward alone %.4f ms   two-lane step %.4f ms' % (p, numpy.median(a[:, 0]), numpy.median(a[:, 1])))
-    setup(p)
-    for q in n2.profile(1, N, 5, window=True):
-        if q['name'].startswith('ry_igemm') and q['ms'] > 0.02:
-            say('#     %-11s %-44s grid=%-5d %7.2f us' % (q['layer'], q['name'], q['grid'][0], q['ms'] * 1e3))
+    setup('0'); f0 = forward_alone(); t0 = two_lane()
+    setup('1'); f1 = forward_alone(); t1 = two_lane()
+    rows.append((f0, f1, t0, t1))
+    say('%2d  forward alone %.4f -> %.4f ms   two-lane step %.4f -> %.4f ms per window' % (r, f0, f1, t0, t1))
+a = numpy.array(rows)
+say('# median: forward alone %.4f -> %.4f ms; two-lane step %.4f -> %.4f ms (%+.2f %%); two-lane faster in %d of %d alternations'
+    % (numpy.median(a[:, 0]), numpy.median(a[:, 1]), numpy.median(a[:, 2]), numpy.median(a[:, 3]),
+       100 * (numpy.median(a[:, 3]) / numpy.median(a[:, 2]) - 1), int((a[:, 3] < a[:, 2]).sum()), ALT))
+setup('1')
+for q in n2.profile(1, N, 10, window=True):
+    if q['layer'] in ('encoder/c1', 'encoder/c2'):
+        say('#   %-11s %-44s grid=%-5d %7.2f us' % (q['layer'], q['name'], q['grid'][0], q['ms'] * 1e3))
 Path(OUT).parent.mkdir(parents=True, exist_ok=True)
 Path(OUT).write_text(''.join(lines))

@@ -9,7 +9,7 @@ RY_PLAN (re-read by ry_net_set_dtype), the window core re-created (fresh clones,
 exactly like bench.py does (priming of every ring slot, warm-up, K steps between synchronisations).  Also prints the single-window
 forward (graph replay of stage 2 alone) of every candidate, because a plan that wins with two lanes may lose alone.
 
-usage (GPU box): python scripts/gpu_r3_lanesweep.py [frames] [out file] [steps]"""
+usage (GPU box): python scripts/gpu_lanesweep.py [frames] [out file] [steps]"""
 import os
 import sys
 import time

@@ -7,7 +7,7 @@ timed with HIP events inside the eager window forward (ry_net_profile_window: th
 forward as graph replays of the convert call, and the chained two-lane step exactly as bench.py's step.  Results are checked against the
 implicit-GEMM forward of the same window (other summation order only).
 
-usage (GPU box): python scripts/gpu_r5_os_sweep.py [frames] [out file] [reps]"""
+usage (GPU box): python scripts/gpu_os_sweep.py [frames] [out file] [reps]"""
 import os
 import sys
 import time

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Round 5: the encoder's identical padding rows copied instead of computed (RY_S2_HOLE=1, default) against computing them (=0), one process,
-interleaved: stage-2 forward alone (graph replay) and the chained two-lane step exactly as bench.py's step.
-usage (GPU box): python scripts/gpu_r5_hole_ab.py [frames] [alternations] [out file]"""
+"""Stage-2 launch plans under two window lanes, in turn (env assignments separated by ";" so that RY_WINO lists fit).  The planner prices a layer by its lone time (one workgroup of two K groups per CU: 8 waves,
+124 KiB of LDS); two lanes put two launches on the chip, and two such workgroups do not fit one CU.  Candidates (RY_PLAN strings, "-" = the planner's
+picks) are measured in turn: stage-2 forward alone (graph replay) and the chained two-lane step exactly as bench.py's step.
+usage (GPU box): python scripts/gpu_plan_ab.py [frames] [alternations] [out file] plan [plan ...]"""
 import ctypes
 import os
 import sys
@@ -18,7 +19,8 @@ from realtime_yukarin_amd.weights import flatten_params             # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 ALT = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-OUT = sys.argv[3] if len(sys.argv) > 3 else str(ROOT / 'gpurun_out' / ('r5_hole_ab_n%d.txt' % N))
+OUT = sys.argv[3] if len(sys.argv) > 3 else str(ROOT / 'gpurun_out' / ('r6_plan_ab_n%d.txt' % N))
+PLANS = sys.argv[4:] or ['-']
 (d1, P1), (d2, P2) = synth.model_params('SYN-64')
 ctx = engine.get_context(0)
 n1 = engine.Net(ctx, d1, flatten_params(d1, P1))
@@ -39,8 +41,21 @@ def say(s):
     lines.append(s + '\n'); print(s, flush=True)
 
 
-def setup(hole):
-    os.environ['RY_S2_HOLE'] = hole; reread(); n2.set_dtype('f32')
+ENV_KEYS = set()
+
+
+def setup(plan):
+    """'-': the planner's picks; 'env:K=V[,K=V]': the planner's picks under these switches; else an RY_PLAN string"""
+    for k in ENV_KEYS:
+        os.environ.pop(k, None)
+    os.environ.pop('RY_PLAN', None)
+    if plan.startswith('env:'):
+        for kv in plan[4:].split(';'):
+            k, v = kv.split('=', 1)
+            os.environ[k] = v; ENV_KEYS.add(k)
+    elif plan != '-':
+        os.environ['RY_PLAN'] = plan
+    reread(); n2.set_dtype('f32')
 
 
 def forward_alone(reps=40):
@@ -53,7 +68,7 @@ def forward_alone(reps=40):
 
 
 def two_lane(steps=100):
-    core = engine.VcCore(n1, n2, mtx, lanes=2)
+    core = engine.VcCore(n1, n2, mtx, lanes=int(os.environ.get('AB_LANES', '2')))
     k = [0]
 
     def step():
@@ -76,20 +91,19 @@ def two_lane(steps=100):
     return best
 
 
-say('# RY_S2_HOLE=0 (identical padding rows of encoder c1 / c2 computed) against =1 (copied), SYN-64, %d frames, %d alternations' % (N, ALT))
-rows = []
+say('# stage-2 plans under two lanes, SYN-64, %d frames, %d rounds over %d candidates' % (N, ALT, len(PLANS)))
+res = {p: [] for p in PLANS}
 for r in range(ALT):
-    setup('0'); f0 = forward_alone(); t0 = two_lane()
-    setup('1'); f1 = forward_alone(); t1 = two_lane()
-    rows.append((f0, f1, t0, t1))
-    say('%2d  forward alone %.4f -> %.4f ms   two-lane step %.4f -> %.4f ms per window' % (r, f0, f1, t0, t1))
-a = numpy.array(rows)
-say('# median: forward alone %.4f -> %.4f ms; two-lane step %.4f -> %.4f ms (%+.2f %%); two-lane faster in %d of %d alternations'
-    % (numpy.median(a[:, 0]), numpy.median(a[:, 1]), numpy.median(a[:, 2]), numpy.median(a[:, 3]),
-       100 * (numpy.median(a[:, 3]) / numpy.median(a[:, 2]) - 1), int((a[:, 3] < a[:, 2]).sum()), ALT))
-setup('1')
-for q in n2.profile(1, N, 10, window=True):
-    if q['layer'] in ('encoder/c1', 'encoder/c2'):
-        say('#   %-11s %-44s grid=%-5d %7.2f us' % (q['layer'], q['name'], q['grid'][0], q['ms'] * 1e3))
+    for p in PLANS:
+        setup(p); f = forward_alone(); t = two_lane()
+        res[p].append((f, t))
+        say('%2d  %-60s forward alone %.4f ms   two-lane step %.4f ms per window' % (r, p, f, t))
+for p in PLANS:
+    a = numpy.array(res[p])
+    say('# median  %-60s forward alone %.4f ms   two-lane step %.4f ms' % (p, numpy.median(a[:, 0]), numpy.median(a[:, 1])))
+    setup(p)
+    for q in n2.profile(1, N, 5, window=True):
+        if q['name'].startswith(('ry_igemm', 'ry_wino', 'ry_splitk', 'ry_rep')) and (q['ms'] > 0.02 or q['name'].startswith('ry_wino')):
+            say('#     %-11s %-44s grid=%-5d %7.2f us' % (q['layer'], q['name'], q['grid'][0], q['ms'] * 1e3))
 Path(OUT).parent.mkdir(parents=True, exist_ok=True)
 Path(OUT).write_text(''.join(lines))

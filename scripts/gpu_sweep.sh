@@ -1,9 +1,9 @@
 #!/bin/bash
 # The chained step at every BASELINE window size (configs #3/#4, #5, #1, #2), in bf16 / split-bf16 mode and with 8 lanes: the table of DESIGN.md section 7.
-#   gpu_r4_sweep.sh <tag>  ->  gpurun_out/<tag>/sweep.txt
-cd "$GRAFT_REPO_ROOT"; TAG=${1:-r04_s}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O
+#   gpu_sweep.sh [round] [tag]  ->  gpurun_out/<round>_<tag>/sweep.txt
+cd "$GRAFT_REPO_ROOT"; RND=${1:-r06}; TAG=${2:-w}; O=$GRAFT_REPO_ROOT/gpurun_out/${RND}_$TAG; mkdir -p $O
 HASH=$(python -c "import bench; print(bench.source_hash())")
-echo "# round 4 (source $HASH): python bench.py --no-cpu-baseline --no-split-bf16 <args>; one MI355X, SYN-64" > $O/sweep.txt
+echo "# $RND (source $HASH): python bench.py --no-cpu-baseline --no-split-bf16 <args>; one MI355X, SYN-64" > $O/sweep.txt
 echo "# args | frames/s | ms per window | x real-time | effective x real-time | mixed stream frames/s | stage-2 forward alone ms | whole stage-2 forward / peak (executed FLOPs) | lone host call ms | batch8 ms per window" >> $O/sweep.txt
 run() {
   timeout 300 python bench.py --no-cpu-baseline --no-split-bf16 "$@" > $O/line.json 2> $O/line.err || { echo "$* FAILED" >> $O/sweep.txt; tail -3 $O/line.err >> $O/sweep.txt; return; }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 6: an experiment build of the library (libry355<suffix>.so, build.build_product(defs=[...], suffix=...)) against fixed Winograd plans: us of the
-Winograd launches (HIP events inside the eager window forward), one line per build.   usage (GPU box): python scripts/gpu_r6_var.py <suffix | -> <frames> <RY_WINO spec> ..."""
+Winograd launches (HIP events inside the eager window forward), one line per build.   usage (GPU box): python scripts/gpu_variant.py <suffix | -> <frames> <RY_WINO spec> ..."""
 import os
 import sys
 from pathlib import Path

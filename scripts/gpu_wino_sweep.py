@@ -5,7 +5,7 @@ One process.  A plan is forced through RY_WINO="layer:cfg:mbw:splits" (re-read b
 launches are timed with HIP events inside the eager window forward (ry_net_profile_window), the whole stage-2 forward as graph replays of the convert
 call, and the chained two-lane step exactly as bench.py's step.  Results are checked against the direct forward of the same window.
 
-usage (GPU box): python scripts/gpu_r6_wino.py [frames] [out file] [reps]      (SWEEP_LAYERS=none: only the planner's defaults)"""
+usage (GPU box): python scripts/gpu_wino_sweep.py [frames] [out file] [reps]      (SWEEP_LAYERS=none: only the planner's defaults)"""
 import os
 import sys
 import time

@@ -3,7 +3,7 @@
 ry_c2d_os's LDS-DMA pixel path (XL) reads LDS bytes that the wave's OWN earlier global_load_lds wrote and times that read with a hand-written
 `s_waitcnt vmcnt(after * (MT4 + NT4))` (ry_kernels.h, consume()): the count is right only while the compiler emits exactly MT4 + NT4 vector-memory
 loads per K unit, in program order, between two such waits -- a merged or hoisted load would let the wait pass before the slot has landed, and
-neither the emulator nor a CPU test can see that (round 5: hipcc 7.2's own timing read a slot early on the MI355X only, profiles/r05_n_xl.txt;
+neither the emulator nor a CPU test can see that (round 5: hipcc 7.2's own timing read a slot early on the MI355X only, profiles/r05/n_xl.txt;
 round-5 advisor).  This test counts them in the disassembly of every XL instantiation."""
 import re
 import subprocess

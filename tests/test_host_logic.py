@@ -144,7 +144,7 @@ def test_bench_line_stays_short_enough_for_the_drivers_tail():
     root = Path(__file__).resolve().parent.parent
     sys.path.insert(0, str(root))
     import bench
-    full = json.loads((root / 'profiles' / 'r04_d_bench_details.json').read_text())
+    full = json.loads((root / 'profiles' / 'r04/d_bench_details.json').read_text())
     line = bench.compact_line(full, 'gpurun_out/bench_details_1gpu.json')
     text = json.dumps(line)
     assert len(text) < 6144, len(text)

@@ -1,7 +1,7 @@
 // mfma_share_probe -- what does a wave running v_mfma_f32_32x32x2_f32 lose to the OTHER wave of its SIMD, by what that wave does?
 // 512-thread workgroups (two waves per SIMD, one workgroup per CU): waves 0-3 run N independent-accumulator fp32 MFMAs and time themselves (s_memtime);
 // waves 4-7 run a partner loop until the MFMA waves are done: nothing / fp32 VALU (v_sub_f32) / integer VALU / ds_read_b128 / SALU / fp32 MFMAs too.
-// Round 6: the Winograd kernel's time came out as MFMA time PLUS the time of everything else, two waves per SIMD or not (scripts/gpu_r6_abl.sh).
+// Round 6: the Winograd kernel's time came out as MFMA time PLUS the time of everything else, two waves per SIMD or not (profiles/r06/wino_ablation.txt).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_share_probe.cpp -o tools/mfma_share_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>

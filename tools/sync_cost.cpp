@@ -4,7 +4,7 @@
 //       `bytes` of output, arrives on a counter in memory, polls it, then reads the bytes another workgroup (on another XCD) wrote -- the XCDs
 //       do not snoop each other's L2, so data handed from one workgroup to another inside a launch has to travel through memory.
 //       What is measured is the PESSIMISTIC form: every data store, the arrival and the poll are SYSTEM-scope atomics (one atomic store per
-//       element), with s_sleep in the spin -- an UPPER bound (13 / 27 / 67 us per barrier at 128 / 256 / 512 workgroups, profiles/r04_h).  The
+//       element), with s_sleep in the spin -- an UPPER bound (13 / 27 / 67 us per barrier at 128 / 256 / 512 workgroups, profiles/r04/h).  The
 //       XCD-hierarchical barrier of /opt/skills/guides/MI355X_MICROARCH.md (per-XCC counters, agent-scope fences, plain stores) is quoted there
 //       at 4.1 / 5.9 / 9.7 us at 256 / 512 / 1024 workgroups with nothing published and ~7 us after a phase that wrote a 64 KB slab per
 //       workgroup: that is the figure DESIGN.md section 10 prices a fused multi-layer kernel with (against 2.2 us per dependent graph node).
