@@ -10,8 +10,8 @@ CSRC = PKG / 'csrc'
 LIB = PKG / 'libry355.so'
 EMU_DIR = ROOT / 'tests' / 'emu'
 EMU_LIB = EMU_DIR / 'libry355_emu.so'
-UNITS = [CSRC / 'ry_net.cpp', CSRC / 'ry_vc.cpp', CSRC / 'ry_comm.cpp']          # translation units of libry355.so
-SOURCES = UNITS + [CSRC / 'ry_kernels.h', CSRC / 'ry_vc_kernels.h', CSRC / 'ry_host.h', CSRC / 'ry_dev.h', ROOT / 'include' / 'ry355.h']
+UNITS = [CSRC / 'ry_exec.cpp', CSRC / 'ry_plan.cpp', CSRC / 'ry_net.cpp', CSRC / 'ry_vc.cpp', CSRC / 'ry_comm.cpp']          # translation units of libry355.so (ry_exec.cpp carries the kernels)
+SOURCES = UNITS + [CSRC / 'ry_kernels.h', CSRC / 'ry_vc_kernels.h', CSRC / 'ry_plan.h', CSRC / 'ry_host.h', CSRC / 'ry_dev.h', ROOT / 'include' / 'ry355.h']
 
 
 def _stale(target: Path, deps) -> bool:
@@ -29,7 +29,7 @@ def _hipcc() -> str:
 
 
 def _compile_units(cc, flags, obj_dir: Path, suffix: str, extra_sources=()):
-    """Every translation unit to its own object file, side by side (ry_net.cpp carries the implicit-GEMM instantiations and takes most of
+    """Every translation unit to its own object file, side by side (ry_exec.cpp carries the kernel instantiations and takes most of
     the time), then the caller links them."""
     from concurrent.futures import ThreadPoolExecutor
     obj_dir.mkdir(parents=True, exist_ok=True)

@@ -16,6 +16,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define RY_DEV __device__ __forceinline__
+#define RY_DEV_STATIC static __device__ __forceinline__      // static member functions (the emulator build spells RY_DEV "static inline")
 #define RY_KERNEL(...) __global__ __launch_bounds__(__VA_ARGS__)
 
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
@@ -104,3 +105,7 @@ typedef hipStream_t ry_stream_t;
 
 RY_DEV f32x4 ry_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 RY_DEV void ry_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// constants the host planner (ry_plan.cpp) and the kernels share: epilogue activations, forms of a stage-1 layer
+enum { RY_ACT_NONE = 0, RY_ACT_LRELU = 1, RY_ACT_RELU = 2, RY_ACT_GLU = 3 };
+enum { RY_C1D_S2 = 0, RY_C1D_S1 = 1, RY_C1D_DECONV = 2, RY_C1D_GEN = 3 };

@@ -30,7 +30,6 @@
 #pragma once
 #include "ry_dev.h"
 
-enum { RY_ACT_NONE = 0, RY_ACT_LRELU = 1, RY_ACT_RELU = 2, RY_ACT_GLU = 3 };
 
 RY_DEV float ry_act(float v, int act, float slope) {
     if (act == RY_ACT_LRELU) return v >= 0.f ? v : v * slope;
@@ -1661,7 +1660,6 @@ RY_DEV f32x4 ry_src1d_load4(const RySrc1d& s, long long pix0, int c, int valid_m
     return v;
 }
 
-enum { RY_C1D_S2 = 0, RY_C1D_S1 = 1, RY_C1D_DECONV = 2, RY_C1D_GEN = 3 };
 
 struct RyConv1dParams {
     RySrc1d s[2];
@@ -1861,7 +1859,7 @@ struct RyC1dOsParams {
 // total).  N - 1 + (6 - log2 N) exchanges, fixed order.
 template <int N, int MASK>
 struct RyReduceScatter64 {
-    static RY_DEV float run(const float (&v)[N], int lane) {
+    RY_DEV_STATIC float run(const float (&v)[N], int lane) {
         float h[N / 2];
         const bool up = (lane & MASK) != 0;
 #pragma unroll
@@ -1876,7 +1874,7 @@ struct RyReduceScatter64 {
 };
 template <int MASK>
 struct RyReduceScatter64<1, MASK> {
-    static RY_DEV float run(const float (&v)[1], int lane) {
+    RY_DEV_STATIC float run(const float (&v)[1], int lane) {
         float r = v[0];
         if constexpr (MASK <= 32) {
             r += ry_shfl_xor_c<MASK>(r);

@@ -45,6 +45,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 #define __syncthreads() ry_emu::sync_block()
 
 #define RY_DEV static inline
+#define RY_DEV_STATIC static inline
 #define RY_KERNEL(...)
 
 RY_DEV f32x16 ry_mfma_32x32x2(float a, float b, f32x16 c) { return ry_emu::mfma_32x32x2(a, b, c); }
