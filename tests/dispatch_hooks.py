@@ -45,3 +45,34 @@ def stall_hook(rank):
         if rank == 0 and len(seen) == 2:
             time.sleep(2.0)
     return per_window
+
+
+def jitter_hook(rank):
+    """Eight workers of different, changing speed (no emulator context: for null workers): worker r sleeps 0 .. 35 ms per window by a fixed pseudo-random
+    sequence of its own, and every worker has one long stall somewhere in its first windows -- completion order is far from submission order."""
+    state = [0x9E3779B9 * (rank + 1) & 0xFFFFFFFF, 0]
+
+    def per_window(index):
+        state[0] = (state[0] * 1664525 + 1013904223) & 0xFFFFFFFF
+        state[1] += 1
+        time.sleep((state[0] >> 24) % 36 / 1000.0 + (0.25 if state[1] == 2 + rank % 3 else 0.0))
+    return per_window
+
+
+def dying_mid_stream_hook(rank):
+    """Worker 5 of eight is lost on its third window (null workers)."""
+    seen = []
+
+    def per_window(index):
+        seen.append(index)
+        if rank == 5 and len(seen) == 3:
+            raise RuntimeError('window %d: device lost' % index)
+    return per_window
+
+
+def long_stall_hook(rank):
+    """Worker 3 sleeps 8 s on its first window (null workers): close() must not wait for it beyond its own deadline."""
+    def per_window(index):
+        if rank == 3:
+            time.sleep(8.0)
+    return per_window

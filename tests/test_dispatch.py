@@ -23,7 +23,8 @@ REF = Path('/root/reference')
 KEYS = ('f0', 'ap', 'sp', 'voiced', 'mc')
 
 
-from dispatch_hooks import dying_hook, emu_hook, failing_window_hook, stall_hook      # top-level functions of a LIGHT module: every spawned worker imports the module of its hook
+from dispatch_hooks import (dying_hook, dying_mid_stream_hook, emu_hook, failing_window_hook, jitter_hook, long_stall_hook,
+                            stall_hook)      # top-level functions of a LIGHT module: every spawned worker imports the module of its hook
 
 
 def windows(n_frames, count):
@@ -123,6 +124,69 @@ def test_a_stalled_worker_with_a_backlog_behind_it_does_not_deadlock(tmp_path):
     assert d.max_out_of_order >= 2                                   # worker 1 ran ahead while worker 0 slept
     for _, f in got:
         assert f.sp.shape == (10, 513) and f.ap.shape == (10, 513)
+
+
+def test_eight_workers_jitter_small_rings_in_order_release(tmp_path):
+    """Round-5 verdict, item 7: the hand-out at the node's real width.  G = 8 null workers (no arithmetic; the rings, the round-robin hand-out and the
+    in-order release are the product's), two-slot rings, every worker at its own changing pace with a long stall somewhere: 240 windows come back in
+    submission order, every worker got every eighth window, completions ran far ahead of the release point, nothing deadlocks."""
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    wins = windows(24, 3)
+    t0 = time.time()
+    with dispatch.ChunkDispatcher(ac, sr, [0] * 8, comm='host', null_workers=True, worker_hook=jitter_hook, slots=2, start_timeout=600) as d:
+        got, workers = [], []
+        for i in range(240):
+            workers.append(d.submit(1000 + i, wins[i % 3][2], discard=(7, 7), pick=(7, -7, KEYS)))
+            got += d.collect()
+        got += d.drain(timeout=180)
+        ooo = d.max_out_of_order
+    assert workers == [i % 8 for i in range(240)]
+    assert [i for i, _ in got] == list(range(1000, 1240)) and time.time() - t0 < 120
+    assert ooo >= 4, ooo                                              # several workers finished windows ahead of the one being waited for
+    assert all(f.sp.shape == (10, 513) and f.ap.shape == (10, 513) for _, f in got)
+
+
+def test_eight_emulator_workers_return_the_single_worker_bits(tmp_path):
+    """... and with the arithmetic: eight emulator worker processes (SYN-8) against one, bit for bit, in order."""
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    wins = windows(24, 8)
+    one, w1, _ = run(ac, sr, [0], wins, emu_hook)
+    eight, w8, _ = run(ac, sr, [0] * 8, wins, emu_hook)
+    assert w8 == list(range(8)) and [i for i, _ in eight] == [i for i, _ in one] == list(range(100, 108))
+    for (_, a), (_, b) in zip(one, eight):
+        assert same(a, b)
+
+
+def test_one_of_eight_workers_dies_mid_stream(tmp_path):
+    """Worker 5 of eight is lost after start-up with windows queued on every ring: the caller gets the worker's error (not a hang), the dispatcher closes
+    itself and the other seven processes are gone afterwards."""
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    wins = windows(24, 3)
+    t0 = time.time()
+    d = dispatch.ChunkDispatcher(ac, sr, [0] * 8, comm='host', null_workers=True, worker_hook=dying_mid_stream_hook, slots=2, start_timeout=600)
+    with pytest.raises(RuntimeError, match='device lost'):
+        for i in range(64):
+            d.submit(i, wins[i % 3][2], discard=(7, 7), pick=(7, -7, KEYS))
+        d.drain(timeout=120)
+    assert d.closed and time.time() - t0 < 120
+    assert not any(p.is_alive() for p in d._procs)
+
+
+def test_close_keeps_its_deadline_with_a_stalled_worker_among_eight(tmp_path):
+    """close() with work in flight and one worker asleep for 8 s: one deadline for all workers (20 s), the sleeper is joined when it wakes, nobody is left."""
+    e2e.write_models(tmp_path, 'SYN-8')
+    ac, sr = e2e.build_converters(tmp_path)
+    wins = windows(24, 3)
+    d = dispatch.ChunkDispatcher(ac, sr, [0] * 8, comm='host', null_workers=True, worker_hook=long_stall_hook, slots=2, start_timeout=600)
+    for i in range(16):
+        d.submit(i, wins[i % 3][2], discard=(7, 7), pick=(7, -7, KEYS))
+    t0 = time.time()
+    d.close()
+    assert d.closed and time.time() - t0 < 30
+    assert not any(p.is_alive() for p in d._procs)
 
 
 def test_lean_windows_and_whole_objects_return_the_same_bits(tmp_path):

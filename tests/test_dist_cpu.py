@@ -105,7 +105,8 @@ def test_bench_main_runs_its_distributed_branches_with_two_gloo_ranks(tmp_path):
     assert r0['config']['parallelism'].startswith('chunk-dp2')
 
 
-def test_bench_starts_its_own_ranks_when_run_plainly(tmp_path):
+@pytest.mark.parametrize('world', [2, 4])
+def test_bench_starts_its_own_ranks_when_run_plainly(tmp_path, world):
     """Round-4 verdict: `python3 bench.py --gpus N` -- the form of the driver's 1-GPU command, no launcher -- used to exit with a usage hint.
     It now starts the N ranks itself (torch.distributed.run on a free port) and rank 0 prints the one JSON line, of the same shape as under
     the launcher."""
@@ -114,11 +115,13 @@ def test_bench_starts_its_own_ranks_when_run_plainly(tmp_path):
     from realtime_yukarin_amd import build
     build.build_emu()
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
-    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--emulator', '--frames', '24', '--steps', '1', '--warmup', '0', '--no-cpu-baseline',
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', str(world), '--emulator', '--frames', '24', '--steps', '1', '--warmup', '0', '--no-cpu-baseline',
                         '--details-out', str(tmp_path / 'details.json')], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['comm'] == 'torch.distributed/gloo' and d['comm_ranks'] == 2 and d['scaling'] == 'weak'
-    assert d['value'] > 0 and d['config']['parallelism'].startswith('chunk-dp2') and 'metric' in d and len(d['brackets']) >= 1
+    assert d['n_gpus'] == world and d['comm'] == 'torch.distributed/gloo' and d['comm_ranks'] == world and d['scaling'] == 'weak'
+    assert d['value'] > 0 and d['config']['parallelism'].startswith('chunk-dp%d' % world) and 'metric' in d and len(d['brackets']) >= 1
+    # whole-job aggregate: `world` ranks x windows per rank x frames over the max-over-ranks time (value is rounded to 0.1)
+    assert abs(d['value'] - world * d['config']['windows_per_gpu'] * 24 / (d['ms_per_step'] * 1e-3)) / d['value'] < 5e-3
