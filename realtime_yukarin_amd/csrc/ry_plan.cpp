@@ -465,7 +465,7 @@ bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int* waves
 // Workgroup shapes: cfg 1 = 2 x 2 waves (two M-blocks of 8 x 16 pixels x 64 channels, one 8-channel slice per iteration, 74 KiB of LDS: two per CU),
 // cfg 2 = 4 x 2 waves (four M-blocks x 64 channels, two slices per iteration, 146 KiB: one per CU).  mbw = M-blocks per tile row.
 static int g_wino = 1;                 // RY_WINOGRAD=0: every layer keeps the direct implicit GEMM (the bit-exact reference of the Winograd form; A/B)
-static int g_wino_min_m = 512;         // RY_WINO_MINM: rows (pixels of one phase) from which an eligible layer takes the Winograd form
+static int g_wino_min_m = 256;         // RY_WINO_MINM: rows (pixels of one phase) from which an eligible layer takes the Winograd form (512 -> 256: encoder c4 / decoder c3 of the 100-frame window, 231.8 -> 240.9 k frames/s)
 static int g_wino_force[16][3];        // RY_WINO="layer:cfg:mbw:splits,...": tuning aid, fixes the Winograd plan of single layers ("layer:0" keeps that layer on the direct kernel)
 static bool g_wino_forced[16];
 
@@ -499,7 +499,7 @@ bool choose_wino(int Mh, int Mw, int N, int nphases, int npatches, int B, int* c
             if (Mh % th || Mw % tw) continue;
             const long units = (long)B * (Mh / th) * (Mw / tw) * (N / 64) * nphases;
             const int slots = c == 1 ? 512 : 256;
-            const double halo = (double)(th + 1) * (tw + 1) / ((double)th * tw) + 0.002 * th;      // (short tiles: the dead-row crop and the copied padding rows round to whole tile rows)
+            const double halo = (double)(th + 1) * (tw + 1) / ((double)th * tw) + 0.006 * th;      // short tiles: the dead-row crop and the copied padding rows round to whole tile rows (8 x 32 against 16 x 16 tiles, two-lane step at 300 frames: encoder -1.1 %, decoder -2.8 %, profiles/r06/plan_ab_mbw.txt)
             for (int sp = 1; sp <= 32 && sp <= npatches; ++sp) {
                 if (*splits != 0 ? *splits != sp : (sp > 1 && sp > npatches / 2)) continue;      // (the planner's own splits leave two patches per workgroup)
                 // rounds of workgroups x iterations of the longest split (+ prologue / epilogue of a workgroup, in iterations) x time of an iteration relative to
@@ -786,7 +786,7 @@ int read_plan_env() {
     if (const char* e = getenv("RY_OS2_MAXCOST")) g_os2_maxcost = atoi(e);
     if (const char* e = getenv("RY_OS2_MINW")) g_os2_min_filter = (size_t)atoll(e);
     memset(g_wino_force, 0, sizeof(g_wino_force)); memset(g_wino_forced, 0, sizeof(g_wino_forced));
-    g_wino = 1; g_wino_min_m = 512;
+    g_wino = 1; g_wino_min_m = 256;
     if (const char* e = getenv("RY_WINOGRAD")) g_wino = atoi(e);
     if (const char* e = getenv("RY_WINO_MINM")) g_wino_min_m = atoi(e);
     if (const char* e = getenv("RY_WINO")) {

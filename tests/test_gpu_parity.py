@@ -133,8 +133,12 @@ def test_conv2d_wino_full_size_gpu(gpu_ctx, case):
     bn = bn_params(rng, Cout)
     kw = dict(stride=2, pad=1, transposed=tr, act='relu' if tr else 'lrelu')
     yd = gpu_ctx.conv2d(x, Wt, b, bn, path='igemm', **kw)
-    for tile in (None, (2, 0)):
-        y = gpu_ctx.conv2d(x, Wt, b, bn, path='wino', tile=tile, **kw)
+    for tile in (None, (1, 0), (2, 0)):
+        try:
+            y = gpu_ctx.conv2d(x, Wt, b, bn, path='wino', tile=tile, **kw)
+        except RuntimeError as e:                  # (no tile of that workgroup shape divides the grid: 24 x 32 has no 16-row tile of the eight-wave shape)
+            assert 'no Winograd plan' in str(e) and tile == (2, 0) and (H if tr else H // 2) % 16, (case, tile, e)
+            continue
         y2 = gpu_ctx.conv2d(x, Wt, b, bn, path='wino', tile=tile, **kw)
         assert numpy.array_equal(y, y2)
         assert rel_max(y, yd) < 1e-5, (case, tile, rel_max(y, yd))
