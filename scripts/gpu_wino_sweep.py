@@ -24,7 +24,8 @@ OUT = sys.argv[2] if len(sys.argv) > 2 else str(ROOT / 'gpurun_out' / ('r6_wino_
 REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 NAMES = ['encoder/c%d' % i for i in range(8)] + ['decoder/c%d' % i for i in range(8)]
 LAYERS = tuple(int(v) for v in os.environ.get('SWEEP_LAYERS', '12,13,14,11,1,2,3,4').split(',') if v.strip().isdigit())
-BY_FORWARD = os.environ.get('SWEEP_BY', 'forward') == 'forward'       # rank a layer's plans by the graph-replayed forward they give (default) or by the layer's own eager launches
+BY_FORWARD = os.environ.get('SWEEP_BY', 'forward') in ('forward', 'lanes')       # rank a layer's plans by the graph-replayed forward they give (default) or by the layer's own eager launches
+BY_LANES = os.environ.get('SWEEP_BY', 'forward') == 'lanes'           # ... by the chained two-lane step (bench.py's step) with every OTHER layer on the planner's default: what the headline runs
 EMU = bool(os.environ.get('SWEEP_EMU'))                             # flow check on the CPU emulator (numbers mean nothing)
 SPLITS = tuple(int(v) for v in os.environ.get('SWEEP_SPLITS', '0,1,2,3,4,5,6,8').split(','))
 CFGS = tuple(int(v) for v in os.environ.get('SWEEP_CFGS', '1,2,3,4').split(','))     # 1: 2 x 2 waves, 2: 4 x 2 waves (two slices per barrier), 3 / 4: two channel blocks per wave, one wave per SIMD (2 x 2 / 4 x 1 waves)
@@ -129,6 +130,9 @@ setup('', 0)
 base = layer_us()
 y0 = result()
 f0 = forward_alone()
+if BY_LANES:
+    setup('', 1)
+    f0 = min(two_lane(40) for _ in range(3))          # lanes: the reference is the two-lane step under the planner's own picks
 say('# direct implicit GEMM (RY_WINOGRAD=0): stage-2 forward alone %.4f ms (graph replay)' % f0)
 for l in (1, 2, 3, 4, 11, 12, 13, 14):
     say('#   %-11s %7.2f us   %s' % (NAMES[l], base[NAMES[l]][0], ' + '.join(base[NAMES[l]][1])))
@@ -137,14 +141,14 @@ for layer in LAYERS:
     rows = []
     for c in CONFIGS:
         try:
-            setup(','.join(['%d:0' % l for l in (1, 2, 3, 4, 11, 12, 13, 14) if l != layer] + ['%d:%d:%d:%d' % ((layer,) + c)]))
+            setup(','.join(([] if BY_LANES else ['%d:0' % l for l in (1, 2, 3, 4, 11, 12, 13, 14) if l != layer]) + ['%d:%d:%d:%d' % ((layer,) + c)]))
             lu = layer_us()
         except Exception as e:                                       # no such plan for this layer
             if 'no Winograd plan' not in str(e) and 'RY_WINO' not in str(e):
                 say('%-11s cfg %d mbw %d splits %d: %s' % (NAMES[layer], c[0], c[1], c[2], str(e)[:120]))
             continue
         us, names = lu[NAMES[layer]]
-        fwd = forward_alone(20) * 1e3                                # the whole stage-2 forward under graph replay with this one layer in Winograd form
+        fwd = (two_lane(40) if BY_LANES else forward_alone(20)) * 1e3     # the whole stage-2 forward under graph replay with this one layer in Winograd form (lanes: the two-lane step, the other layers on their defaults)
         rows.append((fwd if BY_FORWARD else us, c, names))
         say('%-11s cfg %d mbw %d splits %2d  %7.2f us  (direct %7.2f)  forward %8.2f us (direct %8.2f)   %s' % (NAMES[layer], c[0], c[1], c[2], us, base[NAMES[layer]][0], fwd, f0 * 1e3, ' + '.join(names)))
     if rows:
@@ -152,7 +156,8 @@ for layer in LAYERS:
         best[layer] = rows[0]
         say('# best %-11s cfg %d mbw %d splits %d: %.2f us against %.2f direct' % ((NAMES[layer],) + rows[0][1] + (rows[0][0], f0 * 1e3 if BY_FORWARD else base[NAMES[layer]][0])))
 if best:
-    spec = ','.join('%d:%d:%d:%d' % ((l,) + best[l][1]) if best[l][0] < (f0 * 1e3 if BY_FORWARD else base[NAMES[l]][0]) else '%d:0' % l for l in sorted(best))
+    spec = ','.join('%d:%d:%d:%d' % ((l,) + best[l][1]) if best[l][0] < (f0 * 1e3 * (0.993 if BY_LANES else 1.0) if BY_FORWARD else base[NAMES[l]][0]) else ('' if BY_LANES else '%d:0' % l) for l in sorted(best))
+    spec = ','.join(v for v in spec.split(',') if v)
     setup(spec)
     yb = result()
     fb = forward_alone()
