@@ -38,7 +38,7 @@ for q in s2q:
         if prev_end is not None:
             st[2] += max(0, s - prev_end) / 1e3
         prev_end = e
-big = [(s, e) for s, e, q, n in rows if 'ry_igemm' in n and e - s >= 40000]
+big = [(s, e) for s, e, q, n in rows if ('ry_igemm' in n or 'ry_wino' in n) and e - s >= 40000]
 ev = []
 for s, e in big:
     ev.append((s, 0, 'B', 1)); ev.append((e, 0, 'B', -1))
@@ -63,7 +63,7 @@ wall = (rows[-1][1] - rows[0][0]) / 1e3
 nwin = per_pos[0][0]
 with open(sys.argv[2], 'w') as f:
     f.write('# %s\n' % sys.argv[3])
-    f.write('# %d windows in %.1f ms; no MFMA-bound launch (igemm >= 40 us) on the chip for %.1f ms = %.1f %% = %.1f us per window\n' % (nwin, wall / 1e3, t_none / 1e3, 100 * t_none / wall, t_none / max(nwin, 1)))
+    f.write('# %d windows in %.1f ms; no MFMA-bound launch (igemm | wino >= 40 us) on the chip for %.1f ms = %.1f %% = %.1f us per window\n' % (nwin, wall / 1e3, t_none / 1e3, 100 * t_none / wall, t_none / max(nwin, 1)))
     f.write('# what the two stage-2 queues run meanwhile (sequence position:kernel; us per window)\n')
     for key, v in sorted(acc.items(), key=lambda kv: -kv[1])[:28]:
         f.write('%8.1f  %s\n' % (v / max(nwin, 1), '  +  '.join(key)))

@@ -34,7 +34,7 @@ for t, d, q in ev:
 wall = t1 - t0
 # the MFMA-bound launches (implicit-GEMM kernels of at least 40 us): how long is at least one of them on the chip, how long two of them together,
 # and how long does NOTHING run -- what two lanes can and cannot hide
-big = sorted((s_, e_) for s_, e_, q_, n_ in rows if 'ry_igemm' in n_ and e_ - s_ >= 40000)
+big = sorted((s_, e_) for s_, e_, q_, n_ in rows if ('ry_igemm' in n_ or 'ry_wino' in n_) and e_ - s_ >= 40000)
 bev = sorted([(s_, 1) for s_, _ in big] + [(e_, -1) for _, e_ in big])
 nb = 0; lastb = t0; big1 = 0; big2 = 0
 for t, d in bev:
@@ -57,7 +57,7 @@ with open(sys.argv[2], 'w') as f:
     f.write('nothing running                          %.3f ms  %.1f %%  (%d gaps; median %.1f us, the 10 longest %s us)\n' % (
         (wall - any_t) / 1e6, 100.0 * (wall - any_t) / wall, len(gaps), (gaps[len(gaps) // 2] / 1e3 if gaps else 0.0),
         ' '.join('%.0f' % (g / 1e3) for g in gaps[:10])))
-    f.write('>= 1 MFMA-bound launch (igemm >= 40 us)   %.3f ms  %.1f %%   (%d such launches, sum of their durations %.3f ms)\n' % (
+    f.write('>= 1 MFMA-bound launch (igemm | wino >= 40 us)   %.3f ms  %.1f %%   (%d such launches, sum of their durations %.3f ms)\n' % (
         big1 / 1e6, 100.0 * big1 / wall, len(big), sum(e_ - s_ for s_, e_ in big) / 1e6))
     f.write('>= 2 MFMA-bound launches together         %.3f ms  %.1f %%\n' % (big2 / 1e6, 100.0 * big2 / wall))
     for q, (n, busy) in sorted(per_q.items(), key=lambda kv: -kv[1][1]):
