@@ -8,16 +8,19 @@ static void fill_geom(RyConvGeom& g, const Layer& l, const LayerPlan& lp, int B,
     memset(&g, 0, sizeof g);
     const TapTable t = make_taps(l);
     g.src1 = s1; g.src2 = s2; g.C1 = C1; g.C2 = C2; g.S1 = C1; g.S2 = C2;
-    if (lp.path == PATH_IGEMM_BF16 && lp.x3) { g.C1 = 3 * C1; g.C2 = 3 * C2; g.S1 = 2 * C1; g.S2 = 2 * C2; }   // K = [hi | lo | hi(wrapped)] over [hi | lo] pixels
+    // K = [hi | lo | hi(wrapped)] over [hi | lo] pixels
+    if (lp.path == PATH_IGEMM_BF16 && lp.x3) { g.C1 = 3 * C1; g.C2 = 3 * C2; g.S1 = 2 * C1; g.S2 = 2 * C2; }
     g.B = B; g.Hi = lp.Hi; g.Wi = lp.Wi; g.Ho = lp.Ho; g.Wo = lp.Wo;
     g.Hs = lp.Hi; g.Hos = lp.Ho;
-    if (lp.crop_hi > 0) { g.Hi = lp.crop_hi; g.Ho = l.deconv ? 2 * lp.crop_hi : lp.crop_hi; }   // a row range of every image in the same buffers; the rows around it read as padding
+    // a row range of every image in the same buffers; the rows around it read as padding
+    if (lp.crop_hi > 0) { g.Hi = lp.crop_hi; g.Ho = l.deconv ? 2 * lp.crop_hi : lp.crop_hi; }
     if (l.deconv) { g.Mh = g.Hi; g.Mw = lp.Wi; g.stride = 1; g.pad = 0; g.ostride = 2; }
     else { g.Mh = g.Ho; g.Mw = lp.Wo; g.stride = l.stride; g.pad = l.pad; g.ostride = 1; }
     g.nphases = t.nphases; g.ntaps = t.ntaps; g.N = l.cout; g.kw = l.deconv ? 2 : l.k; g.dil = l.deconv ? 1 : l.dil;
     const size_t esize = lp.path == PATH_IGEMM_BF16 ? 2 : 4;                  // implicit-GEMM sources end in a zeroed tail (ZTAIL floats)
     g.zoff1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * g.S1 * esize); g.zoff2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * g.S2 * esize);
-    if (lp.crop_hi > 0 && lp.crop_lo > 0) {                                   // the range starts crop_lo rows into every image: move the bases, keep the zero tails where they are
+    // the range starts crop_lo rows into every image: move the bases, keep the zero tails where they are
+    if (lp.crop_hi > 0 && lp.crop_lo > 0) {
         const size_t o1 = (size_t)lp.crop_lo * lp.Wi * g.S1 * esize, o2 = (size_t)lp.crop_lo * lp.Wi * g.S2 * esize;
         g.src1 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(s1) + o1); g.zoff1 -= (unsigned)o1;
         if (s2) { g.src2 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(s2) + o2); g.zoff2 -= (unsigned)o2; }
@@ -45,7 +48,8 @@ static int launch_c2d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     if (!l.w2os || C1 % 256 || C2 % 256 || l.cout % NT || U % (4 * lp.os2_waves) || (size_t)C1 > ZTAIL || (size_t)C2 > ZTAIL)
         return fail(RY_ESTATE, "%s: not a shape for the output-stationary kernel (slice %dx%d, %d waves, depth %d)", l.name, lp.os2_mt4, lp.os2_nt4, lp.os2_waves, lp.os2_depth);
     if (p.M >= (1 << 24) || (long long)p.mtiles * p.ntiles * p.nphases >= (1 << 24)) return fail(RY_EINVAL, "%s: more than 2^24 rows or tiles in one launch", l.name);
-    if (((size_t)B * lp.Hi * lp.Wi * (size_t)(C1 > C2 ? C1 : C2) + ZTAIL) * 4 >= ((size_t)1 << 32))      // the kernel's pixel offsets (zp1 / zp2, its offset table) are 32-bit byte offsets
+    // the kernel's pixel offsets (zp1 / zp2, its offset table) are 32-bit byte offsets
+    if (((size_t)B * lp.Hi * lp.Wi * (size_t)(C1 > C2 ? C1 : C2) + ZTAIL) * 4 >= ((size_t)1 << 32))
         return fail(RY_EINVAL, "%s: a source of 4 GiB or more does not fit the output-stationary kernel's 32-bit offsets", l.name);
     p.zp1 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C1 * 4); p.zp2 = (unsigned)((size_t)B * lp.Hi * lp.Wi * C2 * 4);
     p.inv_Mimg = 1.f / (float)(p.Mh * p.Mw); p.inv_Mw = 1.f / p.Mw; p.inv_mtiles = 1.f / p.mtiles; p.inv_ntiles = 1.f / p.ntiles; p.inv_cpt = 1.f / cpt;
@@ -54,7 +58,8 @@ static int launch_c2d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
     char nm[48];
     const bool xl = os2_xl_ok(lp.os2_mt4, lp.os2_waves, lp.os2_depth);
-    snprintf(nm, sizeof nm, "ry_c2d_os<%d,%d,%d,%d,%s>", lp.os2_mt4, lp.os2_nt4, lp.os2_waves, lp.os2_depth, xl ? "true" : "false");      // as rocprofv3 prints it
+    // as rocprofv3 prints it
+    snprintf(nm, sizeof nm, "ry_c2d_os<%d,%d,%d,%d,%s>", lp.os2_mt4, lp.os2_nt4, lp.os2_waves, lp.os2_depth, xl ? "true" : "false");
     RY_TRY(Lc.begin(nm, l.name, lp.flops, lp.bytes, grid));
     bool done = false;
 #define X(A, B_, C, D)                                                                                          \
@@ -68,7 +73,8 @@ static int launch_c2d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     return Lc.end();
 }
 
-// the rows a launch left out of its grid (LayerPlan::hole_*): copies of the row above them, into the fp32 output and / or the bf16 copy ([pixel][N] or split [pixel][hi | lo])
+// the rows a launch left out of its grid (LayerPlan::hole_*): copies of the row above them, into the fp32 output and / or the bf16 copy ([pixel][N]
+// or split [pixel][hi | lo])
 static int launch_rep_rows(Launcher& Lc, const Layer& l, const LayerPlan& lp, int B) {
     for (int copy = 0; copy < 2; ++copy) {
         if (copy == 0 ? !lp.w32 : !lp.w16) continue;
@@ -92,7 +98,8 @@ static int launch_reduce(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     r.slabs = lp.slabs + ro; r.splits = lp.splits; r.slab_stride = slab_stride;
     r.scale = l.scale; r.shift = l.shift; r.out = lp.w32 ? lp.out + ro : nullptr; r.out16 = lp.w16 ? lp.out16 + ro * (lp.o16x3 ? 2 : 1) : nullptr;
     r.x3 = lp.o16x3 ? 1 : 0;
-    r.total = B == 1 ? (long long)Ho_run * lp.Wo * l.cout : slab_stride; r.N = l.cout;      // one window: only the rows this launch wrote (a prefix when cropped)
+    // one window: only the rows this launch wrote (a prefix when cropped)
+    r.total = B == 1 ? (long long)Ho_run * lp.Wo * l.cout : slab_stride; r.N = l.cout;
     r.act = l.act; r.slope = slope;
     if (lp.splits >= 16 && r.total <= (1 << 20)) {      // many slabs, few outputs
         dim3 rg((unsigned)((r.total / 4 + 63) / 64));
@@ -119,7 +126,8 @@ static int launch_wino(Launcher& Lc, const Layer& l, const LayerPlan& lp, const 
     p.g = g; p.wt = wwin; p.scale = l.scale; p.shift = l.shift;
     p.splits = lp.splits; p.act = l.act; p.slope = slope;
     p.slab_stride = (long long)B * lp.Ho * lp.Wo * l.cout;
-    const size_t oo = lp.crop_hi > 0 ? (size_t)(l.deconv ? 2 : 1) * lp.crop_lo * lp.Wo * l.cout : 0;     // output rows start (2 x for the sub-pixel form) crop_lo rows into every image
+    // output rows start (2 x for the sub-pixel form) crop_lo rows into every image
+    const size_t oo = lp.crop_hi > 0 ? (size_t)(l.deconv ? 2 : 1) * lp.crop_lo * lp.Wo * l.cout : 0;
     p.out = lp.splits > 1 ? lp.slabs + oo : lp.out + oo;
     if (!p.out) return fail(RY_ESTATE, "%s: no output buffer", l.name);
     p.mbw = lp.wino_mbw; p.tcols = g.Mw / tw; p.trows = g.Mh / th;
@@ -161,7 +169,8 @@ static int launch_wino(Launcher& Lc, const Layer& l, const LayerPlan& lp, const 
         else RY_LAUNCH((ry_wino_ldsdma<4, 2, 2, 2>), grid, 512, Lc.stream, p);
     }
     RY_TRY(Lc.end());
-    // (with an external split the rows left out of the grid have no slabs: the reduce node writes whatever their slab memory holds, the copy node behind it fills them in)
+    // (with an external split the rows left out of the grid have no slabs: the reduce node writes whatever their slab memory holds, the copy node
+    // behind it fills them in)
     if (lp.splits > 1) RY_TRY(launch_reduce(Lc, l, lp, B, g.Ho, oo, p.slab_stride, slope));
     if (p.hole_nt > 0) RY_TRY(launch_rep_rows(Lc, l, lp, B));
     return RY_OK;
@@ -303,7 +312,8 @@ static int launch_conv2d(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
         dim3 grid((unsigned)((total + 7) / 8));
         if (C1 + C2 == 128 && lp.Wi % 16 == 0) {
             const long long strips = (long long)B * p.rows_valid * (lp.Wi / 16);
-            p.xcd_band = 1;                                   // every XCD owns a contiguous band of output rows (45.0 -> 31.5 us against raster order)
+            // every XCD owns a contiguous band of output rows (45.0 -> 31.5 us against raster order)
+            p.xcd_band = 1;
             const long long nb = (strips + 7) / 8;
             dim3 sg((unsigned)(((nb + 7) / 8) * 8));
             RY_TRY(Lc.begin("ry_sr_last<false>", l.name, lp.flops, lp.bytes, sg));
@@ -372,7 +382,8 @@ static int launch_c1d_os(Launcher& Lc, const Layer& l, const LayerPlan& lp, int 
     const bool usrc = Cb == 0 || Ca % 64 == 0;
     if (!usrc && !(lp.os_cb == 2 && lp.os_tp == 4)) return fail(RY_ESTATE, "%s: a layer whose sources split inside a wave runs the 2x4 slice", l.name);
     char nm[48];
-    snprintf(nm, sizeof nm, "ry_c1d_os<%d,%d,%d,%s,%s>", mode, lp.os_cb, lp.os_tp, n_real > 0 ? "true" : "false", usrc ? "true" : "false");   // as rocprofv3 prints it (MODE: 0 = k4 s2 conv, 1 = stride-1 conv, 2 = k4 s2 deconv)
+    // as rocprofv3 prints it (MODE: 0 = k4 s2 conv, 1 = stride-1 conv, 2 = k4 s2 deconv)
+    snprintf(nm, sizeof nm, "ry_c1d_os<%d,%d,%d,%s,%s>", mode, lp.os_cb, lp.os_tp, n_real > 0 ? "true" : "false", usrc ? "true" : "false");
     RY_TRY(Lc.begin(nm, l.name, lp.flops, lp.bytes, grid));
 #define RY_OS_CASE(MODE_, CB_, TP_) if (usrc && lp.os_cb == CB_ && lp.os_tp == TP_) { RY_LAUNCH((ry_c1d_os<MODE_, CB_, TP_, false, true>), grid, 256, Lc.stream, p); } else
 #define RY_OS_CASE_NU(MODE_) if (!usrc) { RY_LAUNCH((ry_c1d_os<MODE_, 2, 4, false, false>), grid, 256, Lc.stream, p); } else
@@ -422,7 +433,8 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
     const float slope = d.lrelu_slope;
     // the fused pad takes the column minimum inside the workgroups that reach the padding: one chain of n_frames / 8 load rounds, worth
     // it while the window is short (measured: 300 frames -3 us, 1000 frames +14 us against the separate ry_pad_min_rows node)
-    const bool padfuse_now = nd == 1 && P.s1_padfuse && P.n_frames <= 2048;     // [r5] (the cooperative minimum: one round of loads per 1024 frames; was 512 with the per-lane walk)
+    // [r5] (the cooperative minimum: one round of loads per 1024 frames; was 512 with the per-lane walk)
+    const bool padfuse_now = nd == 1 && P.s1_padfuse && P.n_frames <= 2048;
     if (P.mode == 1 && !padfuse_now) {
         const int cols_in = nd == 1 ? d.in_ch : d.width + 1;
         const int cols_out = nd == 1 ? d.in_ch : d.width;
@@ -469,7 +481,8 @@ static int enqueue_forward(ry_net* net, Plan& P, Launcher& Lc) {
             else break;
             const int Mw = l.deconv ? lp.Wi : lp.Wo, Mh = l.deconv ? lp.Hi : lp.Ho;
             int th = 1;
-            if (plan_tile_rows(lp, Mh, Mw, &th)) { r0 = r0 / th * th; r1 = (r1 + th - 1) / th * th; }      // keep the 2-D pixel tiles of the launch: whole tile rows
+            // keep the 2-D pixel tiles of the launch: whole tile rows
+            if (plan_tile_rows(lp, Mh, Mw, &th)) { r0 = r0 / th * th; r1 = (r1 + th - 1) / th * th; }
             if (r1 > lp.Hi) r1 = lp.Hi;
             if (r0 <= 0 && r1 >= lp.Hi) break;
             // measured at 300 frames (round 2, interleaved A/B on one box): decoder c6 (1536 -> 1216 workgroups, six per CU -> five) 208 -> 177 us, decoder c5
@@ -616,7 +629,8 @@ int autotune_plan(ry_net* net, Plan& P) {
         float* tmp_slabs = nullptr;
         if (max_sp > 1) {
             void* q = nullptr;
-            if (rt::dmalloc(&q, out_elems * (size_t)max_sp * sizeof(float)) != 0) { (void)rt::last_error(); continue; }   // no room to tune this layer: keep the pick
+            // no room to tune this layer: keep the pick
+            if (rt::dmalloc(&q, out_elems * (size_t)max_sp * sizeof(float)) != 0) { (void)rt::last_error(); continue; }
             tmp_slabs = (float*)q;
         }
         int best = 0; float best_ms = 1e30f;
@@ -992,7 +1006,8 @@ int ry_conv2d_dilated(ry_ctx* ctx, const float* x, int B, int H, int Wd, int Cin
         } else {
             for (size_t q = 0; q < nx; ++q) x16[q] = host_f2bf(x[q]);
         }
-        RT_TRY(rt::dmemset(dx, 0, (nx + ZTAIL) * sizeof(float), ctx->stream));      // the bf16 data ends half way (split-bf16: at the end): zero tail right behind it
+        // the bf16 data ends half way (split-bf16: at the end): zero tail right behind it
+        RT_TRY(rt::dmemset(dx, 0, (nx + ZTAIL) * sizeof(float), ctx->stream));
         RT_TRY(rt::h2d(dx, x16.data(), x16.size() * sizeof(unsigned short), ctx->stream));
         RT_TRY(rt::stream_sync(ctx->stream));
         RY_TRY(launch_conv2d(Lc, l, lp, B, dx, Cin, nullptr, 0, 0.2f));

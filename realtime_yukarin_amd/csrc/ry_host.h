@@ -71,7 +71,8 @@ static err_t event_record(Event& e, ry_stream_t s) { return hipEventRecord(e, s)
 static err_t event_sync(Event& e) { return hipEventSynchronize(e); }
 static err_t event_elapsed(float* ms, Event& a, Event& b) { return hipEventElapsedTime(ms, a, b); }
 static err_t stream_wait_event(ry_stream_t s, Event& e) { return hipStreamWaitEvent(s, e, 0); }
-static err_t hmalloc(void** p, size_t bytes) { return hipHostMalloc(p, bytes ? bytes : 256, hipHostMallocDefault); }   // pinned: async copies really are asynchronous
+// pinned: async copies really are asynchronous
+static err_t hmalloc(void** p, size_t bytes) { return hipHostMalloc(p, bytes ? bytes : 256, hipHostMallocDefault); }
 static err_t hfree(void* p) { return hipHostFree(p); }
 static err_t event_create_fast(Event* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming); }
 #endif
@@ -135,7 +136,8 @@ struct Arena {
         for (void* q : bufs) rt::dfree(q);
         bufs.clear();
     }
-    std::map<int, float*> lazy;          // filter layouts built on first use (key = layer index): shared by the clones of a predictor like everything in this arena
+    // filter layouts built on first use (key = layer index): shared by the clones of a predictor like everything in this arena
+    std::map<int, float*> lazy;
     void free_one(void* q) {               // a buffer that is being replaced by a larger one
         for (size_t i = 0; i < bufs.size(); ++i)
             if (bufs[i] == q) { rt::dfree(q); bufs.erase(bufs.begin() + (long)i); return; }
@@ -161,10 +163,15 @@ struct Layer {
     float* w1os = nullptr;               // stage-1 [N][Ctot][4] (output-stationary kernel ry_c1d_os: lanes = input channels)
     float* wig = nullptr;                // stage-2 implicit-GEMM blocks [phase][N/64][tap][Ctot/32][fragment order], see wig_inblock()
     float* wdir = nullptr;               // stage-2 direct [phase][tap][Ctot][N]
-    float* wig16 = nullptr;              // stage-2 implicit-GEMM bf16 blocks [phase][N/64][tap][Ctot/64][fragment order], see wig16_inblock() (ry_net_set_dtype)
-    float* w2os = nullptr;               // stage-2 output-stationary kernel ry_c2d_os: [phase][N/4][tap][Ctot/64][lane][4], see relayout_c2d_os() (the weight-streaming layers only)
-    float* wwin = nullptr;               // stage-2 Winograd F(2x2, 2x2) filters [phase][N/64][slice of 8 channels][position 9][n/32][lane][4], see relayout_wino() (op-level calls; predictors: Arena::lazy)
-    float* wigx3 = nullptr;              // split-bf16 blocks [phase][N/64][tap][3 Ctot/64][fragment order]: K runs over [hi | hi | lo] per source, see build_wigx3()
+    // stage-2 implicit-GEMM bf16 blocks [phase][N/64][tap][Ctot/64][fragment order], see wig16_inblock() (ry_net_set_dtype)
+    float* wig16 = nullptr;
+    // stage-2 output-stationary kernel ry_c2d_os: [phase][N/4][tap][Ctot/64][lane][4], see relayout_c2d_os() (the weight-streaming layers only)
+    float* w2os = nullptr;
+    // stage-2 Winograd F(2x2, 2x2) filters [phase][N/64][slice of 8 channels][position 9][n/32][lane][4], see relayout_wino() (op-level calls;
+    // predictors: Arena::lazy)
+    float* wwin = nullptr;
+    // split-bf16 blocks [phase][N/64][tap][3 Ctot/64][fragment order]: K runs over [hi | hi | lo] per source, see build_wigx3()
+    float* wigx3 = nullptr;
     int cin() const { return cin_a + cin_b; }
 };
 
@@ -172,7 +179,8 @@ enum { PATH_IGEMM = 1, PATH_DIRECT = 2, PATH_FIRST = 3, PATH_LAST = 4, PATH_IGEM
        PATH_IGEMM_X3 = 6,     // op-level selector only (ry_conv2d): runs as PATH_IGEMM_BF16 with LayerPlan::x3
        PATH_OS2D = 7,         // output-stationary weight-streaming layer (ry_c2d_os): one node, no slabs
        PATH_WINO = 8 };       // k4 s2 p1 layer in Winograd F(2x2, 2x2) form on the fp32 matrix pipe (ry_wino_ldsdma): 9 / 16 of the direct form's MFMA work
-enum { TILE_128x128 = 1, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5, TILE_96x128 = 6 };   // (2 and 7 were the 256-row tiles of the register-staged kernel, removed in round 3)
+// (2 and 7 were the 256-row tiles of the register-staged kernel, removed in round 3)
+enum { TILE_128x128 = 1, TILE_64x128 = 3, TILE_32x128 = 4, TILE_128x64 = 5, TILE_96x128 = 6 };
 
 struct LayerPlan {
     // geometry
@@ -181,12 +189,15 @@ struct LayerPlan {
     int splits = 1;
     long long slab_stride = 0;
     float* raw = nullptr;                     // [splits][B*Lo][N] raw sums
-    int os_cb = 0, os_tp = 0, os_kt = 0;      // output-stationary stage-1 kernel (ry_c1d_os): output channels / rows per workgroup slice, ci waves per position group
+    // output-stationary stage-1 kernel (ry_c1d_os): output channels / rows per workgroup slice, ci waves per position group
+    int os_cb = 0, os_tp = 0, os_kt = 0;
     // stage-2
     int path = 0, tile = 0;
     bool any_m_patch = false;                 // op-level calls (tests): take the input-patch variants whatever the row count
-    int os2_mt4 = 0, os2_nt4 = 0, os2_waves = 0, os2_depth = 0;   // PATH_OS2D: tile of 4 mt4 pixels x 4 nt4 channels per workgroup, waves that share the K axis, units in flight per wave
-    int wino_cfg = 0, wino_mbw = 0;           // PATH_WINO: workgroup shape (1 = 2 x 2 waves, one 8-channel slice per iteration; 2 = 4 x 2 waves, two slices) and M-blocks per tile row
+    // PATH_OS2D: tile of 4 mt4 pixels x 4 nt4 channels per workgroup, waves that share the K axis, units in flight per wave
+    int os2_mt4 = 0, os2_nt4 = 0, os2_waves = 0, os2_depth = 0;
+    // PATH_WINO: workgroup shape (1 = 2 x 2 waves, one 8-channel slice per iteration; 2 = 4 x 2 waves, two slices) and M-blocks per tile row
+    int wino_cfg = 0, wino_mbw = 0;
     int kg = 1;                               // K groups inside a workgroup (LDS-DMA implicit GEMM): 2 = split-K summed through the LDS
     float* out = nullptr;                     // NHWC activation, fp32
     unsigned short* out16 = nullptr;          // NHWC activation, bf16 copy for consumers on the bf16 path (bf16 / split-bf16 mode only)
@@ -194,9 +205,11 @@ struct LayerPlan {
     bool x3 = false;                          // PATH_IGEMM_BF16 in split-bf16 form: sources are [pixel][hi | lo], K = [hi | lo | hi] x filters [hi | hi | lo]
     bool o16x3 = false;                       // format of the out16 copy this layer writes: plain bf16 or split [hi | lo]
     float* slabs = nullptr;
-    int hole_lo = 0, hole_n = 0;              // > 0 (set per enqueue): output rows hole_lo .. hole_lo + hole_n - 1 equal row hole_lo - 1 (padding behind the real frames): not computed, copied
-    int crop_hi = 0;                          // > 0 (set per enqueue, one window): the layer runs on the first crop_hi input rows only -- the rows behind them feed nothing but
-                                              // output rows the convert wrapper throws away (dead padding rows, see enqueue_forward)
+    // > 0 (set per enqueue): output rows hole_lo .. hole_lo + hole_n - 1 equal row hole_lo - 1 (padding behind the real frames): not computed, copied
+    int hole_lo = 0, hole_n = 0;
+    // > 0 (set per enqueue, one window): the layer runs on the first crop_hi input rows only -- the rows behind them feed nothing but
+    // output rows the convert wrapper throws away (dead padding rows, see enqueue_forward)
+    int crop_hi = 0;
     int crop_lo = 0;                          // ... starting at this input row (> 0 when the caller discards the leading frames of the window too)
     int last_rows = 0, last_cols = 0, last_exp = 0;   // PATH_LAST: fused exp / edge-pad / crop
     int last_row0 = 0, last_out_rows = 0;     // PATH_LAST: first output row computed, rows per image of the caller's block (0: last_rows)
@@ -208,7 +221,8 @@ struct Plan {
     int B = 0, T = 0;
     int mode = 0;                             // 0 = forward, 1 = convert wrapper
     int n_frames = 0;
-    int disc_front = 0, disc_back = 0;        // convert mode, stage 2: the caller throws away this many leading / trailing frames of every window (ry_sr_convert_rows)
+    // convert mode, stage 2: the caller throws away this many leading / trailing frames of every window (ry_sr_convert_rows)
+    int disc_front = 0, disc_back = 0;
     Arena arena;
     std::vector<LayerPlan> lp;
     float* user_in = nullptr;                 // staging of the caller's input

@@ -96,7 +96,8 @@ struct RyConvGeom {
     int S1, S2;                 // LDS-DMA kernel: elements per pixel of each source (= C1 / C2, except in the split-bf16 mode where a pixel
                                 // keeps [hi | lo] = 2 C bf16 and the K axis runs over [hi | lo | hi] = 3 C: a channel offset past S wraps to 0)
     int B, Hi, Wi, Ho, Wo;
-    int Hs, Hos;                // rows per image IN MEMORY of the sources / the output (>= Hi / Ho: a launch may cover a row prefix of every image, see LayerPlan::crop_hi)
+    // rows per image IN MEMORY of the sources / the output (>= Hi / Ho: a launch may cover a row prefix of every image, see LayerPlan::crop_hi)
+    int Hs, Hos;
     int Mh, Mw;
     int stride, pad, ostride;
     int nphases, ntaps;
@@ -125,11 +126,13 @@ struct RyIgemmParams {
     // host-side helpers of the LDS-DMA kernel's prologue (reciprocals for ry_fdiv, the 2-D tile grid, the K split)
     float inv_nphases, inv_ntiles, inv_mtiles, inv_Mimg, inv_Mw, inv_cpt, inv_kw, inv_tcols, inv_trows;
     int tw_shift, th, tcols, trows;   // 2-D M-tiles: tw = 1 << tw_shift columns x th rows, tcols x trows tiles per image
-    int xcd_gs, xcd_gs_shift, xcd_nsg, xcd_mtg;   // LDS-DMA kernel: XCD grouping (gs slice groups of xcd_nsg slices x 8/gs M-tile groups of xcd_mtg tiles); 0 = contiguous runs
+    // LDS-DMA kernel: XCD grouping (gs slice groups of xcd_nsg slices x 8/gs M-tile groups of xcd_mtg tiles); 0 = contiguous runs
+    int xcd_gs, xcd_gs_shift, xcd_nsg, xcd_mtg;
     float inv_xcd_nsg, inv_nsl; // reciprocals of xcd_nsg and of the slice count splits * ntiles * nphases
     int kq, krem;               // K chunks per split: split s takes kq + (s < krem) chunks starting at s * kq + min(s, krem)
-    int hole_ty, hole_nt;       // 2-D M-tiles: tile rows hole_ty .. hole_ty + hole_nt - 1 of every image are not computed (`trows` counts the computed ones): rows of the
-                                // padding that equal the row above them, filled in by ry_rep_rows (hole_nt = 0: none)
+    // 2-D M-tiles: tile rows hole_ty .. hole_ty + hole_nt - 1 of every image are not computed (`trows` counts the computed ones): rows of the
+    // padding that equal the row above them, filled in by ry_rep_rows (hole_nt = 0: none)
+    int hole_ty, hole_nt;
     int tw;                     // > 0: an M-tile is a 2-D block of (BM/tw) x tw rows of the Mh x Mw grid (compact input footprint:
                                 //      overlapping taps hit L2); 0: BM consecutive rows in raster order
 };
@@ -683,11 +686,14 @@ struct RyWinoParams {
 template <int WM, int WN, int NSL, int MODE>
 RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
-    constexpr int NPOS = WM == 2 ? 304 : 592;          // patch positions per A buffer: 17 x 17 / 9 x 33 (WM = 2), 17 x 33 / 33 x 17 / 9 x 65 (WM = 4), rounded up to whole DMA pieces
+    // patch positions per A buffer: 17 x 17 / 9 x 33 (WM = 2), 17 x 33 / 33 x 17 / 9 x 65 (WM = 4), rounded up to whole DMA pieces
+    constexpr int NPOS = WM == 2 ? 304 : 592;
     constexpr int AG = NPOS / 16;                      // 1-KiB DMA pieces per patch (16 positions x 64 bytes)
     constexpr int AI = (AG + NW - 1) / NW;
-    constexpr int AH = AI;                             // pieces of the next patch issued in the first iteration of the current one: all of them (NSL = 1: they have the second iteration to land)
-    constexpr int AFLY = AG / NW;                      // patch pieces EVERY wave issues behind its filter pieces (the waves with a piece more wait for their first one too)
+    // pieces of the next patch issued in the first iteration of the current one: all of them (NSL = 1: they have the second iteration to land)
+    constexpr int AH = AI;
+    // patch pieces EVERY wave issues behind its filter pieces (the waves with a piece more wait for their first one too)
+    constexpr int AFLY = AG / NW;
     constexpr int BSL = 9 * WN * 256;                  // floats of one filter slice (8 channels x 9 positions x 32 WN output channels)
     constexpr int BG = NSL * 9 * WN;                   // DMA pieces per iteration
     constexpr int BI = (BG + NW - 1) / NW;
@@ -739,7 +745,8 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
     const float* wt_it = p.wt + ((size_t)(phase * p.ntiles + nt) * (size_t)(2 * p.npatches) + (size_t)(2 * pbeg)) * BSL;
     auto b_item = [&](int j, float* Bd) {
         const int gi = j * NW + wave;
-        if (BG % NW == 0 || gi < BG) ry_glds16_off(wt_it, (unsigned)(gi * 1024 + lane * 16), Bd + gi * 256);     // (uniform base + 32-bit lane offset: the scalar-base addressing mode)
+        // (uniform base + 32-bit lane offset: the scalar-base addressing mode)
+        if (BG % NW == 0 || gi < BG) ry_glds16_off(wt_it, (unsigned)(gi * 1024 + lane * 16), Bd + gi * 256);
     };
     if (nit > 0) {                                          // the filters of the first iteration travel while the A side is set up
 #pragma unroll
@@ -796,7 +803,8 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
         const int chunk = MODE == 2 ? pch >> 2 : pch;
         const int ci0 = chunk * 16;
         c_first = ci0 < g.C1;
-        c_src = (c_first ? g.src1 : g.src2) + (c_first ? ci0 : ci0 - g.C1);     // the channel offset rides on the scalar base (the zero tail is a whole zeroed pixel)
+        // the channel offset rides on the scalar base (the zero tail is a whole zeroed pixel)
+        c_src = (c_first ? g.src1 : g.src2) + (c_first ? ci0 : ci0 - g.C1);
         if (MODE == 2) {
             c_par = pch & 3;
             const int dpix = (((pch >> 1) & 1) - 1) * g.Wi + ((pch & 1) - 1);
@@ -840,7 +848,10 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     __syncthreads();
 
-    // ONE code path per unrolled iteration (the requests of the next iteration sit behind wave-uniform branches): a variant per request pattern as a
+    // ONE code path per unrolled iteration (the requests of the next iteration sit behind wave-uniform branches -- issuing them unconditionally, the
+    // last iteration
+    // re-fetching its own operands, measured +3 % on the convolution layers and +-0 on the others, profiles/r06/dma_uncond_ab.txt): a variant per
+    // request pattern as a
     // compile-time argument made hipcc 7.2 keep the 144 accumulator registers of the variants in different places and spill them at the joins.
     auto run_it = [&](auto k4c, int k) {
         constexpr int K4 = decltype(k4c)::value;
@@ -853,13 +864,15 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
         const bool more_b = k + 1 < nit;
         const bool more_a = k - SL + 2 / NSL < nit;                       // a next patch exists
         if (more_a && SL == 0) next_patch();
-        // DMA pieces of the next iteration (filters) and of the next patch (its first AH pieces with the first slice, the rest with the second), one per position
+        // DMA pieces of the next iteration (filters) and of the next patch (its first AH pieces with the first slice, the rest with the second), one
+        // per position
         constexpr int A_LO = SL == 0 ? 0 : AH, A_HI = SL == 0 ? AH : AI, NITEM = BI + (A_HI - A_LO);
         auto issue1 = [&](int item) {
             if (item < BI) { if (more_b) b_item(item, Bn); }
             else if (item < NITEM) { if (more_a) a_item(A_LO + item - BI, An); }
         };
-        auto issue = [&](int step) {                   // in order -- filters first (needed at the next barrier), then the patch --, spread evenly over the position steps
+        // in order -- filters first (needed at the next barrier), then the patch --, spread evenly over the position steps
+        auto issue = [&](int step) {
 #pragma unroll
             for (int item = (step * NITEM) / (9 * NSL); item < ((step + 1) * NITEM) / (9 * NSL); ++item) issue1(item);
         };
@@ -870,9 +883,11 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
             for (int q = 0; q < 9; ++q) {
                 v[q] = ry_ld4(Ac + (aaddr[q] ^ ((SL + s) * 8)));
             }
-            // MFMA order: the three positions of a row TOGETHER, K step by K step -- consecutive MFMAs go to different accumulators.  (The first form ran the four
+            // MFMA order: the three positions of a row TOGETHER, K step by K step -- consecutive MFMAs go to different accumulators.  (The first form
+            // ran the four
             // K steps of one position back to back: every VALU / LDS / DMA instruction the scheduler placed between two MFMAs on the SAME accumulator cost
-            // ~43 cycles (MI355X_MICROARCH.md, cycle constants) -- the input transform alone 13 % of a launch, profiles/r06/wino_ablation.txt.)  The filter fragments
+            // ~43 cycles (MI355X_MICROARCH.md, cycle constants) -- the input transform alone 13 % of a launch, profiles/r06/wino_ablation.txt.)  The
+            // filter fragments
             // of the next row are requested before the MFMAs of this one.
             auto ldb = [&](int q) -> f32x4 {
                 return ry_ld4(Bc + s * BSL + (q * WN + wn) * 256 + lane * 4);
@@ -908,7 +923,8 @@ RY_KERNEL(64 * WM * WN, 2) void ry_wino_ldsdma(RyWinoParams p) {
         if (more_b) wt_it += NSL * BSL;
         // The filters of iteration k + 1 have to be in the LDS behind this barrier; the pieces of the next patch, requested BEHIND them, are read two barriers
         // from here (NSL = 1) and may stay in flight: vmcnt counts this wave's requests in order, AFLY of the youngest are patch pieces in every wave.
-        // (A __syncthreads() here drains every request: the landing time of the youngest -- activations out of another XCD's L2 -- was exposed at every barrier.)
+        // (A __syncthreads() here drains every request: the landing time of the youngest -- activations out of another XCD's L2 -- was exposed at
+        // every barrier.)
         if (NSL == 1 && SL == 0 && more_a) ry_own_dma_landed<AFLY>(); else ry_own_dma_landed<0>();
         ry_lds_barrier();      // this wave's fragment reads are done (lgkmcnt), every wave's filters landed: the buffers of iteration k are free again
     };

@@ -1,5 +1,7 @@
-// ry_net.cpp -- the predictor C ABI of libry355.so (include/ry355.h): context and predictor lifetime, dtype modes, the forward / convert entry points, profiling
-// and planner debug hooks.  Planner: ry_plan.cpp; kernels + launchers + single operators: ry_exec.cpp; shared declarations: ry_plan.h / ry_host.h; window call: ry_vc.cpp.
+// ry_net.cpp -- the predictor C ABI of libry355.so (include/ry355.h): context and predictor lifetime, dtype modes, the forward / convert entry
+// points, profiling
+// and planner debug hooks.  Planner: ry_plan.cpp; kernels + launchers + single operators: ry_exec.cpp; shared declarations: ry_plan.h / ry_host.h;
+// window call: ry_vc.cpp.
 //
 // Build (product): hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -c <each unit>, linked into libry355.so   (realtime_yukarin_amd/build.py)
 // Build (test emulator, no GPU): clang++ -x c++ -DRY_HOST_EMU ... the same units + tests/emu/ry_emu.cpp

@@ -186,7 +186,8 @@ static bool igemm_eligible(const Layer& l) {
 // 4 * (lane / 4) + t of the block for the t-th v_mfma_f32_4x4x1_16B_f32 of the unit.  Consecutive (tap, chunk) units of one channel
 // group are consecutive KiB: a wave streams its run of the K axis as one contiguous range.
 static bool c2d_os_eligible(const Layer& l) {
-    return l.cin_a % 256 == 0 && l.cin_b % 256 == 0 && l.cout % 4 == 0 && l.cin() > 0 && l.cin_a <= 2048 && l.cin_b <= 2048;    // (rounds of four 64-channel units inside one source; a source's zero pixel is ZTAIL floats)
+    // (rounds of four 64-channel units inside one source; a source's zero pixel is ZTAIL floats)
+    return l.cin_a % 256 == 0 && l.cin_b % 256 == 0 && l.cout % 4 == 0 && l.cin() > 0 && l.cin_a <= 2048 && l.cin_b <= 2048;
 }
 
 static void relayout_c2d_os(const Layer& l, const float* W, std::vector<float>& out) {
@@ -247,8 +248,9 @@ int prepare_layer(ry_ctx* ctx, Arena& arena, Layer& l, int ndim, float eps, cons
     return RY_OK;
 }
 
-static int g_poison = 0;               // RY_POISON=1 (diagnostics): fresh activation buffers are filled with NaN patterns, so that a kernel that reads a row / pixel its producer
-                                       // never wrote shows up as NaN in the result instead of depending on what the allocator handed out
+// RY_POISON=1 (diagnostics): fresh activation buffers are filled with NaN patterns, so that a kernel that reads a row / pixel its producer
+// never wrote shows up as NaN in the result instead of depending on what the allocator handed out
+static int g_poison = 0;
 int alloc_ztail(ry_ctx* ctx, Arena& arena, float** p, size_t nfloats) {
     RY_TRY(arena.alloc(p, nfloats + ZTAIL));
     if (g_poison) RT_TRY(rt::dmemset(*p, 0xFF, nfloats * sizeof(float), ctx->stream));
@@ -271,10 +273,16 @@ void tile_dims(int tile, int* bm, int* bn) {
 // Process-wide switches (INTEGRATION.md section 6 lists every one).  Round 3 removed the A/B switches of closed experiments (register-staged
 // kernel, 256-row tiles, burst loads, raster tiles, two-graph cut + stagger, stage-1 tuning aids, ...): their measurements are in DESIGN.md.
 int g_s2_hole = 1;     // RY_S2_HOLE=0: the encoder computes the identical padding rows behind the real frames instead of copying them (A/B, bit-identity tests)
-int g_s2_crop = 2;     // RY_S2_CROP=0: every decoder layer of the convert wrapper computes all padded rows (A/B of the dead-row crop, used by the bit-identity tests); 1: only grids of more than one workgroup per CU
+// RY_S2_CROP=0: every decoder layer of the convert wrapper computes all padded rows (A/B of the dead-row crop, used by the bit-identity tests); 1:
+// only grids of more than one workgroup per CU
+int g_s2_crop = 2;
 int g_force[16][3];    // RY_PLAN="layer:tile:splits:kgroups,...": tuning aid, fixes the stage-2 plan of single layers (0 = planner's choice)
-int g_x3_min_m = 128;  // RY_X3_MINM: split-bf16 mode runs a layer on the bf16 pipe from this many GEMM rows (per phase) up (measured at 300 frames: 1 / 32 / 64 / 128 / 512 / 2048 -> 0.861 / 0.865 / 0.867 / 0.864 vs 0.840 / 0.928 ms per step on two boxes; 128 beat 512 by 1 % in the same-box A/B)
-int g_autotune = 0;    // RY_AUTOTUNE="1[:reps[:max[:pick]]]": time candidate launch plans of every stage-2 implicit-GEMM layer on the device when a plan is built (autotune_plan)
+// RY_X3_MINM: split-bf16 mode runs a layer on the bf16 pipe from this many GEMM rows (per phase) up (measured at 300 frames: 1 / 32 / 64 / 128 / 512
+// / 2048 -> 0.861 / 0.865 / 0.867 / 0.864 vs 0.840 / 0.928 ms per step on two boxes; 128 beat 512 by 1 % in the same-box A/B)
+int g_x3_min_m = 128;
+// RY_AUTOTUNE="1[:reps[:max[:pick]]]": time candidate launch plans of every stage-2 implicit-GEMM layer on the device when a plan is built
+// (autotune_plan)
+int g_autotune = 0;
 int g_autotune_reps = 3, g_autotune_max = 0;   // ... timed rounds per candidate; cap on the candidates per layer (0 = all; tests)
 int g_autotune_pick = -1;                      // ... (tests only) take candidate `pick` of every layer instead of the fastest
 // Kernel names as rocprofv3 prints them (template arguments, no spaces): bench.py matches them against profiles/*.
@@ -342,7 +350,8 @@ static int best_split(long blocks, int bm, int bn, int nk, bool tinyM, int occ, 
     int best = 1; double bt = 1e30;
     for (int s = 1; s <= smax && s <= (nk >= min_chunks ? nk / min_chunks : 1); ++s) {
         double t;
-        if (tinyM) { const long g = blocks * s; t = g >= 512 ? 1.0 + 1e-4 * s : 512.0 / (double)g; }   // weight streaming: two workgroups per CU keep enough loads in flight (1024 measured 30 % slower: more slabs, same bandwidth)
+        // weight streaming: two workgroups per CU keep enough loads in flight (1024 measured 30 % slower: more slabs, same bandwidth)
+        if (tinyM) { const long g = blocks * s; t = g >= 512 ? 1.0 + 1e-4 * s : 512.0 / (double)g; }
         else t = est_time(blocks, bm, bn, s, occ, kg, M, N, nk);
         if (t < bt - 1e-9) { bt = t; best = s; }
     }
@@ -419,15 +428,19 @@ static bool os2_has_config(int mt4, int nt4, int waves, int depth) {
     return false;
 }
 
-static int g_os2_maxcost = 4608;       // RY_OS2_MAXCOST: a layer with the ry_c2d_os filter layout runs output-stationary when slice cost x K units stays below this (0: never).
-                                       // Fitted: encoder c6 / decoder c1 at 300 frames (4096) win by 2-4 us, encoder c5 at 300 frames (10240) and decoder c2 at 100 frames (8192) lose by 8-11
-static int g_os2_force[16][4];         // RY_OS2="layer:mt4:nt4:waves:depth,...": tuning aid, fixes the slice of single layers ("layer:0" keeps that layer on the implicit GEMM)
+// RY_OS2_MAXCOST: a layer with the ry_c2d_os filter layout runs output-stationary when slice cost x K units stays below this (0: never).
+// Fitted: encoder c6 / decoder c1 at 300 frames (4096) win by 2-4 us, encoder c5 at 300 frames (10240) and
+// decoder c2 at 100 frames (8192) lose by 8-11
+static int g_os2_maxcost = 4608;
+// RY_OS2="layer:mt4:nt4:waves:depth,...": tuning aid, fixes the slice of single layers ("layer:0" keeps that layer on the implicit GEMM)
+static int g_os2_force[16][4];
 static bool g_os2_forced[16];
 
 // Slice of one layer, by a cost fitted to the slice sweeps on the MI355X (profiles/r05/e_os_sweep_n{300,100}.txt): a workgroup pulls K x (rows +
 // channels) of its tile through its CU's L1, the pixel rows at about half the rate of the filter rows (a wave-load of pixels is four
 // 256-byte pieces of four different pixels, a wave-load of filters one contiguous KiB), and the launch takes as many rounds as there are
-// workgroups per CU.  cost = max(1, workgroups / 256) x (2 rows + channels) of the tile (1.5 rows where the pixels travel by DMA); the sweeps rank the slices of every bottom layer in this
+// workgroups per CU.  cost = max(1, workgroups / 256) x (2 rows + channels) of the tile (1.5 rows where the pixels travel by DMA); the sweeps rank
+// the slices of every bottom layer in this
 // order (encoder c7: 4 x 8 < 8 x 4 < 4 x 4 < 12 x 4; decoder c1: 24 x 16 < 12 x 16 < 8 x 16 < 16 x 16).  `cost_out` x K units is what the
 // caller compares with the implicit GEMM (g_os2_maxcost).
 bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int* waves, int* depth, double* cost_out) {
@@ -447,12 +460,15 @@ bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int* waves
                 if ((*waves != 0 && *waves != cw) || (*depth != 0 && *depth != cd) || U % (4 * cw) != 0 || !os2_has_config(m, n, cw, cd)) continue;
                 w = cw; d = cd;
             }
-            if (w == 0 && *waves != 0 && *depth != 0)                    // a forced pair outside the preference lists (only one of the two forced and no preferred pair fits: no plan)
+            // a forced pair outside the preference lists (only one of the two forced and no preferred pair fits: no plan)
+            if (w == 0 && *waves != 0 && *depth != 0)
                 if (U % (4 * *waves) == 0 && os2_has_config(m, n, *waves, *depth)) { w = *waves; d = *depth; }
             if (w == 0) continue;
             const double wgs = (double)((M + 4 * m - 1) / (4 * m)) * (N / (4 * n)) * nphases;
-            const double px = os2_xl_ok(m, w, d) ? 6.0 : 8.0;      // pixel rows by DMA through the LDS: contiguous 256-byte pieces (encoder c6: 12 x 8 ahead of 8 x 16)
-            const double cost = (wgs > 256.0 ? wgs / 256.0 : 1.0) * (px * m + 4.0 * n) * ((double)((M + 4 * m - 1) / (4 * m)) * 4 * m / M);   // padded rows are loaded too
+            // pixel rows by DMA through the LDS: contiguous 256-byte pieces (encoder c6: 12 x 8 ahead of 8 x 16)
+            const double px = os2_xl_ok(m, w, d) ? 6.0 : 8.0;
+            // padded rows are loaded too
+            const double cost = (wgs > 256.0 ? wgs / 256.0 : 1.0) * (px * m + 4.0 * n) * ((double)((M + 4 * m - 1) / (4 * m)) * 4 * m / M);
             if (cost < best - 1e-9) { best = cost; bm = m; bn = n; bw = w; bd = d; }
         }
     if (bm == 0) return false;
@@ -465,8 +481,11 @@ bool choose_os2(int M, int N, int nphases, int U, int* mt4, int* nt4, int* waves
 // Workgroup shapes: cfg 1 = 2 x 2 waves (two M-blocks of 8 x 16 pixels x 64 channels, one 8-channel slice per iteration, 74 KiB of LDS: two per CU),
 // cfg 2 = 4 x 2 waves (four M-blocks x 64 channels, two slices per iteration, 146 KiB: one per CU).  mbw = M-blocks per tile row.
 static int g_wino = 1;                 // RY_WINOGRAD=0: every layer keeps the direct implicit GEMM (the bit-exact reference of the Winograd form; A/B)
-static int g_wino_min_m = 256;         // RY_WINO_MINM: rows (pixels of one phase) from which an eligible layer takes the Winograd form (512 -> 256: encoder c4 / decoder c3 of the 100-frame window, 231.8 -> 240.9 k frames/s)
-static int g_wino_force[16][3];        // RY_WINO="layer:cfg:mbw:splits,...": tuning aid, fixes the Winograd plan of single layers ("layer:0" keeps that layer on the direct kernel)
+// RY_WINO_MINM: rows (pixels of one phase) from which an eligible layer takes the Winograd form (512 -> 256: encoder c4 / decoder c3 of the 100-frame
+// window, 231.8 -> 240.9 k frames/s)
+static int g_wino_min_m = 256;
+// RY_WINO="layer:cfg:mbw:splits,...": tuning aid, fixes the Winograd plan of single layers ("layer:0" keeps that layer on the direct kernel)
+static int g_wino_force[16][3];
 static bool g_wino_forced[16];
 
 bool wino_cfg_dims(int cfg, int* wm, int* wn, int* nsl) {
@@ -499,10 +518,13 @@ bool choose_wino(int Mh, int Mw, int N, int nphases, int npatches, int B, int* c
             if (Mh % th || Mw % tw) continue;
             const long units = (long)B * (Mh / th) * (Mw / tw) * (N / 64) * nphases;
             const int slots = c == 1 ? 512 : 256;
-            const double halo = (double)(th + 1) * (tw + 1) / ((double)th * tw) + 0.006 * th;      // short tiles: the dead-row crop and the copied padding rows round to whole tile rows (8 x 32 against 16 x 16 tiles, two-lane step at 300 frames: encoder -1.1 %, decoder -2.8 %, profiles/r06/plan_ab_mbw.txt)
+            // short tiles: the dead-row crop and the copied padding rows round to whole tile rows (8 x 32 against 16 x 16 tiles, two-lane step at 300
+            // frames: encoder -1.1 %, decoder -2.8 %, profiles/r06/plan_ab_mbw.txt)
+            const double halo = (double)(th + 1) * (tw + 1) / ((double)th * tw) + 0.006 * th;
             for (int sp = 1; sp <= 32 && sp <= npatches; ++sp) {
                 if (*splits != 0 ? *splits != sp : (sp > 1 && sp > npatches / 2)) continue;      // (the planner's own splits leave two patches per workgroup)
-                // rounds of workgroups x iterations of the longest split (+ prologue / epilogue of a workgroup, in iterations) x time of an iteration relative to
+                // rounds of workgroups x iterations of the longest split (+ prologue / epilogue of a workgroup, in iterations) x time of an iteration
+                // relative to
                 // cfg 1 (cfg 2 runs twice the slices on twice the rows per slot), + the slab traffic and the reduce node of an external split
                 const long rounds = (units * sp + slots - 1) / slots;
                 const double its = (double)((npatches + sp - 1) / sp) * 2.0;          // 8-channel slices
@@ -517,7 +539,8 @@ bool choose_wino(int Mh, int Mw, int N, int nphases, int npatches, int B, int* c
     return true;
 }
 
-static const int g_s1_wgs = 256, g_s1_maxs = 32;   // split heuristic of the weight-streaming stage-1 kernels (128 / 16 measured 0.275 ms, 256 / 32 0.231 ms, 512 / 64 0.238 ms per forward)
+// split heuristic of the weight-streaming stage-1 kernels (128 / 16 measured 0.275 ms, 256 / 32 0.231 ms, 512 / 64 0.238 ms per forward)
+static const int g_s1_wgs = 256, g_s1_maxs = 32;
 
 int c1d_mode(const Layer& l) {
     if (l.deconv) return RY_C1D_DECONV;
@@ -544,7 +567,9 @@ int choose_splits_1d(const Layer& l, int B, int rows, int mode) {
 
 
 // ---- stage-1, output-stationary form (ry_c1d_os) ----
-static const int g_s1_units = 256;   // smallest workgroup count a layer should reach before it takes a larger slice per workgroup (128 / 256 / 512 / 1024 measured 0.119 / 0.116 / 0.112 / 0.116 ms)
+// smallest workgroup count a layer should reach before it takes a larger slice per workgroup (128 / 256 / 512 / 1024 measured 0.119 / 0.116 / 0.112 /
+// 0.116 ms)
+static const int g_s1_units = 256;
 
 static bool c1d_os_capable(const Layer& l) {
     const int mode = c1d_mode(l);
@@ -647,7 +672,8 @@ int build_plan(ry_net* net, Plan& P) {
     }
     // buffers
     if (nd == 1) {
-        P.s1_os = true;                                   // the output-stationary kernels whenever every layer can take them (generic stride / dilation / GLU layers: the weight-streaming kernels)
+        // the output-stationary kernels whenever every layer can take them (generic stride / dilation / GLU layers: the weight-streaming kernels)
+        P.s1_os = true;
         for (int i = 0; i < 16; ++i) if (!c1d_os_capable(net->layers[i]) || !net->layers[i].w1os) P.s1_os = false;
         // the pad of the convert wrapper inside the first layer: a stride-1 first layer whose input channels fit one lane set
         P.s1_padfuse = P.s1_os && P.mode == 1 && c1d_mode(net->layers[0]) == RY_C1D_S1 && net->layers[0].cin() <= 64;
@@ -660,7 +686,8 @@ int build_plan(ry_net* net, Plan& P) {
             const int mode = c1d_mode(l);
             lp.os_kt = c1d_os_ktw(l.cin());
             choose_os(l, B, mode == RY_C1D_DECONV ? lp.Wi : lp.Wo, &lp.os_cb, &lp.os_tp);
-            if (l.cin_b > 0 && l.cin_a % 64 != 0) { lp.os_cb = 2; lp.os_tp = 4; }      // sources split inside a wave: the per-lane form exists for this slice only
+            // sources split inside a wave: the per-lane form exists for this slice only
+            if (l.cin_b > 0 && l.cin_a % 64 != 0) { lp.os_cb = 2; lp.os_tp = 4; }
             if (i < 15) RY_TRY(P.arena.alloc(&lp.out, out_elems));          // the last layer stores straight into the caller's block
         } else if (nd == 1) {
             const int mode = c1d_mode(l);
@@ -689,7 +716,8 @@ int build_plan(ry_net* net, Plan& P) {
                 for (int src : {l.src_a, l.src_b}) {
                     if (src < 0) continue;
                     const LayerPlan& sp = P.lp[src];
-                    if (sp.path != PATH_FIRST && sp.path != PATH_IGEMM && sp.path != PATH_IGEMM_BF16 && sp.path != PATH_OS2D) want16 = false;   // that producer cannot write a bf16 copy
+                    // that producer cannot write a bf16 copy
+                    if (sp.path != PATH_FIRST && sp.path != PATH_IGEMM && sp.path != PATH_IGEMM_BF16 && sp.path != PATH_OS2D) want16 = false;
                 }
                 if (l.src_a < 0) want16 = false;
                 if (want16) {
@@ -711,7 +739,8 @@ int build_plan(ry_net* net, Plan& P) {
                         return fail(RY_EINVAL, "RY_OS2: no output-stationary slice %d:%d:%d:%d for %s", c[0], c[1], c[2], c[3], l.name);
                     }
                 }
-                // the MFMA-bound k4 s2 p1 layers: Winograd F(2x2, 2x2), 9 / 16 of the matrix-pipe work -- exact-fp32 mode only (RY_WINOGRAD=0: the direct kernels, bit-exact reference)
+                // the MFMA-bound k4 s2 p1 layers: Winograd F(2x2, 2x2), 9 / 16 of the matrix-pipe work -- exact-fp32 mode only (RY_WINOGRAD=0: the
+                // direct kernels, bit-exact reference)
                 if (lp.path == PATH_IGEMM && net->dtype == 0 && g_wino && wino_eligible(l, 2) && !(g_wino_forced[i] && g_wino_force[i][0] == 0) &&
                     !(g_force[i][0] || g_force[i][1] || g_force[i][2])) {                  // (a layer whose direct plan RY_PLAN fixes stays direct)
                     const int Mh = l.deconv ? lp.Hi : lp.Ho, Mw = l.deconv ? lp.Wi : lp.Wo;
@@ -827,7 +856,8 @@ int read_plan_env() {
 }
 
 int read_env_switches() {
-    g_autotune = 0; g_autotune_reps = 3; g_autotune_max = 0; g_autotune_pick = -1;      // (re-read by ry_debug_reload_env: an absent variable means the defaults)
+    // (re-read by ry_debug_reload_env: an absent variable means the defaults)
+    g_autotune = 0; g_autotune_reps = 3; g_autotune_max = 0; g_autotune_pick = -1;
     if (const char* e = getenv("RY_AUTOTUNE")) {                                        // "1[:reps[:max[:pick]]]"
         int on = 0, reps = 3, mx = 0, pick = -1;
         if (sscanf(e, "%d:%d:%d:%d", &on, &reps, &mx, &pick) < 1) return fail(RY_EINVAL, "RY_AUTOTUNE: expected 1[:reps[:max[:pick]]]");

@@ -49,8 +49,10 @@ static void relayout_wino(const Layer& l, F w, std::vector<float>& out) {
 
 // Activation buffers that an implicit-GEMM layer may read end in ZTAIL zeroed floats: the LDS-DMA kernel fetches its padding
 // from there (RyConvGeom::zoff1 / zoff2); nothing ever writes them.
-static const size_t ZTAIL = 2048;     // (round 5: a whole zeroed PIXEL of up to 2048 channels -- ry_c2d_os fetches out-of-image taps from it at any channel offset)
-static const int g_patch = 3;      // bit 0 = input-patch reuse in the deconvolution layers, bit 1 = in the k4 s2 convolution layers (DESIGN.md 5.1 + section 9: A/B measured, both on)
+// (round 5: a whole zeroed PIXEL of up to 2048 channels -- ry_c2d_os fetches out-of-image taps from it at any channel offset)
+static const size_t ZTAIL = 2048;
+// bit 0 = input-patch reuse in the deconvolution layers, bit 1 = in the k4 s2 convolution layers (DESIGN.md 5.1 + section 9: A/B measured, both on)
+static const int g_patch = 3;
 
 // ---- stage-2 output-stationary layers (ry_c2d_os) ----
 // (MT4, NT4, WAVES, DEPTH): tile of 4 MT4 rows x 4 NT4 output channels per workgroup, WAVES waves that deal the K units among them in rounds

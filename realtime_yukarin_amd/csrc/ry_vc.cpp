@@ -222,7 +222,8 @@ void ry_vc_destroy(ry_vc* vc) {
 // it converts buffer + 2 x extra_time and picks the buffer, convert_stream.py:40-42).  Stage 2 then computes only the rows that are
 // kept -- the decoder layers run on the row range those rows depend on, the encoder and the bottom of the U-Net stay whole -- and the
 // discarded rows of the returned spectrogram are zero for the host-array calls (ry_vc_wait / ry_vc_wait_wave / ry_vc_stage2_from_mc); the
-// device-pointer calls (ry_vc_enqueue_device / _batch) leave the discarded rows of the caller's block UNTOUCHED (no memset is queued).  The kept rows are bit-identical to the full result; mc is always complete.
+// device-pointer calls (ry_vc_enqueue_device / _batch) leave the discarded rows of the caller's block UNTOUCHED (no memset is queued).  The kept rows
+// are bit-identical to the full result; mc is always complete.
 // Applies to every following ry_vc_submit / ry_vc_submit_wave / ry_vc_enqueue_device / ry_vc_enqueue_device_batch until changed; (0, 0) =
 // everything (ry_vc_stage2_from_mc included; ry_vc_mid_sp returns every row of the intermediate spectrogram).
 int ry_vc_set_discard(ry_vc* vc, int front, int back) {
