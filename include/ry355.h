@@ -241,6 +241,13 @@ int ry_debug_plan_igemm_bf16(int mode, int M, int Cout, int nphases, int nk, int
  * are kept.  Returns RY_EINVAL when no slice fits the shape.  No device work. */
 int ry_debug_plan_os2(int M, int Cout, int nphases, int units, int* mt4, int* nt4, int* waves, int* depth, double* cost);
 
+/* diagnostics: the plan the planner picks for a k4 s2 p1 stage-2 layer in Winograd F(2x2, 2x2) form (ry_wino_ldsdma, round 6) whose stencil output grid is
+ * Mh x Mw pixels per phase and window, with Cout output channels, `nphases` phases (4: transposed convolution, 1: convolution), K = 16 * npatches input
+ * channels (x 4 parities for a convolution: count them in npatches) and `batch` windows: workgroup shape (1 = 2 x 2 waves, 2 = 4 x 2 waves), M-blocks of
+ * 8 x 16 pixels per tile row, external split-K.  Non-zero values on entry are kept.  Returns RY_EINVAL when no tile of a shape divides the grid (the layer
+ * then stays on the direct implicit GEMM).  No device work. */
+int ry_debug_plan_wino(int Mh, int Mw, int Cout, int nphases, int npatches, int batch, int* cfg, int* mbw, int* splits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,7 +51,7 @@ ABI_SYMBOLS = (
     'ry_init', 'ry_shutdown', 'ry_sync', 'ry_stream', 'ry_device_count', 'ry_last_error',
     'ry_net_param_count', 'ry_net_create', 'ry_net_destroy', 'ry_net_clone', 'ry_net_set_dtype', 'ry_net_forward',
     'ry_ac_convert', 'ry_sr_convert', 'ry_sr_convert_rows', 'ry_conv1d', 'ry_conv2d', 'ry_conv2d_dilated',
-    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_net_profile_window', 'ry_debug_plan_igemm', 'ry_debug_reload_env', 'ry_debug_stream_overlap', 'ry_debug_plan_igemm_bf16', 'ry_debug_plan_os2',
+    'ry_timer_start', 'ry_timer_stop', 'ry_net_profile', 'ry_net_profile_window', 'ry_debug_plan_igemm', 'ry_debug_reload_env', 'ry_debug_stream_overlap', 'ry_debug_plan_igemm_bf16', 'ry_debug_plan_os2', 'ry_debug_plan_wino',
     'ry_vc_create', 'ry_vc_destroy', 'ry_vc_convert', 'ry_mc2sp',
     'ry_vc_submit', 'ry_vc_set_lanes', 'ry_vc_set_discard', 'ry_vc_wait', 'ry_vc_enqueue_device', 'ry_vc_enqueue_device_batch', 'ry_vc_stage1', 'ry_vc_stage2_from_mc', 'ry_vc_mid_sp', 'ry_vc_reserve_frames',
     'ry_vc_submit_wave', 'ry_vc_wait_wave', 'ry_vc_gate',

@@ -63,7 +63,7 @@ def build_product(force: bool = False, defs=(), suffix: str = '') -> Path:
 
 def build_emu(force: bool = False, defs=(), suffix: str = '', sanitize: bool = False) -> Path:
     """Same sources as plain C++ on the fiber SIMT emulator (tests/emu) -- test infrastructure only.
-    sanitize=True: AddressSanitizer + UndefinedBehaviorSanitizer over the host executor (ry_net.cpp / ry_vc.cpp: plans, LRU graph slots, pointer
+    sanitize=True: AddressSanitizer + UndefinedBehaviorSanitizer over the host planner / executor (ry_plan.cpp / ry_exec.cpp / ry_vc.cpp: plans, LRU graph slots, pointer
     arithmetic) and the kernels' index arithmetic -> tests/emu/libry355_emu_asan.so, run by scripts/asan_emu.sh."""
     if sanitize:
         suffix = suffix or '_asan'

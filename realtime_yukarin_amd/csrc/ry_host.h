@@ -1,6 +1,8 @@
 // ry_host.h -- what the translation units of libry355.so share on the host side: the runtime shim (HIP in the product, malloc / memcpy
 // under the test emulator), status codes + message, and the executor's data structures (context, arena, layer, launch plan, predictor).
-//   ry_net.cpp   topology, filter re-layout, the stage-2 planner, launch helpers, plans + graphs, the predictor API, single operators
+//   ry_plan.cpp  topology, filter re-layout, the launch planner and its switches (no device code; declarations shared with the next two: ry_plan.h)
+//   ry_exec.cpp  the kernels (ry_kernels.h), their launchers, the captured forward, autotune, profiling, the single operators
+//   ry_net.cpp   the predictor C ABI: context / predictor lifetime, dtype modes, forward / convert entry points, debug hooks
 //   ry_vc.cpp    the window call (ring slots, lanes, silence gate, batch) = VoiceChanger.convert_from_acoustic_feature on the device
 //   ry_comm.cpp  RCCL bound at run time (weight broadcast, barrier, max) and plain device buffers for callers without a tensor library
 #pragma once

@@ -152,7 +152,7 @@ struct RyIgemmParams {
 //     position q of row r fetches slot q ^ f(r).
 //     PATCH = 0: every tap gathers its own BM rows.  PATCH = 1 / 2: the taps of a deconvolution phase / of one input parity
 //     of a k4 s2 convolution read one shared (BM / 16 + 1) x 17-pixel patch at compile-time row offsets (see below).
-//   B (filters): stored in fragment order by the host (ry_net.cpp: wig_inblock / wig16_inblock), one 1-KiB piece per
+//   B (filters): stored in fragment order by the host (ry_plan.cpp: wig_inblock / wig16_inblock), one 1-KiB piece per
 //     (32 columns, K step); copied as is, read back lane-linearly.
 // Buffers are double, held in DISTINCT __shared__ arrays with loops unrolled so that every buffer index is static: the
 // compiler's LDS-DMA alias tracking then does not order the reads of one buffer behind the DMA into the other.

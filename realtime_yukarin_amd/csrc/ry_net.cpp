@@ -1,7 +1,6 @@
-// ry_net.cpp -- the predictor C ABI of libry355.so (include/ry355.h): context and predictor lifetime, dtype modes, the forward / convert entry
-// points, profiling
-// and planner debug hooks.  Planner: ry_plan.cpp; kernels + launchers + single operators: ry_exec.cpp; shared declarations: ry_plan.h / ry_host.h;
-// window call: ry_vc.cpp.
+// ry_net.cpp -- the predictor C ABI of libry355.so (include/ry355.h): context and predictor lifetime, dtype modes, the forward / convert entry points,
+// profiling and planner debug hooks.  Planner: ry_plan.cpp; kernels + launchers + single operators: ry_exec.cpp; shared declarations: ry_plan.h /
+// ry_host.h; window call: ry_vc.cpp.
 //
 // Build (product): hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -c <each unit>, linked into libry355.so   (realtime_yukarin_amd/build.py)
 // Build (test emulator, no GPU): clang++ -x c++ -DRY_HOST_EMU ... the same units + tests/emu/ry_emu.cpp
@@ -323,6 +322,13 @@ int ry_debug_plan_os2(int M, int Cout, int nphases, int units, int* mt4, int* nt
     if (M < 1 || Cout < 4 || Cout % 4 != 0 || nphases < 1 || units < 1) return fail(RY_EINVAL, "not an output-stationary layer shape");
     if (!choose_os2(M, Cout, nphases, units, mt4, nt4, waves, depth, cost))
         return fail(RY_EINVAL, "no output-stationary slice for %d rows x %d channels x %d units", M, Cout, units);
+    return RY_OK;
+}
+
+int ry_debug_plan_wino(int Mh, int Mw, int Cout, int nphases, int npatches, int batch, int* cfg, int* mbw, int* splits) {
+    if (!cfg || !mbw || !splits) return fail(RY_EINVAL, "null argument");
+    if (Mh < 1 || Mw < 1 || Cout < 64 || Cout % 64 || (nphases != 1 && nphases != 4) || npatches < 1 || batch < 1) return fail(RY_EINVAL, "not a Winograd layer shape");
+    if (!choose_wino(Mh, Mw, Cout, nphases, npatches, batch, cfg, mbw, splits)) return fail(RY_EINVAL, "no Winograd tile divides a %d x %d grid", Mh, Mw);
     return RY_OK;
 }
 

@@ -7,7 +7,7 @@ The reference builds both predictors inside un-vendored dependencies
 restates the topology as data: an ordered K-list of
 Chainer `save_npz` keys with shapes.  The flat weight blob handed to the C-ABI
 (`ry_net_create`, include/ry355.h) is the concatenation of these arrays in exactly this order;
-`csrc/ry_net.cpp` derives the same order from the same five integers and both sides cross-check
+`csrc/ry_plan.cpp` derives the same order from the same five integers and both sides cross-check
 the element count.
 """
 from dataclasses import dataclass

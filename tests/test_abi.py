@@ -140,6 +140,33 @@ def test_output_stationary_planner_follows_the_measured_ranking(lib):
     assert f(12, 512, 1, 6, ctypes.byref(a), ctypes.byref(b), ctypes.byref(w), ctypes.byref(d), None) != 0      # 6 units: no whole rounds of four per wave
 
 
+def test_winograd_planner_prefers_short_tiles_and_refuses_grids_no_tile_divides(lib):
+    """choose_wino (round 6): (stencil grid per phase, channels, phases, patches of 16 input channels) -> (workgroup shape, M-blocks per tile row, split).
+    Short tiles win where both divide the grid -- the dead-row crop and the copied padding rows round to whole tile rows (8 x 32 against 16 x 16 pixels:
+    two-lane step -1.1 % encoder, -2.8 % decoder, profiles/r06/plan_ab_mbw.txt); decoder c5 of the 300-frame window stays unsplit (a 3-way split is 25 us
+    faster alone and 1.5 - 3.7 % slower under two lanes, profiles/r06/wino_lanes_sweep_n300.txt); the 12 x 16 grids of encoder c5 / decoder c2 have no tile."""
+    def plan(Mh, Mw, N, nph, npat, B=1, cfg=0, mbw=0, sp=0):
+        c, m, s_ = ctypes.c_int(cfg), ctypes.c_int(mbw), ctypes.c_int(sp)
+        rc = lib.dll.ry_debug_plan_wino(Mh, Mw, N, nph, npat, B, ctypes.byref(c), ctypes.byref(m), ctypes.byref(s_))
+        return rc, c.value, m.value, s_.value
+    # SYN-64 at 384 padded frames: encoder c1 .. c4 (convolutions: 4 parities x Cin / 16 patches), decoder c3 .. c6 (4 phases)
+    layers = dict(e1=(192, 256, 128, 1, 16), e2=(96, 128, 256, 1, 32), e3=(48, 64, 512, 1, 64), e4=(24, 32, 1024, 1, 128),
+                  d3=(24, 32, 512, 4, 64), d4=(48, 64, 256, 4, 64), d5=(96, 128, 128, 4, 32), d6=(192, 256, 64, 4, 16))
+    got = {k: plan(*v) for k, v in layers.items()}
+    assert all(rc == 0 for rc, *_ in got.values()), got
+    for k, (rc, cfg, mbw, sp) in got.items():
+        th = 8 * ((2 if cfg == 1 else 4) // mbw)
+        assert th == 8, (k, got[k])                                   # 8-row tiles everywhere
+        assert 1 <= sp <= layers[k][4]
+    assert got['d5'][3] == 1 and got['d6'][3] == 1 and got['e1'][3] == 1          # enough tiles of their own: no slabs
+    assert got['e3'][3] > 1 and got['e4'][3] > 1 and got['d3'][3] > 1             # deep K, few tiles: split
+    assert plan(12, 16, 1024, 1, 256)[0] != 0 and plan(12, 16, 512, 4, 128)[0] != 0          # encoder c5 / decoder c2: no Winograd tile divides 12 x 16
+    assert plan(24, 32, 512, 4, 64, cfg=2)[0] != 0                                # the eight-wave shape has no tile for 24 x 32 either
+    rc, cfg, mbw, sp = plan(96, 128, 128, 4, 32, cfg=1, mbw=1, sp=3)              # forced values are kept
+    assert (rc, cfg, mbw, sp) == (0, 1, 1, 3)
+    assert lib.dll.ry_debug_plan_wino(96, 128, 100, 4, 32, 1, None, None, None) != 0
+
+
 def test_stage2_planner_near_tie_goes_to_the_small_workgroup(lib):
     """Round 5: where slabs are needed anyway, two K groups per workgroup (125 KiB of LDS: nothing fits beside it on a CU) must beat the external-split-only
     form (62 KiB) by more than 1 % of the estimate.  At 300 / 400 frames that is decoder c3 (768 / 1024 rows per phase, 512 channels, 128 K chunks):
