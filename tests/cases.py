@@ -318,3 +318,27 @@ def poisoned_converts(ctx, net, sizes, monkeypatch, modes=('f32', 'bf16', 'bf16x
         monkeypatch.delenv('RY_POISON', raising=False); reread()
         net.set_dtype('f32')
     return out
+
+
+def wino_properties(ctx, shape, transposed):
+    """Size-independent properties of the Winograd operator (`path='wino'`, no activation: the operator is affine in its input) at any layer size:
+    affinity y(x1 + x2) + y(0) = y(x1) + y(x2); equivariance -- the input shifted by two rows / columns (one for a transposed convolution) gives the
+    output shifted by one (two) away from the borders: every pixel then falls on ANOTHER position of its Winograd tile or on another tile; external
+    split-K sums the same products in another order.  Returns the three relative errors (the scale is max |y(x1)|)."""
+    B, H, Wd, Cin, Cout = shape
+    rng = numpy.random.default_rng(97)
+    x1 = rng.normal(size=(B, H, Wd, Cin)).astype('f4'); x2 = rng.normal(size=(B, H, Wd, Cin)).astype('f4')
+    Wt = rng.normal(0, 0.05, size=(Cin, Cout, 4, 4) if transposed else (Cout, Cin, 4, 4)).astype('f4')
+    b = rng.normal(0, 0.1, Cout).astype('f4')
+    kw = dict(stride=2, pad=1, transposed=transposed, act=None, path='wino')
+    f = lambda x, **k: ctx.conv2d(x, Wt, b, None, **dict(kw, **k)).astype(numpy.float64)
+    y1, y2, y12, y0 = f(x1), f(x2), f(x1 + x2), f(numpy.zeros_like(x1))
+    scale = float(numpy.abs(y1).max())
+    e_aff = float(numpy.abs(y12 + y0 - y1 - y2).max()) / scale
+    si, so = (1, 2) if transposed else (2, 1)                       # input shift -> output shift
+    xs = numpy.zeros_like(x1); xs[:, si:, si:] = x1[:, :-si, :-si]
+    ys = f(xs)
+    m = 2 * so + 2                                                  # margin: pixels whose stencil touches the border or the shifted-in zeros
+    e_eq = float(numpy.abs(ys[:, so + m:-m, so + m:-m] - y1[:, m:-so - m, m:-so - m]).max()) / scale
+    e_split = float(numpy.abs(f(x1, splits=3) - y1).max()) / scale
+    return e_aff, e_eq, e_split

@@ -114,6 +114,16 @@ def test_conv2d_wino_vs_direct_gpu(gpu_ctx, transposed):
     assert err < 1e-5 and scale > 0.1, (err, scale)
 
 
+@pytest.mark.parametrize('shape,transposed', [((1, 96, 128, 512, 128), True), ((1, 48, 64, 1024, 256), True), ((1, 192, 256, 128, 256), False), ((2, 96, 128, 256, 512), False)],
+                         ids=['decoder_c5', 'decoder_c4', 'encoder_c2', 'encoder_c3_two_windows'])
+def test_conv2d_wino_properties_full_size_gpu(gpu_ctx, shape, transposed):
+    """Size-independent properties at BASELINE layer sizes (where the float64 oracle takes minutes): the Winograd operator is affine in its input, commutes
+    with shifts of the image (every pixel then sits on another position of its 2 x 2 tile or on another tile) and does not depend on the external split
+    beyond the summation order."""
+    e_aff, e_eq, e_split = cases.wino_properties(gpu_ctx, shape, transposed)
+    assert e_aff < 1e-5 and e_eq < 1e-5 and e_split < 1e-5, (e_aff, e_eq, e_split)        # (four float32 results of K = 2048 .. 4096 products each: measured 1.5e-6 .. 3.2e-6)
+
+
 WINO_FULL_SIZE = [        # the eight MFMA-bound layers of SYN-64 at the 300-frame window (T = 384), the planner's plan: B, H, W, Cin, Cout, transposed
     (1, 384, 512, 64, 128, False), (1, 192, 256, 128, 256, False), (1, 96, 128, 256, 512, False), (1, 48, 64, 512, 512, False),      # encoder c1 .. c4
     (1, 24, 32, 1024, 512, True), (1, 48, 64, 1024, 256, True), (1, 96, 128, 512, 128, True), (1, 192, 256, 256, 64, True),          # decoder c3 .. c6

@@ -56,6 +56,14 @@ def test_conv2d_wino_vs_direct_emu(emu_ctx, transposed):
     assert err < 1e-5 and scale > 0.1, (err, scale)
 
 
+@pytest.mark.parametrize('transposed', [True, False])
+def test_conv2d_wino_properties_emu(emu_ctx, transposed):
+    """affinity, shift equivariance and split invariance of the Winograd operator (small size; `-m gpu` runs the BASELINE layer sizes)"""
+    shape = (1, 16, 32, 48, 64) if transposed else (1, 32, 64, 32, 64)
+    e = cases.wino_properties(emu_ctx, shape, transposed)
+    assert max(e) < 2e-6, e
+
+
 @pytest.mark.parametrize('case', cases.CONV2D_DILATED_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
 def test_conv2d_dilated_emu(emu_ctx, case):
     y, r = cases.run_conv2d_dilated(emu_ctx, numpy.random.default_rng(19), case, bn_params)
